@@ -1,0 +1,170 @@
+/*
+ * mquant_hip.h -- C ABI of the MI355X (gfx950) W4A8 static-quant hot path.
+ *
+ * This is the drop-in boundary.  The reference (StiphyJay/MQuant) has no native
+ * code of its own: its hot path is Python calling torch ops plus ONE third-party
+ * CUDA extension (fast_hadamard_transform).  Each entry point below replaces the
+ * chain of reference calls cited next to it (paths relative to the reference
+ * tree); INTEGRATION.md shows the ctypes binding a maintainer adds on the
+ * reference side.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - every pointer is a DEVICE pointer unless its name ends in _host.
+ *   - stream is a hipStream_t passed as void* (NULL = default stream); all work is
+ *     stream-ordered, nothing synchronises, nothing allocates; re-entrant.
+ *   - return value: 0 on success; >0 a hipError_t; <0 an argument error
+ *     (MQ_EINVAL...).  mq_last_error() returns a thread-local message.
+ *   - dtype codes: MQ_F16 / MQ_BF16 / MQ_F32 for activations and outputs.
+ *   - bit-exactness contract: integer outputs (int8 levels, int32 accumulators,
+ *     packed nibbles) equal oracle/mq_oracle.c bit for bit; fp outputs are
+ *     computed with the same single-rounded fp32 operations as the oracle.
+ */
+#ifndef MQUANT_HIP_H
+#define MQUANT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MQ_F16 0
+#define MQ_BF16 1
+#define MQ_F32 2
+
+#define MQ_OK 0
+#define MQ_EINVAL (-1)      /* bad argument (shape / alignment / dtype)          */
+#define MQ_EUNSUPPORTED (-2) /* valid request this build does not implement       */
+
+/* Geometry of the pre-tiled weight image consumed by mq_gemm_w4a8. */
+#define MQ_W_TILE_N 16   /* output channels per MFMA fragment                     */
+#define MQ_W_TILE_K 128  /* reduction elements per fragment pair (2 x K=64 MFMAs) */
+
+int mq_version(void);
+const char *mq_last_error(void);
+
+/* Name and compute-unit count of the current device (host strings/ints). */
+int mq_device_info(char *name_host, size_t name_len, int *cu_count_host);
+
+/* ---------------------------------------------------------------------------
+ * Static activation quantizer: fp -> int8 levels.
+ * Replaces UniformQuantizer.quant on the static path
+ *   fake_quant/quantizer/uniform.py:20-33, fake_quant/quantizer/base.py:44-50
+ *   (called from ActQuantWrapper.forward, fake_quant/quant_utils.py:378-383).
+ *   q = clamp(rint(float(x) / s), -128, 127), IEEE division, round-half-even.
+ * x: [M, K] row-major with leading dimension ldx (elements).
+ * out: [M, K_pad] int8 row-major, leading dimension ldo (bytes) >= K_pad; columns
+ *      K..K_pad-1 are written as 0 so the GEMM can consume whole 128-wide tiles.
+ * Scale selection:
+ *   scale_vec0 == NULL: per-tensor scales passed by value (scale0 / scale1);
+ *   scale_vec0 != NULL: per-channel scales [K] (calibration_mode="channel_wise").
+ *   row_sel == NULL: every row uses set 0; else row_sel[m] in {0,1} picks the set
+ *   (Modality-Specific Static Quantization: vision vs. text rows).
+ * skip_col0 != 0 implements ActQuantWrapper.split (quant_utils.py:367-376): channel 0
+ *   bypasses the quantizer: out[:,0] = 0 and x0_out[m] = float(x[m,0]).
+ * ------------------------------------------------------------------------- */
+int mq_quantize_act_i8(const void *x, int x_dtype, long M, long K, long ldx,
+                       float scale0, float scale1,
+                       const float *scale_vec0, const float *scale_vec1,
+                       const uint8_t *row_sel, int skip_col0, float *x0_out,
+                       int8_t *out, long K_pad, long ldo, void *stream);
+
+/* Fused quantize->dequantize in x's dtype (the reference's simulated form,
+ * uniform.py:20-43 + base.py:44-50), used when weights stay in floating point. */
+int mq_fakequant_act(const void *x, int x_dtype, long M, long K, long ldx,
+                     float scale0, float scale1,
+                     const float *scale_vec0, const float *scale_vec1,
+                     const uint8_t *row_sel, int skip_col0,
+                     void *out, long ldo, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Online Hadamard rotation, optionally fused with the static quantizer.
+ * Replaces revise_down_input + matmul_hadU_cuda (+ UniformQuantizer.quant):
+ *   fake_quant/utils.py:465-471, fake_quant/hadamard_utils.py:115-128,
+ *   fake_quant/quant_utils.py:334-341 (and :378-383 when quantizing).
+ *   y = (H_K (x) H_{n/K}) [x ; 0] / sqrt(n),  flat index = k*(n/K) + j.
+ * x: [M, n_in] (n_in <= n: zero padded up to n, the forward-pre-hook's job).
+ * had_bits: K*K sign bits of hadK, row-major, bit=1 means +1, packed MSB-first
+ *           per byte (numpy.packbits order); NULL when K == 1.
+ * fp32_had: 0 = the extension's behaviour for half inputs (butterflies in fp32,
+ *           result rounded to x's dtype before the K x K stage and again after),
+ *           1 = --fp32_had (fp32 throughout, one final cast to x's dtype).
+ * The K x K stage accumulates in ascending k as a single fp32 chain (oracle step 4).
+ *
+ * mq_hadamard:        writes the rotated activations in x's dtype, [M, n].
+ * mq_hadamard_quant_i8: writes int8 levels like mq_quantize_act_i8 (same scale /
+ *           row_sel / skip_col0 / x0_out semantics); the rotated activations never
+ *           reach HBM.
+ * ------------------------------------------------------------------------- */
+int mq_hadamard(const void *x, int x_dtype, long M, long n_in, long ldx,
+                long n, int K, const uint8_t *had_bits, int fp32_had,
+                void *out, long ldo, void *stream);
+
+int mq_hadamard_quant_i8(const void *x, int x_dtype, long M, long n_in, long ldx,
+                         long n, int K, const uint8_t *had_bits, int fp32_had,
+                         float scale0, float scale1, const uint8_t *row_sel,
+                         int skip_col0, float *x0_out,
+                         int8_t *out, long K_pad, long ldo, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Weight formats.
+ * mq_pack_i4 / mq_unpack_i4: the reference wire format, quant_utils.py:61-94
+ *   (two's-complement nibbles, even index -> low nibble, along the last dim).
+ * mq_weight_levels: integer levels of a fake-quantized weight,
+ *   q[n][k] = clamp(rint(float(w[n][k]) / scale[n]), lo, hi)
+ *   (the inverse of WeightQuantizer.quantize, quant_utils.py:42-45,512-518).
+ * mq_prepack_w4 / mq_prepack_w8: re-tile int levels [N, K] into the image the GEMM
+ *   streams straight into LDS (layout in DESIGN.md).  N_pad = ceil16(N),
+ *   K_pad = ceil128(K); padding is zero.  Output bytes: N_pad*K_pad/2 (w4),
+ *   N_pad*K_pad (w8).  zero_col0 clears column 0 (ActQuantWrapper.split: L2 has no
+ *   column for the bypassed channel, quant_utils.py:320-326).
+ * ------------------------------------------------------------------------- */
+int mq_pack_i4(const int8_t *q, long rows, long cols, uint8_t *out, void *stream);
+int mq_unpack_i4(const uint8_t *packed, long rows, long cols, int8_t *out, void *stream);
+int mq_weight_levels(const void *w, int w_dtype, long N, long K, long ldw,
+                     const float *scale, int lo, int hi, int8_t *q, void *stream);
+int mq_prepack_w4(const int8_t *q, long N, long K, int zero_col0, uint8_t *out, void *stream);
+int mq_prepack_w8(const int8_t *q, long N, long K, int zero_col0, int8_t *out, void *stream);
+size_t mq_prepacked_bytes(long N, long K, int w_bits);
+
+/* ---------------------------------------------------------------------------
+ * Quantized Linear: int8 activations x int4/int8 weights -> int32 -> dequant.
+ * Replaces F.linear on fake-quantized tensors, quant_utils.py:384 (and the fp32
+ * L1/L2 pair of :374-376 when x0/w0 are given), with
+ *   acc[m][n] = sum_k a[m][k] * w[n][k]                      (int32, exact)
+ *   y[m][n]   = ((float(acc) * s_x[row_sel[m]]) * s_w[n]) + bias[n] + x0[m]*w0[n]
+ * each fp32 operation rounded once, in that order, then cast to out_dtype.
+ * a: [M, K_pad] int8, leading dimension lda (bytes, multiple of 16), K_pad % 128 == 0.
+ * w: image produced by mq_prepack_w4 / _w8 for (N, K) with the same K_pad.
+ * bias, x0, w0, row_sel may be NULL.  out: [M, N], leading dimension ldo (elements).
+ * mq_gemm_w4a8_i32 stores the raw accumulators (parity interface).
+ * ------------------------------------------------------------------------- */
+int mq_gemm_w4a8(const int8_t *a, long lda, const void *w, int w_bits,
+                 long M, long N, long K_pad,
+                 float s_x0, float s_x1, const uint8_t *row_sel,
+                 const float *s_w, const float *bias,
+                 const float *x0, const float *w0,
+                 void *out, int out_dtype, long ldo, void *stream);
+
+int mq_gemm_w4a8_i32(const int8_t *a, long lda, const void *w, int w_bits,
+                     long M, long N, long K_pad, int32_t *acc, long ldacc, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Min/max observer reduction.  Replaces the two reductions of
+ * MinmaxObserver.update, fake_quant/observer/minmax.py:13-28 (after
+ * BaseObserver.reshape_tensor, observer/base.py:15-28): per-channel min and max of
+ * x[M, C] over rows.  col_begin skips leading channels (split: the observer only
+ * sees x[..., 1:], quant_utils.py:369).  Results are fp32 [C - col_begin].
+ * mq_minmax_tensor reduces to two scalars (layer_wise): out2[0]=min, out2[1]=max.
+ * ------------------------------------------------------------------------- */
+int mq_minmax_channels(const void *x, int x_dtype, long M, long C, long ldx, long col_begin,
+                       float *mn, float *mx, void *stream);
+int mq_minmax_tensor(const void *x, int x_dtype, long M, long C, long ldx, long col_begin,
+                     float *out2, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MQUANT_HIP_H */

@@ -1,0 +1,72 @@
+"""ctypes binding of ``libmquant_hip.so`` (the C ABI declared in ``include/mquant_hip.h``).
+
+There is no CPU fallback: if the shared library is missing or a call fails, this module
+raises.  Build the library with ``python __graft_entry__.py`` (or ``make -C mquant_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmquant_hip.so")
+
+MQ_F16, MQ_BF16, MQ_F32 = 0, 1, 2
+
+_vp = C.c_void_p
+_l = C.c_long
+_i = C.c_int
+_f = C.c_float
+
+# name -> (restype, argtypes); mirrors include/mquant_hip.h one to one
+SIGNATURES = {
+    "mq_version": (_i, []),
+    "mq_last_error": (C.c_char_p, []),
+    "mq_device_info": (_i, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
+    "mq_quantize_act_i8": (_i, [_vp, _i, _l, _l, _l, _f, _f, _vp, _vp, _vp, _i, _vp, _vp, _l, _l, _vp]),
+    "mq_fakequant_act": (_i, [_vp, _i, _l, _l, _l, _f, _f, _vp, _vp, _vp, _i, _vp, _l, _vp]),
+    "mq_hadamard": (_i, [_vp, _i, _l, _l, _l, _l, _i, _vp, _i, _vp, _l, _vp]),
+    "mq_hadamard_quant_i8": (_i, [_vp, _i, _l, _l, _l, _l, _i, _vp, _i, _f, _f, _vp, _i, _vp, _vp, _l, _l, _vp]),
+    "mq_pack_i4": (_i, [_vp, _l, _l, _vp, _vp]),
+    "mq_unpack_i4": (_i, [_vp, _l, _l, _vp, _vp]),
+    "mq_weight_levels": (_i, [_vp, _i, _l, _l, _l, _vp, _i, _i, _vp, _vp]),
+    "mq_prepack_w4": (_i, [_vp, _l, _l, _i, _vp, _vp]),
+    "mq_prepack_w8": (_i, [_vp, _l, _l, _i, _vp, _vp]),
+    "mq_prepacked_bytes": (C.c_size_t, [_l, _l, _i]),
+    "mq_gemm_w4a8": (_i, [_vp, _l, _vp, _i, _l, _l, _l, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _l, _vp]),
+    "mq_gemm_w4a8_i32": (_i, [_vp, _l, _vp, _i, _l, _l, _l, _vp, _l, _vp]),
+    "mq_minmax_channels": (_i, [_vp, _i, _l, _l, _l, _l, _vp, _vp, _vp]),
+    "mq_minmax_tensor": (_i, [_vp, _i, _l, _l, _l, _l, _vp, _vp]),
+}
+
+_lib = None
+
+
+class MQuantHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MQuantHipError(
+                f"{LIB_PATH} not found: the W4A8 path has no CPU fallback. "
+                "Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI and the header drift apart
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def call(name: str, *args) -> None:
+    """Invoke an ``int``-returning entry point and raise on a non-zero status."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.mq_last_error().decode("utf-8", "replace")
+        raise MQuantHipError(f"{name} failed (status {rc}): {msg}")

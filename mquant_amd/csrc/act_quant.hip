@@ -1,0 +1,150 @@
+// act_quant.hip -- static activation quantizer (fp16/bf16/fp32 -> int8 levels, or the
+// fused quantize->dequantize form).  HBM-bound: 2 B in + 1 B out per element for half
+// inputs.  One thread owns 16 consecutive channels of one row: two 16-byte loads, one
+// 16-byte store, rows are walked by a grid-stride loop.
+//
+// Reference semantics: fake_quant/quantizer/uniform.py:20-43, base.py:44-50.
+#include "mq_common.h"
+
+namespace mq {
+
+template <int DT, bool DEQUANT>
+__global__ __launch_bounds__(256) void act_quant_kernel(
+    const typename Elem<DT>::T *__restrict__ x, long M, long K, long ldx,
+    float scale0, float scale1, const float *__restrict__ svec0,
+    const float *__restrict__ svec1, const uint8_t *__restrict__ row_sel, int skip_col0,
+    float *__restrict__ x0_out, void *__restrict__ out_, long K_pad, long ldo, int vec_ok)
+{
+    typedef typename Elem<DT>::T T;
+    const long chunks_per_row = K_pad / 16;
+    const long total = M * chunks_per_row;
+    for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < total;
+         c += (long)gridDim.x * blockDim.x) {
+        const long row = c / chunks_per_row;
+        const long col = (c - row * chunks_per_row) * 16;
+        const int sel = row_sel ? (row_sel[row] != 0) : 0;
+        const float s_t = sel ? scale1 : scale0;
+        const float *sv = sel ? svec1 : svec0;
+        const T *xr = x + row * ldx + col;
+
+        float v[16];
+        if (col + 16 <= K && vec_ok) {
+            if (sizeof(T) == 2) {
+                const v8us a = *reinterpret_cast<const v8us *>(xr);
+                const v8us b = *reinterpret_cast<const v8us *>(xr + 8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    v[i] = Elem<DT>::ld((T)a[i]);
+                    v[8 + i] = Elem<DT>::ld((T)b[i]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const v4f a = *reinterpret_cast<const v4f *>((const float *)xr + 4 * j);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[4 * j + i] = a[i];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = (col + i < K) ? Elem<DT>::ld(xr[i]) : 0.0f;
+        }
+
+        int q[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float s = sv ? ((col + i < K) ? sv[col + i] : 1.0f) : s_t;
+            q[i] = quant_level(v[i], s, -128.0f, 127.0f);
+        }
+        if (skip_col0 && col == 0) {
+            if (x0_out) x0_out[row] = v[0];
+            q[0] = 0;
+        }
+
+        if (!DEQUANT) {
+            int8_t *out = reinterpret_cast<int8_t *>(out_) + row * ldo + col;
+            v4i p;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                p[j] = (q[4 * j] & 0xff) | ((q[4 * j + 1] & 0xff) << 8) |
+                       ((q[4 * j + 2] & 0xff) << 16) | ((q[4 * j + 3] & 0xff) << 24);
+            *reinterpret_cast<v4i *>(out) = p;
+        } else {
+            T *out = reinterpret_cast<T *>(out_) + row * ldo + col;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (col + i >= K) break;
+                const float s = sv ? sv[col + i] : s_t;
+                float d = (float)q[i] * s;
+                if (skip_col0 && col == 0 && i == 0) d = v[0];
+                out[i] = Elem<DT>::st(d);
+            }
+        }
+    }
+}
+
+template <int DT, bool DEQUANT>
+static int launch_act_quant(const void *x, long M, long K, long ldx, float scale0, float scale1,
+                            const float *sv0, const float *sv1, const uint8_t *row_sel,
+                            int skip_col0, float *x0_out, void *out, long K_pad, long ldo,
+                            hipStream_t st)
+{
+    typedef typename Elem<DT>::T T;
+    const long total = M * (K_pad / 16);
+    if (total == 0) return MQ_OK;
+    const int vec_ok = (((uintptr_t)x) % 16 == 0) && ((ldx * (long)sizeof(T)) % 16 == 0);
+    long blocks = ceil_div(total, 256);
+    if (blocks > 256L * 16) blocks = 256L * 16;
+    hipLaunchKernelGGL((act_quant_kernel<DT, DEQUANT>), dim3((unsigned)blocks), dim3(256), 0, st,
+                       (const T *)x, M, K, ldx, scale0, scale1, sv0, sv1, row_sel, skip_col0,
+                       x0_out, out, K_pad, ldo, vec_ok);
+    return check_launch("act_quant");
+}
+
+}  // namespace mq
+
+extern "C" int mq_quantize_act_i8(const void *x, int x_dtype, long M, long K, long ldx,
+                                  float scale0, float scale1, const float *scale_vec0,
+                                  const float *scale_vec1, const uint8_t *row_sel,
+                                  int skip_col0, float *x0_out, int8_t *out, long K_pad,
+                                  long ldo, void *stream)
+{
+    using namespace mq;
+    MQ_REQUIRE(M >= 0 && K >= 0, "mq_quantize_act_i8: negative shape");
+    if (M == 0 || K == 0) return MQ_OK;
+    MQ_REQUIRE(x && out, "mq_quantize_act_i8: null buffer");
+    MQ_REQUIRE(K_pad >= K && K_pad % 16 == 0, "mq_quantize_act_i8: K_pad=%ld must be >= K=%ld and a multiple of 16", K_pad, K);
+    MQ_REQUIRE(ldo >= K_pad && ldo % 16 == 0 && ((uintptr_t)out) % 16 == 0,
+               "mq_quantize_act_i8: out must be 16-byte aligned with ldo %% 16 == 0 (ldo=%ld)", ldo);
+    MQ_REQUIRE(ldx >= K, "mq_quantize_act_i8: ldx < K");
+    MQ_REQUIRE(!row_sel || !scale_vec0 || scale_vec1, "mq_quantize_act_i8: row_sel with per-channel scales needs scale_vec1");
+    if (!scale_vec1) scale_vec1 = scale_vec0;
+    hipStream_t st = (hipStream_t)stream;
+    switch (x_dtype) {
+    case MQ_F16: return launch_act_quant<MQ_F16, false>(x, M, K, ldx, scale0, scale1, scale_vec0, scale_vec1, row_sel, skip_col0, x0_out, out, K_pad, ldo, st);
+    case MQ_BF16: return launch_act_quant<MQ_BF16, false>(x, M, K, ldx, scale0, scale1, scale_vec0, scale_vec1, row_sel, skip_col0, x0_out, out, K_pad, ldo, st);
+    case MQ_F32: return launch_act_quant<MQ_F32, false>(x, M, K, ldx, scale0, scale1, scale_vec0, scale_vec1, row_sel, skip_col0, x0_out, out, K_pad, ldo, st);
+    }
+    return fail(MQ_EINVAL, "mq_quantize_act_i8: unknown dtype %d", x_dtype);
+}
+
+extern "C" int mq_fakequant_act(const void *x, int x_dtype, long M, long K, long ldx,
+                                float scale0, float scale1, const float *scale_vec0,
+                                const float *scale_vec1, const uint8_t *row_sel, int skip_col0,
+                                void *out, long ldo, void *stream)
+{
+    using namespace mq;
+    MQ_REQUIRE(M >= 0 && K >= 0, "mq_fakequant_act: negative shape");
+    if (M == 0 || K == 0) return MQ_OK;
+    MQ_REQUIRE(x && out, "mq_fakequant_act: null buffer");
+    MQ_REQUIRE(ldx >= K && ldo >= K, "mq_fakequant_act: leading dimension < K");
+    if (!scale_vec1) scale_vec1 = scale_vec0;
+    const long K_pad = ceil_div(K, 16) * 16;
+    hipStream_t st = (hipStream_t)stream;
+    switch (x_dtype) {
+    case MQ_F16: return launch_act_quant<MQ_F16, true>(x, M, K, ldx, scale0, scale1, scale_vec0, scale_vec1, row_sel, skip_col0, nullptr, out, K_pad, ldo, st);
+    case MQ_BF16: return launch_act_quant<MQ_BF16, true>(x, M, K, ldx, scale0, scale1, scale_vec0, scale_vec1, row_sel, skip_col0, nullptr, out, K_pad, ldo, st);
+    case MQ_F32: return launch_act_quant<MQ_F32, true>(x, M, K, ldx, scale0, scale1, scale_vec0, scale_vec1, row_sel, skip_col0, nullptr, out, K_pad, ldo, st);
+    }
+    return fail(MQ_EINVAL, "mq_fakequant_act: unknown dtype %d", x_dtype);
+}

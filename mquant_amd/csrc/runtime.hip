@@ -1,0 +1,47 @@
+// runtime.hip -- error plumbing, version / device queries of the C ABI.
+#include <stdarg.h>
+
+#include "mq_common.h"
+
+namespace mq {
+
+char *last_error_buf()
+{
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(last_error_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, "%s: launch failed: %s", what, hipGetErrorString(e));
+    return MQ_OK;
+}
+
+}  // namespace mq
+
+extern "C" int mq_version(void) { return 100; }  // 0.1.0
+
+extern "C" const char *mq_last_error(void) { return mq::last_error_buf(); }
+
+extern "C" int mq_device_info(char *name_host, size_t name_len, int *cu_count_host)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return mq::fail((int)e, "hipGetDevice: %s", hipGetErrorString(e));
+    hipDeviceProp_t p;
+    e = hipGetDeviceProperties(&p, dev);
+    if (e != hipSuccess) return mq::fail((int)e, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (name_host && name_len) snprintf(name_host, name_len, "%s (%s)", p.name, p.gcnArchName);
+    if (cu_count_host) *cu_count_host = p.multiProcessorCount;
+    return MQ_OK;
+}

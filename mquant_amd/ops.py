@@ -1,0 +1,224 @@
+"""Torch-tensor front-end of the C ABI.  PyTorch is plumbing here (device memory and
+streams); every function below launches hand-written gfx950 kernels through
+``include/mquant_hip.h`` and has no eager/CPU fallback.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import MQ_BF16, MQ_F16, MQ_F32, call
+
+_DT = {torch.float16: MQ_F16, torch.bfloat16: MQ_BF16, torch.float32: MQ_F32}
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    try:
+        return _DT[dt]
+    except KeyError:
+        raise TypeError(f"unsupported activation dtype {dt}") from None
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.MQuantHipError(
+                "the W4A8 path runs on the GPU only (got a CPU tensor); there is no CPU fallback")
+
+
+def ceil_to(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def _rows(x: torch.Tensor) -> torch.Tensor:
+    """View as [M, C] with a unit inner stride (no copy when already so)."""
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    return x2
+
+
+# --------------------------------------------------------------------------- quantizer
+def quantize_act_i8(x: torch.Tensor, scale0: float = 1.0, scale1: Optional[float] = None, *,
+                    scale_vec0: Optional[torch.Tensor] = None,
+                    scale_vec1: Optional[torch.Tensor] = None,
+                    row_sel: Optional[torch.Tensor] = None, skip_col0: bool = False,
+                    out: Optional[torch.Tensor] = None,
+                    x0_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """fp -> int8 levels, [M, K] -> [M, ceil128(K)] (pad columns are zero)."""
+    x2 = _rows(x)
+    _need_cuda(x2, scale_vec0, scale_vec1, row_sel, out)
+    M, K = x2.shape
+    K_pad = ceil_to(K, 128)
+    if out is None:
+        out = torch.empty((M, K_pad), dtype=torch.int8, device=x.device)
+    if skip_col0 and x0_out is None:
+        x0_out = torch.empty((M,), dtype=torch.float32, device=x.device)
+    call("mq_quantize_act_i8", x2.data_ptr(), dtype_code(x2.dtype), M, K, x2.stride(0),
+         float(scale0), float(scale0 if scale1 is None else scale1),
+         _ptr(scale_vec0), _ptr(scale_vec1), _ptr(row_sel), int(skip_col0), _ptr(x0_out),
+         out.data_ptr(), K_pad, out.stride(0), _stream())
+    return out, x0_out
+
+
+def fakequant_act(x: torch.Tensor, scale0: float = 1.0, scale1: Optional[float] = None, *,
+                  scale_vec0: Optional[torch.Tensor] = None,
+                  scale_vec1: Optional[torch.Tensor] = None,
+                  row_sel: Optional[torch.Tensor] = None, skip_col0: bool = False) -> torch.Tensor:
+    """Fused quantize->dequantize in x's dtype (same shape as x)."""
+    x2 = _rows(x)
+    _need_cuda(x2, scale_vec0, scale_vec1, row_sel)
+    M, K = x2.shape
+    out = torch.empty((M, K), dtype=x.dtype, device=x.device)
+    call("mq_fakequant_act", x2.data_ptr(), dtype_code(x2.dtype), M, K, x2.stride(0),
+         float(scale0), float(scale0 if scale1 is None else scale1),
+         _ptr(scale_vec0), _ptr(scale_vec1), _ptr(row_sel), int(skip_col0),
+         out.data_ptr(), out.stride(0), _stream())
+    return out.reshape(x.shape)
+
+
+# --------------------------------------------------------------------------- Hadamard
+def hadamard(x: torch.Tensor, n: int, K: int, had_bits: Optional[torch.Tensor],
+             fp32_had: bool = False) -> torch.Tensor:
+    """Rotated activations in x's dtype, last dim zero-padded from x.shape[-1] to n."""
+    x2 = _rows(x)
+    _need_cuda(x2, had_bits)
+    M, n_in = x2.shape
+    out = torch.empty((M, n), dtype=x.dtype, device=x.device)
+    call("mq_hadamard", x2.data_ptr(), dtype_code(x2.dtype), M, n_in, x2.stride(0), n, K,
+         _ptr(had_bits), int(fp32_had), out.data_ptr(), out.stride(0), _stream())
+    return out.reshape(*x.shape[:-1], n)
+
+
+def hadamard_quant_i8(x: torch.Tensor, n: int, K: int, had_bits: Optional[torch.Tensor],
+                      scale0: float, scale1: Optional[float] = None, *, fp32_had: bool = False,
+                      row_sel: Optional[torch.Tensor] = None, skip_col0: bool = False,
+                      out: Optional[torch.Tensor] = None,
+                      x0_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    x2 = _rows(x)
+    _need_cuda(x2, had_bits, row_sel, out)
+    M, n_in = x2.shape
+    K_pad = ceil_to(n, 128)
+    if out is None:
+        out = torch.empty((M, K_pad), dtype=torch.int8, device=x.device)
+    if skip_col0 and x0_out is None:
+        x0_out = torch.empty((M,), dtype=torch.float32, device=x.device)
+    call("mq_hadamard_quant_i8", x2.data_ptr(), dtype_code(x2.dtype), M, n_in, x2.stride(0), n, K,
+         _ptr(had_bits), int(fp32_had), float(scale0), float(scale0 if scale1 is None else scale1),
+         _ptr(row_sel), int(skip_col0), _ptr(x0_out), out.data_ptr(), K_pad, out.stride(0),
+         _stream())
+    return out, x0_out
+
+
+# --------------------------------------------------------------------------- weights
+def pack_i4(q: torch.Tensor) -> torch.Tensor:
+    _need_cuda(q)
+    q = q.to(torch.int8).contiguous()
+    rows, cols = q.reshape(-1, q.shape[-1]).shape
+    out = torch.empty((rows, cols // 2), dtype=torch.uint8, device=q.device)
+    call("mq_pack_i4", q.data_ptr(), rows, cols, out.data_ptr(), _stream())
+    return out.reshape(*q.shape[:-1], cols // 2)
+
+
+def unpack_i4(p: torch.Tensor) -> torch.Tensor:
+    _need_cuda(p)
+    p = p.contiguous()
+    rows, half = p.reshape(-1, p.shape[-1]).shape
+    out = torch.empty((rows, half * 2), dtype=torch.int8, device=p.device)
+    call("mq_unpack_i4", p.data_ptr(), rows, half * 2, out.data_ptr(), _stream())
+    return out.reshape(*p.shape[:-1], half * 2)
+
+
+def weight_levels(w: torch.Tensor, scale: torch.Tensor, bits: int) -> torch.Tensor:
+    """Integer levels of a fake-quantized weight: clamp(rint(w / scale[n]), -2^(b-1), 2^(b-1)-1)."""
+    _need_cuda(w, scale)
+    w2 = w.reshape(w.shape[0], -1)
+    if w2.stride(-1) != 1:
+        w2 = w2.contiguous()
+    N, K = w2.shape
+    scale = scale.reshape(-1).to(torch.float32).contiguous()
+    assert scale.numel() == N
+    q = torch.empty((N, K), dtype=torch.int8, device=w.device)
+    call("mq_weight_levels", w2.data_ptr(), dtype_code(w2.dtype), N, K, w2.stride(0),
+         scale.data_ptr(), -(1 << (bits - 1)), (1 << (bits - 1)) - 1, q.data_ptr(), _stream())
+    return q
+
+
+def prepack(q: torch.Tensor, bits: int, zero_col0: bool = False) -> torch.Tensor:
+    """int levels [N, K] -> the pre-tiled image streamed by gemm_w4a8."""
+    _need_cuda(q)
+    q = q.to(torch.int8).contiguous()
+    N, K = q.shape
+    nbytes = _lib.load().mq_prepacked_bytes(N, K, bits)
+    out = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
+    call("mq_prepack_w4" if bits == 4 else "mq_prepack_w8", q.data_ptr(), N, K, int(zero_col0),
+         out.data_ptr(), _stream())
+    return out
+
+
+# --------------------------------------------------------------------------- GEMM
+def gemm_w4a8(a: torch.Tensor, w_img: torch.Tensor, w_bits: int, N: int, s_x0: float,
+              s_w: torch.Tensor, *, s_x1: Optional[float] = None,
+              row_sel: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+              x0: Optional[torch.Tensor] = None, w0: Optional[torch.Tensor] = None,
+              out_dtype: torch.dtype = torch.float16, M: Optional[int] = None,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _need_cuda(a, w_img, s_w, row_sel, bias, x0, w0, out)
+    assert a.dtype == torch.int8 and a.dim() == 2 and a.stride(1) == 1
+    M = a.shape[0] if M is None else M
+    K_pad = a.shape[1]
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    call("mq_gemm_w4a8", a.data_ptr(), a.stride(0), w_img.data_ptr(), w_bits, M, N, K_pad,
+         float(s_x0), float(s_x0 if s_x1 is None else s_x1), _ptr(row_sel), s_w.data_ptr(),
+         _ptr(bias), _ptr(x0), _ptr(w0), out.data_ptr(), dtype_code(out.dtype), out.stride(0),
+         _stream())
+    return out
+
+
+def gemm_w4a8_i32(a: torch.Tensor, w_img: torch.Tensor, w_bits: int, N: int) -> torch.Tensor:
+    _need_cuda(a, w_img)
+    assert a.dtype == torch.int8 and a.dim() == 2 and a.stride(1) == 1
+    M, K_pad = a.shape
+    acc = torch.empty((M, N), dtype=torch.int32, device=a.device)
+    call("mq_gemm_w4a8_i32", a.data_ptr(), a.stride(0), w_img.data_ptr(), w_bits, M, N, K_pad,
+         acc.data_ptr(), acc.stride(0), _stream())
+    return acc
+
+
+# --------------------------------------------------------------------------- observers
+def minmax_channels(x: torch.Tensor, col_begin: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    x2 = _rows(x)
+    _need_cuda(x2)
+    M, Cn = x2.shape
+    mn = torch.empty((Cn - col_begin,), dtype=torch.float32, device=x.device)
+    mx = torch.empty_like(mn)
+    call("mq_minmax_channels", x2.data_ptr(), dtype_code(x2.dtype), M, Cn, x2.stride(0), col_begin,
+         mn.data_ptr(), mx.data_ptr(), _stream())
+    return mn, mx
+
+
+def minmax_tensor(x: torch.Tensor, col_begin: int = 0) -> torch.Tensor:
+    """Returns a device tensor [min, max] (fp32)."""
+    x2 = _rows(x)
+    _need_cuda(x2)
+    M, Cn = x2.shape
+    out = torch.empty((2,), dtype=torch.float32, device=x.device)
+    call("mq_minmax_tensor", x2.data_ptr(), dtype_code(x2.dtype), M, Cn, x2.stride(0), col_begin,
+         out.data_ptr(), _stream())
+    return out
+
+
+def had_scale(n: int) -> float:
+    return 1.0 / math.sqrt(n)

@@ -1,0 +1,203 @@
+"""ctypes/numpy front-end of the CPU oracle (``oracle/mq_oracle.c``).
+
+TEST INFRASTRUCTURE ONLY -- importable from ``tests/``, ``__graft_entry__.smoke``
+and ``bench.py``'s ``cpu_baseline`` leg.  The product packages (``fake_quant``,
+``mquant_amd``) never import this module.
+
+Parity: pinned against outputs of the reference generated in the build container
+(``tools/gen_golden.py`` -> ``tests/golden/*.npz``); see ``tests/test_oracle_golden.py``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libmq_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    """Compile the C restatement with gcc (idempotent)."""
+    src = os.path.join(_HERE, "mq_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libmq_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_round_f16.restype = C.c_float
+        _lib.orc_round_f16.argtypes = [C.c_float]
+        _lib.orc_round_bf16.restype = C.c_float
+        _lib.orc_round_bf16.argtypes = [C.c_float]
+    return _lib
+
+
+def _p(a, ctype):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def round_to(x: np.ndarray, mode: int) -> np.ndarray:
+    """mode 0: identity, 1: fp16 round trip, 2: bf16 round trip (RNE)."""
+    x = np.array(x, dtype=np.float32, order="C")
+    lib().orc_round_array(_p(x, C.c_float), C.c_long(x.size), C.c_int(mode))
+    return x
+
+
+def quant_static(x, scale, zp=None, scale1=None, zp1=None, row_sel=None,
+                 lo=-128, hi=127) -> np.ndarray:
+    """uniform.py:20-33.  x: (rows, cols) fp32.  scale scalar or (cols,)."""
+    x = _f32(x)
+    rows, cols = x.shape
+    scale = _f32(np.atleast_1d(scale))
+    per_channel = int(scale.size > 1)
+    zp = _f32(np.zeros_like(scale) if zp is None else np.atleast_1d(zp))
+    if scale1 is not None:
+        scale1 = _f32(np.atleast_1d(scale1))
+        zp1 = _f32(np.zeros_like(scale1) if zp1 is None else np.atleast_1d(zp1))
+        row_sel = np.ascontiguousarray(row_sel, dtype=np.uint8)
+    else:
+        scale1, zp1, row_sel = scale, zp, None
+    q = np.empty((rows, cols), dtype=np.int8)
+    lib().orc_quant_static(_p(x, C.c_float), C.c_long(rows), C.c_long(cols),
+                           _p(scale, C.c_float), _p(zp, C.c_float),
+                           _p(scale1, C.c_float), _p(zp1, C.c_float),
+                           _p(row_sel, C.c_uint8), C.c_int(per_channel),
+                           C.c_int(lo), C.c_int(hi), _p(q, C.c_int8))
+    return q
+
+
+def dequant_static(q, scale, zp=None, scale1=None, zp1=None, row_sel=None) -> np.ndarray:
+    q = np.ascontiguousarray(q, dtype=np.int8)
+    rows, cols = q.shape
+    scale = _f32(np.atleast_1d(scale))
+    per_channel = int(scale.size > 1)
+    zp = _f32(np.zeros_like(scale) if zp is None else np.atleast_1d(zp))
+    if scale1 is not None:
+        scale1 = _f32(np.atleast_1d(scale1))
+        zp1 = _f32(np.zeros_like(scale1) if zp1 is None else np.atleast_1d(zp1))
+        row_sel = np.ascontiguousarray(row_sel, dtype=np.uint8)
+    else:
+        scale1, zp1, row_sel = scale, zp, None
+    out = np.empty((rows, cols), dtype=np.float32)
+    lib().orc_dequant_static(_p(q, C.c_int8), C.c_long(rows), C.c_long(cols),
+                             _p(scale, C.c_float), _p(zp, C.c_float),
+                             _p(scale1, C.c_float), _p(zp1, C.c_float),
+                             _p(row_sel, C.c_uint8), C.c_int(per_channel),
+                             _p(out, C.c_float))
+    return out
+
+
+def minmax_channels(x):
+    x = _f32(x)
+    rows, cols = x.shape
+    mn = np.empty(cols, dtype=np.float32)
+    mx = np.empty(cols, dtype=np.float32)
+    lib().orc_minmax_channels(_p(x, C.c_float), C.c_long(rows), C.c_long(cols),
+                              _p(mn, C.c_float), _p(mx, C.c_float))
+    return mn, mx
+
+
+def minmax_scale_sym(min_val, max_val, qmin=-128, qmax=127):
+    """observer/minmax.py:30-46 (symmetric branch), fp32."""
+    mn = np.float32(min_val)
+    mx = np.float32(max_val)
+    s = np.maximum(np.abs(mn / np.float32(qmin)), np.abs(mx / np.float32(qmax)))
+    return np.maximum(s, np.float32(np.finfo(np.float32).eps)).astype(np.float32)
+
+
+def hadamard(x, n, K, hadK=None, mid_round=0, out_round=0, post_div=False) -> np.ndarray:
+    """hadamard_utils.py:115-128 incl. the zero pad of utils.py:465-471."""
+    x = _f32(x)
+    rows, n_in = x.shape
+    out = np.empty((rows, n), dtype=np.float32)
+    hk = None if hadK is None else np.ascontiguousarray(np.sign(hadK), dtype=np.int8)
+    lib().orc_hadamard(_p(x, C.c_float), C.c_long(rows), C.c_long(n_in), C.c_long(n),
+                       C.c_int(K), _p(hk, C.c_int8), C.c_int(mid_round),
+                       C.c_int(out_round), C.c_int(int(post_div)), _p(out, C.c_float))
+    return out
+
+
+def pack_i4(q) -> np.ndarray:
+    q = np.ascontiguousarray(q, dtype=np.int8)
+    rows, cols = q.shape
+    out = np.empty((rows, cols // 2), dtype=np.uint8)
+    lib().orc_pack_i4(_p(q, C.c_int8), C.c_long(rows), C.c_long(cols), _p(out, C.c_uint8))
+    return out
+
+
+def unpack_i4(p) -> np.ndarray:
+    p = np.ascontiguousarray(p, dtype=np.uint8)
+    rows, half = p.shape
+    out = np.empty((rows, half * 2), dtype=np.int8)
+    lib().orc_unpack_i4(_p(p, C.c_uint8), C.c_long(rows), C.c_long(half * 2),
+                        _p(out, C.c_int8))
+    return out
+
+
+def gemm_i32(a, w) -> np.ndarray:
+    """acc[m][n] = sum_k a[m][k] * w[n][k]; a int8 (M,K), w int8-held int4 (N,K)."""
+    a = np.ascontiguousarray(a, dtype=np.int8)
+    w = np.ascontiguousarray(w, dtype=np.int8)
+    M, K = a.shape
+    N = w.shape[0]
+    acc = np.empty((M, N), dtype=np.int32)
+    lib().orc_gemm_i8i4_i32(_p(a, C.c_int8), _p(w, C.c_int8), C.c_long(M), C.c_long(N),
+                            C.c_long(K), _p(acc, C.c_int32))
+    return acc
+
+
+def epilogue(acc, sx0, s_w, bias=None, sx1=None, row_sel=None, x0=None, w0=None):
+    acc = np.ascontiguousarray(acc, dtype=np.int32)
+    M, N = acc.shape
+    s_w = _f32(s_w).reshape(-1)
+    bias = _f32(bias)
+    x0 = _f32(x0)
+    w0 = _f32(w0)
+    rs = None if row_sel is None else np.ascontiguousarray(row_sel, dtype=np.uint8)
+    out = np.empty((M, N), dtype=np.float32)
+    lib().orc_epilogue(_p(acc, C.c_int32), C.c_long(M), C.c_long(N),
+                       C.c_float(sx0), C.c_float(sx0 if sx1 is None else sx1),
+                       _p(rs, C.c_uint8), _p(s_w, C.c_float), _p(bias, C.c_float),
+                       _p(x0, C.c_float), _p(w0, C.c_float), _p(out, C.c_float))
+    return out
+
+
+def linear_fakequant_f32(x, s_x, w_dq, bias=None) -> np.ndarray:
+    x = _f32(x)
+    w_dq = _f32(w_dq)
+    bias = _f32(bias)
+    M, K = x.shape
+    N = w_dq.shape[0]
+    out = np.empty((M, N), dtype=np.float32)
+    lib().orc_linear_fakequant_f32(_p(x, C.c_float), C.c_long(M), C.c_long(K),
+                                   C.c_float(s_x), _p(w_dq, C.c_float), C.c_long(N),
+                                   _p(bias, C.c_float), _p(out, C.c_float))
+    return out
+
+
+def wquant_sym(w, bits=4, mse=False, norm=2.4, grid=100, maxshrink=0.8, want_levels=True):
+    w = _f32(w)
+    N, K = w.shape
+    scale = np.empty(N, dtype=np.float32)
+    levels = np.empty((N, K), dtype=np.int8) if want_levels else None
+    lib().orc_wquant_sym(_p(w, C.c_float), C.c_long(N), C.c_long(K), C.c_int(bits),
+                         C.c_int(int(mse)), C.c_float(norm), C.c_int(grid),
+                         C.c_float(maxshrink), _p(scale, C.c_float), _p(levels, C.c_int8))
+    return scale, levels

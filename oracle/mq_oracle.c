@@ -1,0 +1,349 @@
+/*
+ * mq_oracle.c -- CPU restatement of MQuant's W4A8 static-quant hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker.  The product path
+ * (the .hip sources in mquant_amd/csrc behind include/mquant_hip.h) never calls it.
+ *
+ * Parity status: PINNED against outputs of the reference itself
+ * (the .npz files in tests/golden, produced by tools/gen_golden.py which imports
+ * /root/reference/fake_quant on CPU).  The one third-party boundary,
+ * fast_hadamard_transform (Dao-AILab, un-pinned HEAD clone per
+ * reference docs/install.md:13-19), is restated from its published
+ * algorithm (in-register/warp/block butterflies in ascending stride, fp32,
+ * scale applied on store) and cross-checked against the reference's in-tree
+ * definition of the same operator, fake_quant/hadamard_utils.py:79-100.
+ *
+ * Every function cites the reference lines it follows (paths relative to
+ * /root/reference).  Floating point is IEEE fp32 with one rounding per
+ * written operation: build with -ffp-contract=off (see oracle/Makefile).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ */
+/* fp16 / bf16 round trips (round-to-nearest-even), used wherever the  */
+/* reference casts back to x_dtype (quant_utils.py:336-341, base.py:49) */
+/* ------------------------------------------------------------------ */
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+float orc_round_f16(float f)
+{
+    uint32_t x = f2u(f);
+    uint32_t sign = x & 0x80000000u;
+    uint32_t ax = x & 0x7fffffffu;
+    if (ax >= 0x7f800000u) return f;                 /* inf / nan */
+    if (ax >= 0x477ff000u) {                         /* >= 65520 -> inf */
+        return u2f(sign | 0x7f800000u);
+    }
+    if (ax < 0x38800000u) {                          /* < 2^-14: fp16 subnormal grid 2^-24 */
+        float a = u2f(ax);
+        /* adding 2^-1 * 2^-24 * 2^24 trick: scale so that unit = 1, rint, scale back */
+        float r = rintf(a * 16777216.0f) * (1.0f / 16777216.0f);
+        return u2f(sign | f2u(r));
+    }
+    /* normal: keep 10 mantissa bits, RNE on the 13 dropped bits */
+    uint32_t lsb = (ax >> 13) & 1u;
+    ax += 0x0fffu + lsb;
+    ax &= 0xffffe000u;
+    return u2f(sign | ax);
+}
+
+float orc_round_bf16(float f)
+{
+    uint32_t x = f2u(f);
+    if ((x & 0x7fffffffu) > 0x7f800000u) return f;   /* nan */
+    uint32_t lsb = (x >> 16) & 1u;
+    x += 0x7fffu + lsb;
+    x &= 0xffff0000u;
+    return u2f(x);
+}
+
+static inline float round_mid(float v, int mode)
+{
+    if (mode == 1) return orc_round_f16(v);
+    if (mode == 2) return orc_round_bf16(v);
+    return v;
+}
+
+void orc_round_array(float *x, long n, int mode)
+{
+    for (long i = 0; i < n; ++i) x[i] = round_mid(x[i], mode);
+}
+
+/* ------------------------------------------------------------------ */
+/* Static activation quantizer                                          */
+/*   fake_quant/quantizer/uniform.py:20-33 (quant)                      */
+/*   fake_quant/quantizer/base.py:44-50    (x.float() first)            */
+/*   q = clamp(round_half_even(x / s + zp), lo, hi)                      */
+/* scale / zp are broadcast on the last dim when per_channel != 0        */
+/* (base.py:20-24), otherwise they are scalars (layer_wise).            */
+/* row_sel (may be NULL) picks scale set 0/1 per row: the MSQ extension  */
+/* (two UniformQuantizers applied to masked rows).      */
+/* ------------------------------------------------------------------ */
+void orc_quant_static(const float *x, long rows, long cols,
+                      const float *scale0, const float *zp0,
+                      const float *scale1, const float *zp1,
+                      const uint8_t *row_sel, int per_channel,
+                      int lo, int hi, int8_t *q)
+{
+    for (long r = 0; r < rows; ++r) {
+        const float *sc = (row_sel && row_sel[r]) ? scale1 : scale0;
+        const float *zp = (row_sel && row_sel[r]) ? zp1 : zp0;
+        for (long c = 0; c < cols; ++c) {
+            float s = per_channel ? sc[c] : sc[0];
+            float z = per_channel ? zp[c] : zp[0];
+            float v = x[r * cols + c] / s + z;
+            v = rintf(v);
+            if (v < (float)lo) v = (float)lo;
+            if (v > (float)hi) v = (float)hi;
+            q[r * cols + c] = (int8_t)v;
+        }
+    }
+}
+
+/* uniform.py:35-43: x_hat = (q - zp) * s  (fp32) */
+void orc_dequant_static(const int8_t *q, long rows, long cols,
+                        const float *scale0, const float *zp0,
+                        const float *scale1, const float *zp1,
+                        const uint8_t *row_sel, int per_channel, float *out)
+{
+    for (long r = 0; r < rows; ++r) {
+        const float *sc = (row_sel && row_sel[r]) ? scale1 : scale0;
+        const float *zp = (row_sel && row_sel[r]) ? zp1 : zp0;
+        for (long c = 0; c < cols; ++c) {
+            float s = per_channel ? sc[c] : sc[0];
+            float z = per_channel ? zp[c] : zp[0];
+            out[r * cols + c] = ((float)q[r * cols + c] - z) * s;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* Min/max observer reduction: fake_quant/observer/minmax.py:13-28.     */
+/* Per-channel (last dim) min and max over all rows; the caller applies */
+/* the zero-inclusion / running / layer_wise collapse rules.            */
+/* ------------------------------------------------------------------ */
+void orc_minmax_channels(const float *x, long rows, long cols,
+                         float *mn, float *mx)
+{
+    for (long c = 0; c < cols; ++c) { mn[c] = INFINITY; mx[c] = -INFINITY; }
+    for (long r = 0; r < rows; ++r)
+        for (long c = 0; c < cols; ++c) {
+            float v = x[r * cols + c];
+            if (v < mn[c]) mn[c] = v;
+            if (v > mx[c]) mx[c] = v;
+        }
+}
+
+/* ------------------------------------------------------------------ */
+/* Online Hadamard, CUDA-path semantics:                                */
+/*   fake_quant/hadamard_utils.py:115-128 (matmul_hadU_cuda)            */
+/*   fake_quant/utils.py:465-471          (zero pad n_in -> n)          */
+/*   y = (H_K (x) H_{n/K}) x / sqrt(n),   index i = k*(n/K) + j          */
+/* Steps, each a single fp32 rounding per operation:                    */
+/*   1. per contiguous block of m = n/K: Walsh-Hadamard butterflies in  */
+/*      ascending stride h = 1,2,4,..  (a+b, a-b) -- the operator of     */
+/*      hadamard_utils.py:83-91 and of fast_hadamard_transform;         */
+/*   2. multiply by scale = 1.0f / sqrtf((float)n)                       */
+/*      (hadamard_utils.py:119,125: 1.0/torch.tensor(n).sqrt(), fp32);   */
+/*   3. mid_round: the FHT extension returns x's dtype, so an fp16/bf16  */
+/*      input is rounded here (mode 1/2); fp32_had keeps fp32 (mode 0);  */
+/*   4. K > 1: out[j*m+i] = sum_k hadK[j][k] * y[k*m+i], k ascending,    */
+/*      as one fp32 add/sub chain starting from 0 (hadamard_utils.py:127 */
+/*      `hadK @ input`);                                                 */
+/*   5. out_round: cast back to x_dtype (quant_utils.py:336-341).        */
+/* post_div != 0 selects the pure-torch ordering of hadamard_utils.py:   */
+/* 79-100 (matmul_hadU): no scale in step 2, `/ sqrt(n)` after step 4.  */
+/* hadK is K*K int8 (+1/-1), row-major, ignored when K == 1.            */
+/* ------------------------------------------------------------------ */
+void orc_hadamard(const float *x, long rows, long n_in, long n, int K,
+                  const int8_t *hadK, int mid_round_mode, int out_round_mode,
+                  int post_div, float *out)
+{
+    const long m = n / K;
+    const float root = sqrtf((float)n);
+    const float scale = 1.0f / root;
+    float *y = (float *)malloc(sizeof(float) * (size_t)n);
+    for (long r = 0; r < rows; ++r) {
+        for (long i = 0; i < n; ++i) y[i] = (i < n_in) ? x[r * n_in + i] : 0.0f;
+        for (int k = 0; k < K; ++k) {
+            float *b = y + (long)k * m;
+            for (long h = 1; h < m; h <<= 1)
+                for (long i = 0; i < m; i += 2 * h)
+                    for (long j = i; j < i + h; ++j) {
+                        float a0 = b[j], a1 = b[j + h];
+                        b[j] = a0 + a1;
+                        b[j + h] = a0 - a1;
+                    }
+        }
+        if (!post_div)
+            for (long i = 0; i < n; ++i) y[i] = round_mid(y[i] * scale, mid_round_mode);
+        float *o = out + r * n;
+        if (K == 1) {
+            for (long i = 0; i < n; ++i)
+                o[i] = round_mid(post_div ? y[i] / root : y[i], out_round_mode);
+        } else {
+            for (int j = 0; j < K; ++j)
+                for (long i = 0; i < m; ++i) {
+                    float acc = 0.0f;
+                    for (int k = 0; k < K; ++k) {
+                        float v = y[(long)k * m + i];
+                        acc = (hadK[j * K + k] > 0) ? (acc + v) : (acc - v);
+                    }
+                    o[(long)j * m + i] = round_mid(post_div ? acc / root : acc, out_round_mode);
+                }
+        }
+    }
+    free(y);
+}
+
+/* ------------------------------------------------------------------ */
+/* int4 wire format: fake_quant/quant_utils.py:61-94                    */
+/* two's-complement nibbles, even index -> low nibble, odd -> high,     */
+/* along the last dim.                                                  */
+/* ------------------------------------------------------------------ */
+void orc_pack_i4(const int8_t *q, long rows, long cols, uint8_t *out)
+{
+    for (long r = 0; r < rows; ++r)
+        for (long c = 0; c < cols / 2; ++c) {
+            uint8_t lo = (uint8_t)q[r * cols + 2 * c] & 0x0f;
+            uint8_t hi = (uint8_t)q[r * cols + 2 * c + 1] & 0x0f;
+            out[r * (cols / 2) + c] = (uint8_t)(lo | (hi << 4));
+        }
+}
+
+void orc_unpack_i4(const uint8_t *p, long rows, long cols, int8_t *out)
+{
+    for (long r = 0; r < rows; ++r)
+        for (long c = 0; c < cols / 2; ++c) {
+            uint8_t b = p[r * (cols / 2) + c];
+            int lo = b & 0x0f, hi = (b >> 4) & 0x0f;
+            out[r * cols + 2 * c] = (int8_t)(lo >= 8 ? lo - 16 : lo);
+            out[r * cols + 2 * c + 1] = (int8_t)(hi >= 8 ? hi - 16 : hi);
+        }
+}
+
+/* ------------------------------------------------------------------ */
+/* Integer core of the quantized Linear.                                */
+/* The reference evaluates F.linear on dequantized tensors              */
+/* (quant_utils.py:384 with uniform.py:42 and quant_utils.py:512-518);  */
+/* on the integer grid that is acc[m][n] = sum_k qx[m][k] * qw[n][k].   */
+/* ------------------------------------------------------------------ */
+void orc_gemm_i8i4_i32(const int8_t *a, const int8_t *w, long M, long N, long K,
+                       int32_t *acc)
+{
+#pragma omp parallel for schedule(static)
+    for (long m = 0; m < M; ++m)
+        for (long n = 0; n < N; ++n) {
+            const int8_t *ar = a + m * K, *wr = w + n * K;
+            int32_t s = 0;
+            for (long k = 0; k < K; ++k) s += (int32_t)ar[k] * (int32_t)wr[k];
+            acc[m * N + n] = s;
+        }
+}
+
+/* ------------------------------------------------------------------ */
+/* Dequant epilogue: y = acc * s_x[row set] * s_w[n] (+ bias) (+ rank-1 */
+/* split term x0[m]*w0[n], quant_utils.py:367-376: channel 0 bypasses   */
+/* the quantizer and goes through L1 in fp32).                           */
+/* One rounding per operation, in this order.                            */
+/* ------------------------------------------------------------------ */
+void orc_epilogue(const int32_t *acc, long M, long N,
+                  float sx0, float sx1, const uint8_t *row_sel,
+                  const float *s_w, const float *bias,
+                  const float *x0, const float *w0, float *out)
+{
+    for (long m = 0; m < M; ++m) {
+        float sx = (row_sel && row_sel[m]) ? sx1 : sx0;
+        for (long n = 0; n < N; ++n) {
+            float t = (float)acc[m * N + n] * sx;
+            t = t * s_w[n];
+            if (bias) t = t + bias[n];
+            if (x0) { float p = x0[m] * w0[n]; t = t + p; }
+            out[m * N + n] = t;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* Whole fake-quant Linear exactly as the reference evaluates it on CPU */
+/* in fp32 (quant_utils.py:378-384): dequantize both operands, then an  */
+/* fp32 matmul.  Used as the timed CPU baseline ("port") and as a        */
+/* sanity cross-check of the integer path; summation is k-ascending.    */
+/* ------------------------------------------------------------------ */
+void orc_linear_fakequant_f32(const float *x, long M, long K,
+                              float s_x, const float *w_dq, long N,
+                              const float *bias, float *out)
+{
+    float *xq = (float *)malloc(sizeof(float) * (size_t)(M * K));
+    for (long i = 0; i < M * K; ++i) {
+        float v = rintf(x[i] / s_x + 0.0f);
+        if (v < -128.0f) v = -128.0f;
+        if (v > 127.0f) v = 127.0f;
+        xq[i] = (v - 0.0f) * s_x;
+    }
+#pragma omp parallel for schedule(static)
+    for (long m = 0; m < M; ++m)
+        for (long n = 0; n < N; ++n) {
+            const float *xr = xq + m * K, *wr = w_dq + n * K;
+            float s = 0.0f;
+            for (long k = 0; k < K; ++k) s += xr[k] * wr[k];
+            out[m * N + n] = bias ? s + bias[n] : s;
+        }
+    free(xq);
+}
+
+/* ------------------------------------------------------------------ */
+/* Symmetric per-output-channel weight quantizer (RTN):                 */
+/*   fake_quant/quant_utils.py:446-518, sym branch.                     */
+/*   xmax = max(|min(row,0)|, max(row,0)).clamp(1e-5); s = xmax/maxq    */
+/*   optional MSE shrink search (:473-500): p = 1 - i/grid, i < 0.8*grid,*/
+/*   err = sum |q - x|^norm; keep the best.                             */
+/*   levels = clamp(round(x/s), -(maxq+1), maxq)  (quant_utils.py:42-45)*/
+/* ------------------------------------------------------------------ */
+void orc_wquant_sym(const float *w, long N, long K, int bits, int mse,
+                    float norm, int grid, float maxshrink,
+                    float *scale, int8_t *levels)
+{
+    const float maxq = (float)((1 << (bits - 1)) - 1);
+    for (long n = 0; n < N; ++n) {
+        const float *r = w + n * K;
+        float mn = 0.0f, mx = 0.0f;
+        for (long k = 0; k < K; ++k) { if (r[k] < mn) mn = r[k]; if (r[k] > mx) mx = r[k]; }
+        float xmax = fmaxf(fabsf(mn), mx);
+        if (xmax < 1e-5f) xmax = 1e-5f;
+        float s = xmax / maxq;
+        if (mse) {
+            float best = INFINITY;
+            int steps = (int)(maxshrink * (float)grid);
+            for (int i = 0; i < steps; ++i) {
+                /* python: p = 1 - i / grid in double, times an fp32 tensor -> fp32 */
+                float p = (float)(1.0 - (double)i / (double)grid);
+                float xmax1 = p * xmax;
+                float s1 = xmax1 / maxq;
+                float err = 0.0f;
+                for (long k = 0; k < K; ++k) {
+                    float q = rintf(r[k] / s1);
+                    if (q < -(maxq + 1.0f)) q = -(maxq + 1.0f);
+                    if (q > maxq) q = maxq;
+                    float d = fabsf(s1 * q - r[k]);
+                    err += powf(d, norm);
+                }
+                if (err < best) { best = err; s = s1; }
+            }
+        }
+        scale[n] = s;
+        if (levels)
+            for (long k = 0; k < K; ++k) {
+                float q = rintf(r[k] / s);
+                if (q < -(maxq + 1.0f)) q = -(maxq + 1.0f);
+                if (q > maxq) q = maxq;
+                levels[n * K + k] = (int8_t)q;
+            }
+    }
+}
