@@ -35,6 +35,10 @@ __device__ __forceinline__ float f16_bits_to_f32(unsigned short h)
 }
 __device__ __forceinline__ unsigned short f32_to_f16_bits(float f)
 {
+    // The empty asm makes `f` opaque: without it the backend folds a preceding fp32 multiply
+    // into V_FMA_MIXLO_F16 (ONE rounding, product -> f16), whereas the reference rounds the
+    // product to fp32 first and then casts (two roundings); they differ on ~0.1 % of values.
+    asm volatile("" : "+v"(f));
     return __half_as_ushort(__float2half_rn(f));
 }
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short h)
