@@ -1,0 +1,808 @@
+"""Operator layer of the W4A8 static-quant path, with the reference's public surface
+(``fake_quant/quant_utils.py``): ``ActQuantizer``, ``ActQuantWrapper``, ``WeightQuantizer``,
+``add_actquant``, ``find_qlayers``, the ``model_*`` calibration toggles and the ``calib_*``
+drivers.  Callers (``exam/quant_*.py``, the GPTQ/RTN passes) use these names unchanged.
+
+What is different underneath: once a wrapper is calibrated (``model_quant``) and its weights
+carry integer levels (the RTN/GPTQ passes attach their ``WeightQuantizer``), ``forward`` no
+longer simulates quantization in floating point.  It runs two hand-written gfx950 kernels
+through the C ABI in ``include/mquant_hip.h``:
+
+    [zero-pad + online Hadamard +] static int8 quantize  ->  int8 x int4 MFMA GEMM with
+    fused per-channel dequant (+ bias, + the fp32 rank-1 ``split`` term)
+
+There is no CPU fallback for that path: a CPU tensor or a missing ``libmquant_hip.so``
+raises ``MQuantHipError``.  Calibration, module surgery and the dynamic (per-token)
+quantizers -- which no canonical command line uses -- stay torch code.
+
+Extension: Modality-Specific Static Quantization.  ``ActQuantizer.configure(..., msq=True)``
+keeps TWO static scale sets per layer (vision tokens / text tokens); the token-type mask of
+the running batch is published with ``token_type_mask(mask)`` and consumed inside the
+kernels (``row_sel``).
+"""
+from __future__ import annotations
+
+import contextlib
+import functools
+import math
+from collections import OrderedDict
+from typing import Optional
+
+import torch
+
+from fake_quant import hadamard_utils, utils
+from fake_quant.bit_type import BIT_TYPE_DICT
+from fake_quant.observer import build_observer
+from fake_quant.quantizer import build_quantizer
+
+
+# =============================================================================== integer grids
+def get_minq_maxq(bits, sym):
+    """(minq, maxq): symmetric -> [-2^(b-1), 2^(b-1)-1]; asymmetric -> [0, 2^b-1]."""
+    if sym:
+        maxq = torch.tensor(2 ** (bits - 1) - 1)
+        return -maxq - 1, maxq
+    return 0, torch.tensor(2 ** bits - 1)
+
+
+def asym_quant(x, scale, zero, maxq):
+    scale, zero = scale.to(x.device), zero.to(x.device)
+    return torch.clamp(torch.round(x / scale) + zero, 0, maxq), scale, zero
+
+
+def asym_dequant(q, scale, zero):
+    return scale * (q - zero)
+
+
+def asym_quant_dequant(x, scale, zero, maxq):
+    return asym_dequant(*asym_quant(x, scale, zero, maxq))
+
+
+def sym_quant(x, scale, maxq):
+    scale = scale.to(x.device)
+    return torch.clamp(torch.round(x / scale), -(maxq + 1), maxq), scale
+
+
+def sym_dequant(q, scale):
+    return scale * q
+
+
+def sym_quant_dequant(x, scale, maxq):
+    return sym_dequant(*sym_quant(x, scale, maxq))
+
+
+def two_compl(x, bits: int):
+    return torch.where(x < 0, 2 ** bits + x, x)
+
+
+def pack_i4(q):
+    """Signed int4 levels -> uint8, two per byte along the last dim: even index in the low
+    nibble, odd index in the high nibble (two's complement).  The wire format."""
+    assert torch.is_signed(q), "The tensor to be packed should be signed int"
+    minq, maxq = get_minq_maxq(4, True)
+    assert torch.all(torch.logical_and(q >= minq, q <= maxq))
+    if q.is_cuda:
+        from mquant_amd import ops
+        return ops.pack_i4(q)
+    nib = two_compl(q.to(torch.int8), 4).to(torch.uint8)
+    return nib[..., 0::2] | (nib[..., 1::2] << 4)
+
+
+def unpack_i4(x: torch.Tensor):
+    """Inverse of ``pack_i4``; returns int32 like upstream."""
+    assert x.dtype == torch.uint8, "The tensor to be unpacked should be stored in uint8"
+    if x.is_cuda:
+        from mquant_amd import ops
+        return ops.unpack_i4(x).to(torch.int32)
+    lo = (x & 0x0F).to(torch.int32)
+    hi = (x >> 4).to(torch.int32)
+    both = torch.stack((lo, hi), dim=-1)
+    both = torch.where(both >= 8, both - 16, both)
+    return both.reshape(*x.shape[:-1], x.shape[-1] * 2)
+
+
+# =============================================================================== MSQ mask
+_MSQ_STATE = {"mask": None}
+
+
+@contextlib.contextmanager
+def token_type_mask(mask: Optional[torch.Tensor]):
+    """Publish the token-type mask of the running batch: one entry per flattened token,
+    0 = vision token (scale set 0), 1 = text token (scale set 1)."""
+    prev = _MSQ_STATE["mask"]
+    _MSQ_STATE["mask"] = None if mask is None else mask.reshape(-1).to(torch.uint8).contiguous()
+    try:
+        yield
+    finally:
+        _MSQ_STATE["mask"] = prev
+
+
+def set_token_type_mask(mask: Optional[torch.Tensor]) -> None:
+    _MSQ_STATE["mask"] = None if mask is None else mask.reshape(-1).to(torch.uint8).contiguous()
+
+
+def _row_mask(rows: int, device) -> torch.Tensor:
+    """Mask for a [rows, C] activation.  Without a published mask of matching length every
+    row counts as text: decode steps append text tokens only."""
+    m = _MSQ_STATE["mask"]
+    if m is not None and m.numel() == rows:
+        return m.to(device)
+    return torch.ones(rows, dtype=torch.uint8, device=device)
+
+
+# =============================================================================== ActQuantizer
+class ActQuantizer(torch.nn.Module):
+    """Activation quantizer.
+
+    static=True  : calibrated scale(s) from an observer; ``calibrate`` / ``last_calibrate`` /
+                   ``quant`` flags drive the protocol (open -> N forwards -> last -> close ->
+                   quant).  During calibration activations pass through unquantized.
+    static=False : dynamic per-token (default), per-tensor (``act_per_tensor``) or group-wise
+                   (``groupsize``) ranges found by ``find_params`` on every call.
+    bits == 16   : identity.
+    """
+
+    def __init__(self, act_per_tensor=False):
+        super().__init__()
+        self.register_buffer("maxq", torch.tensor(0))
+        self.register_buffer("scale", torch.zeros(1))
+        self.register_buffer("zero", torch.zeros(1))
+        self.bits = 16
+        self.act_per_tensor = act_per_tensor
+        self.static = False
+        self.msq = False
+
+    def free(self):
+        self.zero = None
+        self.scale = None
+
+    def configure(self, bits, groupsize=-1, sym=False, clip_ratio=1.0, act_per_tensor=False,
+                  static=False, observer_type="minmax", calibration_mode="layer_wise",
+                  msq=False):
+        _, self.maxq = get_minq_maxq(bits, sym)
+        self.bits = bits
+        self.groupsize = groupsize
+        self.sym = sym
+        self.clip_ratio = clip_ratio
+        self.act_per_tensor = act_per_tensor
+        assert 0 < self.clip_ratio <= 1, "Clip ratio should be in (0, 1]"
+        self.static = static
+        self.msq = bool(msq) and static
+        if static:
+            bit_type = BIT_TYPE_DICT[f"int{bits}"]       # KeyError for bits=4, as upstream
+            if observer_type == "percentile":
+                print("Using percentile observer for activations")
+            self.observer = build_observer(observer_type, "activation", bit_type, calibration_mode)
+            self.quantizer = build_quantizer("uniform", bit_type, self.observer, "activation")
+            if self.msq:
+                self.observer_text = build_observer(observer_type, "activation", bit_type,
+                                                    calibration_mode)
+                self.quantizer_text = build_quantizer("uniform", bit_type, self.observer_text,
+                                                      "activation")
+            self.calibrate = False
+            self.last_calibrate = False
+            self.quant = False
+
+    # ---- static path ---------------------------------------------------------------------
+    def _observe(self, x):
+        if not self.msq:
+            self.quantizer.observer.update(x)
+            if self.last_calibrate:
+                self.quantizer.update_quantization_params(x)
+            return
+        rows = x.reshape(-1, x.shape[-1])
+        text = _row_mask(rows.shape[0], x.device).bool()
+        for qz, part in ((self.quantizer, rows[~text]), (self.quantizer_text, rows[text])):
+            if part.shape[0]:
+                qz.observer.update(part)
+            if self.last_calibrate and qz.observer.max_val is not None:
+                qz.update_quantization_params(part)
+
+    def _static_fakequant(self, x):
+        if not self.msq:
+            return self.quantizer(x)
+        from mquant_amd import ops
+        s0 = self.quantizer.scale if self.quantizer.scale is not None else self.quantizer_text.scale
+        s1 = self.quantizer_text.scale if self.quantizer_text.scale is not None else s0
+        rows = x.reshape(-1, x.shape[-1])
+        return ops.fakequant_act(rows, float(s0), float(s1),
+                                 row_sel=_row_mask(rows.shape[0], x.device)).reshape(x.shape)
+
+    def forward(self, x):
+        if self.static:
+            if self.calibrate:
+                self._observe(x)
+                return x
+            return self._static_fakequant(x) if self.quant else x
+        if self.bits == 16:
+            return x
+        x_dtype = x.dtype
+        if self.sym:
+            return sym_quant_dequant(x, self.scale, self.maxq).to(x_dtype)
+        return asym_quant_dequant(x, self.scale, self.zero, self.maxq).to(x_dtype)
+
+    def quantize(self, x):
+        """Integers + scale (+ zero) instead of the dequantized tensor."""
+        if self.sym:
+            return sym_quant(x, self.scale, self.maxq)
+        return asym_quant(x, self.scale, self.zero, self.maxq)
+
+    # ---- dynamic range search ------------------------------------------------------------
+    def _ranges(self, xmin, xmax):
+        """scale / zero from clipped min & max tensors (any shape); degenerate ranges -> 1."""
+        if self.sym:
+            amax = torch.maximum(torch.abs(xmin), xmax)
+            scale = amax / self.maxq
+            scale = torch.where(amax == 0, torch.ones_like(scale), scale)
+            return scale, torch.zeros_like(scale)
+        dead = (xmin == 0) & (xmax == 0)
+        xmin = torch.where(dead, -torch.ones_like(xmin), xmin)
+        xmax = torch.where(dead, torch.ones_like(xmax), xmax)
+        scale = (xmax - xmin) / self.maxq
+        return scale, torch.round(-xmin / scale)
+
+    def find_params_per_token_groupwise(self, x):
+        shape = x.shape
+        g = x.reshape(-1, x.shape[-2], x.shape[-1] // self.groupsize, self.groupsize)
+        xmax = torch.amax(g, dim=3, keepdim=True) * self.clip_ratio
+        xmin = torch.amin(g, dim=3, keepdim=True) * self.clip_ratio
+        scale, zero = self._ranges(xmin, xmax)
+        self.scale = scale.expand(-1, -1, -1, self.groupsize).reshape(shape)
+        self.zero = zero.expand(-1, -1, -1, self.groupsize).reshape(shape)
+
+    def find_params(self, x):
+        if self.bits == 16:
+            return
+        self.maxq = self.maxq.to(x.device)
+        shape = x.shape
+        if self.act_per_tensor:
+            z = torch.zeros((), dtype=x.dtype, device=x.device)
+            xmin = torch.minimum(x.min(), z) * self.clip_ratio
+            xmax = torch.maximum(x.max(), z) * self.clip_ratio
+            if self.sym:
+                amax = torch.maximum(torch.abs(xmin), xmax)
+                self.scale = 1 if amax == 0 else amax / self.maxq
+                self.zero = torch.zeros_like(amax)
+            else:
+                xmin = -1 if xmin == 0 else xmin     # each end is patched on its own upstream
+                xmax = 1 if xmax == 0 else xmax
+                self.scale = (xmax - xmin) / self.maxq
+                self.zero = torch.round(-xmin / self.scale)
+            return
+        if self.groupsize > 0:
+            self.find_params_per_token_groupwise(x)
+            utils.cleanup_memory(verbos=False)
+            return
+        rows = x.reshape(-1, shape[-1])
+        z = torch.zeros(rows.shape[0], device=x.device)
+        xmin = torch.minimum(rows.min(1)[0], z) * self.clip_ratio
+        xmax = torch.maximum(rows.max(1)[0], z) * self.clip_ratio
+        scale, zero = self._ranges(xmin, xmax)
+        self.scale = scale.unsqueeze(1).expand(-1, shape[-1]).reshape(shape)
+        self.zero = zero.unsqueeze(1).expand(-1, shape[-1]).reshape(shape)
+
+
+# =============================================================================== ActQuantWrapper
+class _NullHandle:
+    def remove(self):
+        pass
+
+
+class ActQuantWrapper(torch.nn.Module):
+    """Wraps ``nn.Linear | Conv2d | Conv3d``: [pad ->] online Hadamard -> activation
+    quantizer -> the wrapped module.  ``split`` keeps channel 0 in floating point (L1) and
+    quantizes the rest (L2).
+
+    Attribute and sub-module names (``module``, ``L1``, ``L2``, ``quantizer``,
+    ``out_quantizer``, ``had_K``, ``K``, ``online_full_had``, ``fp32_had``, ``split`` ...)
+    are part of the contract: GPTQ matches them by string and pickled checkpoints bake in
+    the import path ``fake_quant.quant_utils.ActQuantWrapper``.
+    """
+
+    def __init__(self, module: torch.nn.Linear, act_per_tensor=False):
+        super().__init__()
+        assert isinstance(module, (torch.nn.Linear, torch.nn.Conv2d, torch.nn.Conv3d))
+        self.module = module
+        self.weight = module.weight
+        self.bias = module.bias
+        self.quantizer = ActQuantizer(act_per_tensor)
+        self.out_quantizer = ActQuantizer(act_per_tensor)
+        self.register_buffer("had_K", torch.tensor(0))
+        self._buffers["had_K"] = None
+        self.K = 1
+        self.online_full_had = False
+        self.online_partial_had = False
+        self.had_dim = 0
+        self.fp32_had = False
+        self.split = False
+        # real-integer backend state (not part of the upstream surface)
+        self.real_quant = True          # set False to force the simulated path
+        self.weight_quantizers = {}     # sub-module name ("module" / "L2") -> WeightQuantizer
+        self.pad_to = None              # folded revise_down_input hook
+        self._real = None
+
+    # pickled checkpoints must not drag device handles along
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_real"] = None
+        return state
+
+    def extra_repr(self) -> str:
+        def kind(qz):
+            if qz.bits >= 16:
+                return ""
+            if getattr(qz, "static", False):
+                return " (Static Per-Tensor%s)" % (", MSQ" if getattr(qz, "msq", False) else "")
+            return " (Symmetric Per-Token)" if qz.sym else " (Asymmetric Per-Token)"
+        return (f"Input Quantizer Bits: {self.quantizer.bits}{kind(self.quantizer)}\n"
+                f"Output Quantizer Bits: {self.out_quantizer.bits}{kind(self.out_quantizer)}")
+
+    def register_forward_pre_hook(self, hook, *args, **kwargs):
+        """The drivers pad ``down_proj`` inputs with a ``revise_down_input`` pre-hook.  That
+        hook is folded into the wrapper (``pad_to``) so the fused kernel can read the unpadded
+        activations; any other hook is registered normally."""
+        if isinstance(hook, functools.partial) and hook.func is utils.revise_down_input:
+            self.pad_to = hook.keywords.get("new_size", hook.args[0] if hook.args else None)
+            return _NullHandle()
+        return super().register_forward_pre_hook(hook, *args, **kwargs)
+
+    def split_weights(self):
+        """L1 = column 0, L2 = columns 1: of the wrapped weight (views until a weight pass
+        rebinds ``.data``); L2 inherits the bias."""
+        mod = self.module
+        dev = mod.weight.device
+        has_bias = mod.bias is not None
+        self.L1 = torch.nn.Linear(1, mod.out_features, bias=False).to(dev)
+        self.L2 = torch.nn.Linear(mod.in_features - 1, mod.out_features, bias=has_bias).to(dev)
+        self.L1.weight.data = mod.weight.data[:, 0:1]
+        self.L2.weight.data = mod.weight.data[:, 1:]
+        if has_bias:
+            self.L2.bias.data = mod.bias.data
+        self._real = None
+
+    # ------------------------------------------------------------------ real-integer backend
+    def invalidate_real(self):
+        self._real = None
+
+    def _weight_module(self):
+        return ("L2", self.L2) if self.split else ("module", self.module)
+
+    def _real_ready(self, x) -> bool:
+        qz = self.quantizer
+        if not (self.real_quant and qz.static and qz.quant and not qz.calibrate):
+            return False
+        if qz.bits != 8 or self.out_quantizer.bits < 16 or self.online_partial_had:
+            return False
+        if x.dtype not in (torch.float16, torch.bfloat16, torch.float32):
+            return False
+        name, _ = self._weight_module()
+        wq = self.weight_quantizers.get(name)
+        if wq is None or not getattr(wq, "sym", False) or wq.bits not in (4, 8):
+            return False
+        if qz.quantizer.scale is None or qz.quantizer.scale.numel() != 1:
+            return False                                   # channel_wise scales: simulated path
+        mod = self.module
+        if isinstance(mod, torch.nn.Linear):
+            return True
+        # a convolution is a GEMM when the kernel covers the whole (un-padded) input patch
+        return (not self.split and not self.online_full_had and x.dim() == mod.weight.dim()
+                and tuple(x.shape[2:]) == tuple(mod.kernel_size)
+                and all(p == 0 for p in mod.padding) and mod.groups == 1)
+
+    def _build_real(self, device):
+        from mquant_amd import ops
+        from mquant_amd.engine import HadamardSpec, W4A8Linear
+        name, wmod = self._weight_module()
+        wq = self.weight_quantizers[name]
+        W = wmod.weight.data.to(device)
+        W2 = W.reshape(W.shape[0], -1)
+        scale = wq.scale.reshape(-1).to(device=device, dtype=torch.float32)
+        if scale.numel() == 1:
+            scale = scale.expand(W2.shape[0]).contiguous()
+        levels = ops.weight_levels(W2, scale, wq.bits)
+        w0 = None
+        bias = wmod.bias
+        if self.split:
+            levels = torch.cat((torch.zeros_like(levels[:, :1]), levels), dim=1).contiguous()
+            w0 = self.L1.weight.data.to(device).reshape(-1).float()
+        had = None
+        if self.online_full_had:
+            n = levels.shape[1]
+            had = HadamardSpec(n, self.K, hadamard_utils._bits_for(self.had_K, self.K, device),
+                               bool(self.fp32_had))
+        qz = self.quantizer
+        s0 = float(qz.quantizer.scale)
+        s1 = None
+        if qz.msq:
+            s1 = float(qz.quantizer_text.scale) if qz.quantizer_text.scale is not None else s0
+        self._real = W4A8Linear(levels, scale, wq.bits,
+                                None if bias is None else bias.data.to(device), s0, s1,
+                                had=had, w0=w0)
+        return self._real
+
+    def _forward_real(self, x):
+        if not x.is_cuda:
+            from mquant_amd._lib import MQuantHipError
+            raise MQuantHipError("ActQuantWrapper: the quantized W4A8 path runs on the GPU only; "
+                                 "there is no CPU fallback (got a CPU tensor)")
+        real = self._real if self._real is not None else self._build_real(x.device)
+        if isinstance(self.module, torch.nn.Linear):
+            rows = x.reshape(-1, x.shape[-1])
+            out_shape = (*x.shape[:-1], real.N)
+        else:
+            rows = x.reshape(x.shape[0], -1)
+            out_shape = (x.shape[0], real.N) + (1,) * (x.dim() - 2)
+        sel = _row_mask(rows.shape[0], x.device) if self.quantizer.msq else None
+        return real.forward(rows, sel).reshape(out_shape)
+
+    # ------------------------------------------------------------------ forward
+    def _rotate(self, x, x_dtype):
+        if self.pad_to is not None and x.shape[-1] < self.pad_to:
+            x = torch.nn.functional.pad(x, (0, self.pad_to - x.shape[-1]))
+        if self.online_full_had:
+            if self.fp32_had:
+                x = hadamard_utils.matmul_hadU_cuda(x.float(), self.had_K, self.K).to(x_dtype)
+            else:
+                x = hadamard_utils.matmul_hadU_cuda(x, self.had_K, self.K)
+        elif self.online_partial_had:
+            shape = x.shape
+            xf = x.float() if self.fp32_had else x
+            heads = shape[-1] // self.had_dim
+            v = xf.reshape(-1, heads, self.had_dim)
+            if self.K == 1:   # Walsh-Hadamard across heads, for every within-head index
+                v = hadamard_utils._fht_blocks(v.transpose(1, 2).contiguous(), heads).transpose(1, 2)
+            else:
+                v = (self.had_K.to(v.dtype) @ v) / math.sqrt(heads)
+            x = v.to(x_dtype).reshape(shape) if self.fp32_had else v.reshape(shape)
+        return x
+
+    def _quantize_input(self, x, x_dtype):
+        qz = self.quantizer
+        if qz.static:
+            return qz(x)
+        if qz.bits < 16:
+            qz.find_params(x)
+            x = qz(x).to(x_dtype)
+            qz.free()
+        return x
+
+    def forward(self, x):
+        if self._real_ready(x):
+            return self._forward_real(x)
+        qz = self.quantizer
+        if qz.static and qz.quant and not x.is_cuda:
+            from mquant_amd._lib import MQuantHipError
+            raise MQuantHipError("ActQuantWrapper: static quantized forward needs a CUDA tensor "
+                                 "(no CPU fallback)")
+        x_dtype = x.dtype
+        x = self._rotate(x, x_dtype)
+        if self.split:
+            x[..., 1:] = self._quantize_input(x[..., 1:], x_dtype)
+            lead = self.L1.float()(x[..., 0:1].float())
+            rest = self.L2.float()(x[..., 1:].float())
+            x = (lead + rest).to(x_dtype)
+        else:
+            x = self.module(self._quantize_input(x, x_dtype)).to(x_dtype)
+        oq = self.out_quantizer
+        if oq.bits < 16:
+            oq.find_params(x)
+            x = oq(x).to(x_dtype)
+            oq.free()
+        return x
+
+
+class ActRotateWrapper(torch.nn.Module):
+    """Rotates two inputs by a dense Q before calling ``module(x, y)`` (no upstream caller)."""
+
+    def __init__(self, module: torch.nn.Module, QMatrix):
+        super().__init__()
+        self.module = module
+        self.register_buffer("q_matrix", QMatrix)
+        self.fp32_had = False
+
+    def forward(self, x, y):
+        x_dtype = x.dtype
+        if self.fp32_had:
+            x = (x.float() @ self.q_matrix).to(x_dtype)
+            y.copy_((y.float() @ self.q_matrix).to(y.dtype))
+        else:
+            x = x @ self.q_matrix
+            y.copy_(y @ self.q_matrix.to(y.dtype))
+        return self.module(x, y).to(x_dtype)
+
+
+# =============================================================================== WeightQuantizer
+class WeightQuantizer(torch.nn.Module):
+    """Round-to-nearest weight quantizer (GPTQ lineage): per output channel (``perchannel``)
+    or per tensor, symmetric or affine, optional MSE clip search over shrink factors
+    p = 1 - i/grid, i < maxshrink*grid, error = sum |q - x|^norm."""
+
+    def __init__(self, shape=1):
+        super().__init__()
+        self.register_buffer("maxq", torch.tensor(0))
+        self.register_buffer("scale", torch.zeros(shape))
+        self.register_buffer("zero", torch.zeros(shape))
+
+    def configure(self, bits, perchannel=False, sym=True, mse=False, norm=2.4, grid=100,
+                  maxshrink=0.8):
+        self.bits = bits
+        self.perchannel = perchannel
+        self.sym = sym
+        self.mse = mse
+        self.norm = norm
+        self.grid = grid
+        self.maxshrink = maxshrink
+        self.maxq = torch.tensor(2 ** (bits - 1) - 1 if sym else 2 ** bits - 1)
+
+    def _grid_params(self, lo, hi):
+        if self.sym:
+            scale = hi / self.maxq
+            return scale, torch.zeros_like(scale)
+        scale = (hi - lo) / self.maxq
+        return scale, torch.round(-lo / scale)
+
+    def _fake(self, x, scale, zero):
+        if self.sym:
+            return sym_quant_dequant(x, scale, self.maxq)
+        return asym_quant_dequant(x, scale, zero, self.maxq)
+
+    def find_params(self, x):
+        if self.bits == 16:
+            return
+        dev = x.device
+        self.maxq = self.maxq.to(dev)
+        shape = x.shape
+        rows = x.flatten(1) if self.perchannel else x.flatten().unsqueeze(0)
+        z = torch.zeros(rows.shape[0], device=dev)
+        xmin = torch.minimum(rows.min(1)[0], z)
+        xmax = torch.maximum(rows.max(1)[0], z)
+        if self.sym:
+            xmax = torch.maximum(torch.abs(xmin), xmax).clamp(min=1e-5)
+            self.scale = xmax / self.maxq
+            self.zero = torch.zeros_like(self.scale)
+        else:
+            dead = (xmin == 0) & (xmax == 0)
+            xmin[dead] = -1
+            xmax[dead] = +1
+            self.scale = (xmax - xmin).clamp(min=1e-5) / self.maxq
+            self.zero = torch.round(-xmin / self.scale)
+        if self.mse:
+            best = torch.full([rows.shape[0]], float("inf"), device=dev)
+            for i in range(int(self.maxshrink * self.grid)):
+                p = 1 - i / self.grid
+                scale1, zero1 = self._grid_params(p * xmin, p * xmax)
+                err = self._fake(rows, scale1.unsqueeze(1), zero1.unsqueeze(1))
+                err -= rows
+                err.abs_()
+                err.pow_(self.norm)
+                err = torch.sum(err, 1)
+                better = err < best
+                if torch.any(better):
+                    best[better] = err[better]
+                    self.scale[better] = scale1[better]
+                    self.zero[better] = zero1[better]
+        if not self.perchannel:
+            self.scale = self.scale.repeat(shape[0])
+            self.zero = self.zero.repeat(shape[0])
+        bshape = [-1] + [1] * (len(shape) - 1)
+        self.scale = self.scale.reshape(bshape)
+        self.zero = self.zero.reshape(bshape)
+
+    def quantize(self, x):
+        if self.ready() and self.bits < 16:
+            return self._fake(x, self.scale, self.zero).to(x.dtype)
+        return x
+
+    def enabled(self):
+        return self.maxq > 0
+
+    def ready(self):
+        return torch.all(self.scale != 0)
+
+
+def attach_weight_quantizer(wrapper: ActQuantWrapper, submodule: str, quantizer) -> None:
+    """Tell a wrapper which ``WeightQuantizer`` produced the (fake-quantized) weight of its
+    sub-module ``"module"`` / ``"L2"``; this is what lets ``forward`` recover the integer
+    levels and switch to the real W4A8 kernels.  The RTN / GPTQ passes call it."""
+    wrapper.weight_quantizers[submodule] = quantizer
+    wrapper.invalidate_real()
+
+
+def attach_weight_quantizers(model, quantizers: dict, prefix: str = "") -> int:
+    """Map a ``{dotted_name: WeightQuantizer}`` dict (the return value of the
+    ``*_rtn_gptq_fwrd_plus`` passes) onto the wrappers under ``model``; returns the count."""
+    wrappers = find_qlayers(model, layers=[ActQuantWrapper], name=prefix)
+    n = 0
+    for name, qz in quantizers.items():
+        for sub in ("module", "L2"):
+            tail = "." + sub
+            owner = name[: -len(tail)] if name.endswith(tail) else None
+            if owner is not None and owner in wrappers:
+                attach_weight_quantizer(wrappers[owner], sub, qz)
+                n += 1
+    return n
+
+
+# =============================================================================== module surgery
+@torch.no_grad()
+def fuse_internvl(model):
+    """Fold InternViT's LayerScale vectors (ls1, ls2) into attn.proj / mlp.fc2."""
+    print("fuse internvl vision model...")
+    for layer in model.model.vision_model.encoder.layers:
+        for lin, ls in ((layer.attn.proj, layer.ls1), (layer.mlp.fc2, layer.ls2)):
+            lin.weight.data *= ls.data.view(-1, 1)
+            if getattr(lin, "bias", None) is not None:
+                lin.bias.data *= ls.data
+            ls[:] = 1
+
+
+def add_actquant(module, act_per_tensor=False, name="", layers=[torch.nn.Linear]):
+    """Recursively wrap every attribute / Sequential entry / ModuleList entry whose EXACT type
+    is in ``layers`` (sub-classes are deliberately not matched).  Idempotent."""
+    if isinstance(module, ActQuantWrapper):
+        return
+
+    def wrap(child):
+        return ActQuantWrapper(child, act_per_tensor) if type(child) in layers else child
+
+    for attr in dir(module):
+        tmp = getattr(module, attr)
+        if type(tmp) in layers:
+            setattr(module, attr, ActQuantWrapper(tmp, act_per_tensor))
+        elif type(tmp) == torch.nn.Sequential:
+            setattr(module, attr, torch.nn.Sequential(
+                OrderedDict((n, wrap(c)) for n, c in tmp.named_children())))
+        elif type(tmp) == torch.nn.ModuleList:
+            setattr(module, attr, torch.nn.ModuleList([wrap(c) for c in tmp.children()]))
+    for child_name, child in module.named_children():
+        add_actquant(child, act_per_tensor, f"{name}.{child_name}" if name else child_name,
+                     [torch.nn.Linear])
+
+
+def add_actquant_for_mlp1(module, act_per_tensor=False, name="", layers=[torch.nn.Linear]):
+    for i in (1, 3):
+        module.mlp1[i] = ActQuantWrapper(module.mlp1[i], act_per_tensor)
+
+
+def internvl_add_act_qaunt(model, args):
+    if args.quant_llm:
+        add_actquant(model.model.language_model.model, args.act_per_tensor)
+    if args.quant_visual_clip:
+        emb = model.model.vision_model.embeddings
+        emb.patch_embedding = ActQuantWrapper(emb.patch_embedding, args.act_per_tensor)
+        add_actquant(model.model.vision_model.encoder, args.act_per_tensor)
+    if args.quant_cross_attention:
+        add_actquant_for_mlp1(model.model, args.act_per_tensor)
+
+
+def qwen2vl_add_act_qaunt(model, args):
+    if args.quant_llm:
+        add_actquant(model.model.model, args.act_per_tensor)
+    if args.quant_visual_clip:
+        pe = model.model.visual.patch_embed
+        pe.proj = ActQuantWrapper(pe.proj, args.act_per_tensor)
+        add_actquant(model.model.visual.blocks, args.act_per_tensor)
+    if args.quant_cross_attention:
+        add_actquant(model.model.visual.merger, args.act_per_tensor)
+
+
+def qwenvl_add_act_qaunt(model, args):
+    if args.quant_llm:
+        add_actquant(model.transformer.h, args.act_per_tensor)
+    vis = model.transformer.visual
+    if args.quant_visual_clip:
+        vis.conv1 = ActQuantWrapper(vis.conv1, args.act_per_tensor)
+        add_actquant(vis.transformer, args.act_per_tensor)
+    if args.quant_cross_attention:
+        add_actquant(vis.attn_pool, args.act_per_tensor)
+        vis.proj_fc = ActQuantWrapper(vis.proj_fc, args.act_per_tensor)
+
+
+def minicpmv_add_act_qaunt(model, args):
+    if args.quant_llm:
+        add_actquant(model.llm.model.layers, args.act_per_tensor)
+    if args.quant_visual_clip:
+        emb = model.vpm.embeddings
+        emb.patch_embedding = ActQuantWrapper(emb.patch_embedding, args.act_per_tensor)
+        add_actquant(model.vpm.encoder, args.act_per_tensor)
+    if args.quant_cross_attention:
+        add_actquant(model.resampler, args.act_per_tensor)
+
+
+def find_qlayers(module, layers=[torch.nn.Linear, ActQuantWrapper], name=""):
+    """{dotted name: module} for every descendant whose exact type is in ``layers``
+    (matched modules are not descended into)."""
+    if type(module) in layers:
+        return {name: module}
+    found = {}
+    for child_name, child in module.named_children():
+        found.update(find_qlayers(child, layers=layers,
+                                  name=f"{name}.{child_name}" if name != "" else child_name))
+    return found
+
+
+def _set_flag(model, args, flag, value):
+    for name, wrapper in find_qlayers(model, layers=[ActQuantWrapper]).items():
+        if any(p in name for p in args.skip_names):
+            continue
+        setattr(wrapper.quantizer, flag, value)
+        wrapper.invalidate_real()
+    return model
+
+
+def model_open_calibrate(model, args):
+    return _set_flag(model, args, "calibrate", True)
+
+
+def model_open_last_calibrate(model, args):
+    return _set_flag(model, args, "last_calibrate", True)
+
+
+def model_close_calibrate(model, args):
+    return _set_flag(model, args, "calibrate", False)
+
+
+def model_quant(model, args):
+    return _set_flag(model, args, "quant", True)
+
+
+def model_no_quant(model, args):
+    return _set_flag(model, args, "quant", False)
+
+
+# =============================================================================== calibration
+def _calibrate_vlmeval(model, args, dataset, calib_num, kwargs_attr, restore):
+    """open -> one ``generate`` per sampled record (20 new tokens; the last one with
+    ``last_calibrate`` and a single new token) -> close -> quant."""
+    from tqdm import tqdm
+    total = len(dataset.data)
+    step = math.ceil(total / calib_num)
+    print("Calibrating...")
+    model_open_calibrate(model.model, args)
+    kwargs = getattr(model, kwargs_attr)
+    kwargs["max_new_tokens"] = 20
+    for i in tqdm(range(0, total, step)):
+        if i + step >= total:
+            print("last calibrate")
+            model_open_last_calibrate(model.model, args)
+            kwargs["max_new_tokens"] = 1
+        record = dataset.data.iloc[i]
+        if hasattr(model, "use_custom_prompt") and model.use_custom_prompt(args.dataset_name):
+            struct = model.build_prompt(record, dataset=args.dataset_name)
+        else:
+            struct = dataset.build_prompt(record)
+        model.generate(message=struct, dataset=args.dataset_name)
+    restore(model)
+    model_close_calibrate(model.model, args)
+    print("Calibrate End...")
+    model_quant(model.model, args)
+
+
+def calib_vqa_plus(model, args, dataset, calib_num):
+    def restore(m):
+        m.kwargs = {}
+    _calibrate_vlmeval(model, args, dataset, calib_num, "kwargs", restore)
+
+
+def calib_qwen2vl_plus(model, args, dataset, calib_num):
+    saved = model.generate_kwargs["max_new_tokens"]
+
+    def restore(m):
+        m.generate_kwargs["max_new_tokens"] = saved
+    _calibrate_vlmeval(model, args, dataset, calib_num, "generate_kwargs", restore)
+
+
+def calib_layer(wrapper_or_model, batches, args=None):
+    """Protocol helper for stand-alone layers / toy models: open -> forward every batch (the
+    last one with ``last_calibrate``) -> close -> quant.  ``batches`` are positional inputs."""
+    class _A:
+        skip_names = []
+    args = args or _A()
+    model_open_calibrate(wrapper_or_model, args)
+    for i, b in enumerate(batches):
+        if i == len(batches) - 1:
+            model_open_last_calibrate(wrapper_or_model, args)
+        wrapper_or_model(b)
+    model_close_calibrate(wrapper_or_model, args)
+    model_quant(wrapper_or_model, args)
+    return wrapper_or_model

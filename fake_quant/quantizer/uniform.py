@@ -1,0 +1,50 @@
+"""Uniform affine quantizer: q = clamp(round(x / s + zp), lo, hi), x_hat = (q - zp) * s
+(reference ``fake_quant/quantizer/uniform.py:20-43``).
+
+``forward`` on a CUDA tensor with per-tensor or last-dim per-channel parameters runs the
+fused gfx950 kernel ``mq_fakequant_act`` (one read, one write) instead of eight elementwise
+launches; the arithmetic is identical (IEEE division, round-half-even, fp32 dequant).
+"""
+import torch
+
+from .base import BaseQuantizer
+
+
+class UniformQuantizer(BaseQuantizer):
+    def __init__(self, bit_type, observer, module_type):
+        super().__init__(bit_type, observer, module_type)
+        self.scale = None
+        self.zero_point = None
+
+    def update_quantization_params(self, *args, **kwargs):
+        self.scale, self.zero_point = self.observer.get_quantization_params(*args, **kwargs)
+
+    def _params(self, inputs, scale, zero_point):
+        scale = self.scale if scale is None else scale
+        zero_point = self.zero_point if zero_point is None else zero_point
+        shape = self.get_reshape_range(inputs)
+        return scale.reshape(shape), zero_point.reshape(shape)
+
+    def quant(self, inputs, scale=None, zero_point=None):
+        s, z = self._params(inputs, scale, zero_point)
+        q = inputs / s + z
+        return q.round().clamp(self.bit_type.lower_bound, self.bit_type.upper_bound)
+
+    def dequantize(self, inputs, scale=None, zero_point=None):
+        s, z = self._params(inputs, scale, zero_point)
+        return (inputs - z) * s
+
+    def _fused_ok(self, x):
+        return (x.is_cuda and self.module_type == "activation" and x.dim() in (2, 3)
+                and x.dtype in (torch.float16, torch.bfloat16, torch.float32)
+                and self.bit_type.bits == 8 and self.bit_type.signed
+                and self.scale is not None and not bool(torch.any(self.zero_point != 0)))
+
+    def forward(self, inputs):
+        if self._fused_ok(inputs):
+            from mquant_amd import ops
+            if self.scale.numel() == 1:
+                return ops.fakequant_act(inputs, float(self.scale))
+            vec = self.scale.reshape(-1).to(device=inputs.device, dtype=torch.float32).contiguous()
+            return ops.fakequant_act(inputs, scale_vec0=vec)
+        return super().forward(inputs)

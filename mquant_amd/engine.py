@@ -1,0 +1,116 @@
+"""Real-integer execution of one wrapped Linear: the object ``ActQuantWrapper`` freezes into.
+
+``W4A8Linear`` owns the pre-tiled int4/int8 weight image, the per-channel weight scales, the
+static activation scale set(s), the optional online-Hadamard descriptor and the optional
+rank-1 ``split`` term; ``forward`` is two kernel launches (quantize or Hadamard+quantize,
+then the MFMA GEMM with fused dequant).  Everything here is stream-ordered and allocation
+free after the first call for a given row count.
+
+Reference semantics: ``ActQuantWrapper.forward``, fake_quant/quant_utils.py:330-391.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import ops
+
+
+@dataclass
+class HadamardSpec:
+    n: int                      # padded size the transform runs on
+    K: int                      # special factor (1 for a pure power of two)
+    bits: Optional[torch.Tensor]  # K*K packed sign bits on the device (None when K == 1)
+    fp32_had: bool = False
+
+
+class Workspace:
+    """Per-device cache of int8 activation buffers keyed by (rows, K_pad)."""
+
+    def __init__(self):
+        self._a: Dict[Tuple[int, int, int], torch.Tensor] = {}
+        self._x0: Dict[Tuple[int, int], torch.Tensor] = {}
+
+    def act(self, device, M: int, K_pad: int) -> torch.Tensor:
+        key = (device.index or 0, M, K_pad)
+        buf = self._a.get(key)
+        if buf is None:
+            buf = torch.empty((M, K_pad), dtype=torch.int8, device=device)
+            self._a[key] = buf
+        return buf
+
+    def x0(self, device, M: int) -> torch.Tensor:
+        key = (device.index or 0, M)
+        buf = self._x0.get(key)
+        if buf is None:
+            buf = torch.empty((M,), dtype=torch.float32, device=device)
+            self._x0[key] = buf
+        return buf
+
+
+WORKSPACE = Workspace()
+
+
+class W4A8Linear:
+    """y = dequant( quant(Had(x)) @ W_int^T ) (+ bias) (+ x[:,0] * w0)."""
+
+    def __init__(self, levels: torch.Tensor, s_w: torch.Tensor, w_bits: int,
+                 bias: Optional[torch.Tensor], s_x0: float, s_x1: Optional[float] = None,
+                 had: Optional[HadamardSpec] = None, w0: Optional[torch.Tensor] = None,
+                 in_features: Optional[int] = None):
+        assert levels.is_cuda and levels.dtype == torch.int8 and levels.dim() == 2
+        self.N, self.K = levels.shape
+        self.K_pad = ops.ceil_to(self.K, 128)
+        self.w_bits = w_bits
+        self.split = w0 is not None
+        self.w_img = ops.prepack(levels, w_bits, zero_col0=self.split)
+        self.s_w = s_w.reshape(-1).to(torch.float32).contiguous()
+        self.bias = None if bias is None else bias.reshape(-1).to(torch.float32).contiguous()
+        self.w0 = None if w0 is None else w0.reshape(-1).to(torch.float32).contiguous()
+        self.s_x0 = float(s_x0)
+        self.s_x1 = None if s_x1 is None else float(s_x1)
+        self.had = had
+        self.in_features = self.K if in_features is None else in_features
+        if had is not None:
+            assert had.n == self.K, "Hadamard size must equal the (padded) reduction dim"
+
+    # -- the two launches, exposed separately so callers can share one quantization ----
+    def quantize(self, x2: torch.Tensor, row_sel: Optional[torch.Tensor] = None):
+        M = x2.shape[0]
+        a = WORKSPACE.act(x2.device, M, self.K_pad)
+        x0 = WORKSPACE.x0(x2.device, M) if self.split else None
+        if self.had is not None:
+            ops.hadamard_quant_i8(x2, self.had.n, self.had.K, self.had.bits, self.s_x0, self.s_x1,
+                                  fp32_had=self.had.fp32_had, row_sel=row_sel,
+                                  skip_col0=self.split, out=a, x0_out=x0)
+        else:
+            ops.quantize_act_i8(x2, self.s_x0, self.s_x1, row_sel=row_sel, skip_col0=self.split,
+                                out=a, x0_out=x0)
+        return a, x0
+
+    def gemm(self, a: torch.Tensor, x0: Optional[torch.Tensor], out_dtype: torch.dtype,
+             row_sel: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+        return ops.gemm_w4a8(a, self.w_img, self.w_bits, self.N, self.s_x0, self.s_w,
+                             s_x1=self.s_x1, row_sel=row_sel, bias=self.bias, x0=x0, w0=self.w0,
+                             out_dtype=out_dtype, out=out)
+
+    def forward(self, x: torch.Tensor, row_sel: Optional[torch.Tensor] = None,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        x2 = x.reshape(-1, x.shape[-1])
+        a, x0 = self.quantize(x2, row_sel)
+        y = self.gemm(a, x0, x.dtype, row_sel, out)
+        return y.reshape(*x.shape[:-1], self.N)
+
+    __call__ = forward
+
+    # -- bookkeeping used by bench.py / DESIGN.md ------------------------------------------
+    def gemm_ops(self, M: int) -> int:
+        return 2 * M * self.K_pad * self.N
+
+    def gemm_bytes(self, M: int, out_bytes: int = 2) -> int:
+        return M * self.K_pad + self.K_pad * self.N * self.w_bits // 8 + out_bytes * M * self.N + 4 * self.N
+
+    def quant_bytes(self, M: int, in_bytes: int = 2) -> int:
+        return in_bytes * M * self.in_features + M * self.K_pad

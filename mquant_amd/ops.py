@@ -60,7 +60,7 @@ def quantize_act_i8(x: torch.Tensor, scale0: float = 1.0, scale1: Optional[float
     x2 = _rows(x)
     _need_cuda(x2, scale_vec0, scale_vec1, row_sel, out)
     M, K = x2.shape
-    K_pad = ceil_to(K, 128)
+    K_pad = ceil_to(K, 128) if out is None else out.shape[1]
     if out is None:
         out = torch.empty((M, K_pad), dtype=torch.int8, device=x.device)
     if skip_col0 and x0_out is None:
@@ -109,7 +109,7 @@ def hadamard_quant_i8(x: torch.Tensor, n: int, K: int, had_bits: Optional[torch.
     x2 = _rows(x)
     _need_cuda(x2, had_bits, row_sel, out)
     M, n_in = x2.shape
-    K_pad = ceil_to(n, 128)
+    K_pad = ceil_to(n, 128) if out is None else out.shape[1]
     if out is None:
         out = torch.empty((M, K_pad), dtype=torch.int8, device=x.device)
     if skip_col0 and x0_out is None:
