@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="small shapes (debug only; not a valid bench line)")
+    ap.add_argument("--no-graph", action="store_true", help="launch kernels one by one instead of replaying a hipGraph")
+    ap.add_argument("--no-fuse", action="store_true", help="one GEMM per Linear (no q/k/v, gate/up fusion)")
     args = ap.parse_args()
 
     import torch
@@ -91,14 +93,27 @@ def main():
     from mquant_amd import workload
 
     specs = workload.tiny_specs() if args.tiny else workload.qwen2vl_7b_specs(msq=True)
-    pf = workload.Prefill(specs, device=dev, dtype=torch.float16)
+    pf = workload.Prefill(specs, device=dev, dtype=torch.float16, share_groups=not args.no_fuse)
     tokens_per_step = workload.M_LLM if not args.tiny else specs[-1].M
 
     logits_local = torch.zeros((1, VOCAB), dtype=torch.float16, device=dev)
     logits_all = torch.zeros((world, VOCAB), dtype=torch.float16, device=dev) if distributed else None
 
+    def capture(fn):
+        """Launch-bound inner loop -> one hipGraph (the kernels themselves are unchanged)."""
+        if args.no_graph:
+            return fn
+        fn()                      # first-call allocations / attribute setup happen outside capture
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        return g.replay
+
+    run_prefill = capture(pf.step)
+
     def step():
-        pf.step()
+        run_prefill()
         if distributed:
             dist.all_gather_into_tensor(logits_all, logits_local)
 
@@ -125,17 +140,19 @@ def main():
     # ---- kernel attribution: the GEMM launches of a step alone, HIP events on the launch stream
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = max(3, min(args.steps, 10))
-    pf.step_gemm_only()
+    run_gemms = capture(pf.step_gemm_only)
+    run_quants = capture(pf.step_quant_only)
+    run_gemms()
     torch.cuda.synchronize(dev)
     e0.record()
     for _ in range(reps):
-        pf.step_gemm_only()
+        run_gemms()
     e1.record()
     torch.cuda.synchronize(dev)
     gemm_ms = e0.elapsed_time(e1) / reps
     e0.record()
     for _ in range(reps):
-        pf.step_quant_only()
+        run_quants()
     e1.record()
     torch.cuda.synchronize(dev)
     quant_ms = e0.elapsed_time(e1) / reps
@@ -158,11 +175,12 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "int8",
             "data": "synthetic (random weights with the real shapes, random activations with outlier channels)",
             "config": {"workload": "Qwen2-VL-7B W4A8 MSQ prefill, 1x448^2 image (1024 vision tokens) + "
-                                   "512 text tokens, 327 wrapped Linears, M_llm=768" if not args.tiny
+                                   "512 text tokens, 327 wrapped Linears, M_llm=768" + ("" if args.no_fuse else " (q/k/v and gate/up share one quantization and one GEMM)") if not args.tiny
                        else "tiny debug shapes",
                        "tokens_per_step_per_gpu": tokens_per_step, "parallelism": f"batch-shard x{world}",
                        "ttft_hot_path_ms": round(ms_per_step, 4),
                        "gemm_TOP_per_step": round(pf.gemm_ops() / 1e12, 3),
+                       "hip_graph": not args.no_graph,
                        "weights_GB": round(pf.weight_bytes() / 1e9, 3)},
             "roofline": roofline}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

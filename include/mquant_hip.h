@@ -151,6 +151,28 @@ int mq_gemm_w4a8(const int8_t *a, long lda, const void *w, int w_bits,
 int mq_gemm_w4a8_i32(const int8_t *a, long lda, const void *w, int w_bits,
                      long M, long N, long K_pad, int32_t *acc, long ldacc, void *stream);
 
+/* Same two entry points with a caller-owned scratch buffer, which lets the library split
+ * the reduction over workgroups when M x N alone cannot fill the 256 CUs (e.g. down_proj:
+ * K = 19968, N = 3584).  Partial sums are int32 and are combined in a fixed order, so the
+ * result is bit-identical to the unsplit call.  workspace: 16-byte aligned device memory,
+ * workspace_bytes >= 8 * M * N * 4 allows every split factor the heuristic may pick;
+ * smaller buffers merely restrict it.  workspace == NULL degrades to the calls above. */
+int mq_gemm_w4a8_ws(const int8_t *a, long lda, const void *w, int w_bits,
+                    long M, long N, long K_pad,
+                    float s_x0, float s_x1, const uint8_t *row_sel,
+                    const float *s_w, const float *bias,
+                    const float *x0, const float *w0,
+                    void *out, int out_dtype, long ldo,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+int mq_gemm_w4a8_i32_ws(const int8_t *a, long lda, const void *w, int w_bits,
+                        long M, long N, long K_pad, int32_t *acc, long ldacc,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* Tuning / test hook (process-wide, not part of the drop-in surface): force the tile shape
+ * (-1 heuristic, 0: 128x128, 1: 256x256, 2: 256x128) and the split-K factor (0 heuristic). */
+int mq_gemm_debug_force(int tile, int splits);
+
 /* ---------------------------------------------------------------------------
  * Min/max observer reduction.  Replaces the two reductions of
  * MinmaxObserver.update, fake_quant/observer/minmax.py:13-28 (after

@@ -3,22 +3,25 @@
 //   acc[m][n] = sum_k a[m][k] * w[n][k]        V_MFMA_I32_16X16X64_I8, exact
 //   y[m][n]   = ((float(acc) * s_x[sel(m)]) * s_w[n]) + bias[n] + x0[m] * w0[n]
 //
-// Structure (one workgroup = BM x BN output tile, K walked in steps of 128):
-//   * both operands arrive by LDS-DMA (global_load_lds, 16 B per lane); the LDS image of
-//     every 16x64 fragment is lane-linear (lane l at byte 16*l), so fragment reads are
-//     conflict-free ds_read_b128 with no swizzle:
+// Structure (one workgroup = BM x BN output tile, K walked in steps of 128 bytes):
+//   * both operands arrive by LDS-DMA (global_load_lds, 16 B per lane) into a STAGES-deep
+//     ring; loads stay in flight across the single per-step s_barrier (counted vmcnt,
+//     never 0 in the steady state);
+//   * the LDS image of every 16x64 fragment is lane-linear (lane l at byte 16*l), so
+//     fragment reads are conflict-free ds_read_b128 / ds_read_b64 with no swizzle:
 //       - weights are stored pre-tiled in HBM in exactly that order (weight_formats.hip);
 //       - activations are row-major in HBM, the per-lane SOURCE address does the
-//         re-tiling (row = m0 + (l & 15), bytes 16*(l >> 4) .. +16 of the 64-wide k-tile).
-//   * int4 weights stay packed in LDS; each wave expands the nibbles it is about to feed to
-//     the matrix core into the HIGH nibble of int8 bytes (two VALU ops per 8 weights, no
-//     sign-extension needed); the resulting x16 factor is removed by an exact arithmetic
-//     shift before dequantisation.
+//         re-tiling (row = m0 + (l & 15), bytes 16*(l >> 4) .. +16 of the 64-wide k-tile);
+//   * int4 weights stay packed in LDS; each wave expands the nibbles it is about to feed
+//     to the matrix core into the HIGH nibble of int8 bytes (three VALU ops per 8 weights,
+//     no sign-extension); the x16 factor is removed by an exact arithmetic shift;
 //   * the weight fragment is the MFMA "A" operand and the activation fragment the "B"
-//     operand, so every lane ends up with 4 consecutive output channels of one row: the
-//     epilogue reads s_w / bias / w0 as float4 and stores 8 B (fp16) per lane.
-//   * 2-stage LDS ring: the DMA of step t+1 is issued right after the barrier that
-//     publishes step t and flies under the MFMAs of step t.
+//     operand, so every lane ends up with 4 consecutive output channels of one row;
+//   * workgroup -> tile map is XCD-aware (8 XCDs, private L2s): the m-blocks that share a
+//     weight panel are consecutive on ONE XCD;
+//   * optional split-K: integer partial sums go to a workspace and are combined by
+//     splitk_reduce_kernel in a fixed order (integer addition: exact and order-free),
+//     which also applies the dequant epilogue.
 //
 // Reference semantics: fake_quant/quant_utils.py:384 (F.linear on fake-quant tensors) and
 // :367-376 (split: channel 0 through L1 in fp32).
@@ -47,9 +50,67 @@ struct GemmArgs {
     const float *s_w, *bias, *x0, *w0;
     void *out;
     long ldo;
+    int splits;        // split-K factor (1 = none)
+    int vec_ok;        // N, ldo multiples of 4 and 16-byte aligned parameter vectors
+    int32_t *partial;  // [splits][M][N] when splits > 1
 };
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int W_BITS, int EPI>
+// y = ((float(acc) * sx) * s_w[n]) + bias[n] + x0 * w0[n]; one rounding per operation.
+template <int EPI>
+__device__ __forceinline__ void store_quad(const GemmArgs &p, long m, long n, v4i a, float sx,
+                                           float xz)
+{
+    const bool full = (n + 4 <= p.N) && (p.ldo % 4 == 0);
+    if (EPI == EPI_I32) {
+        int *o = reinterpret_cast<int *>(p.out) + m * p.ldo + n;
+        if (full) {
+            *reinterpret_cast<v4i *>(o) = a;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < p.N) o[r] = a[r];
+        }
+        return;
+    }
+    float y[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long nn = (n + r < p.N) ? n + r : p.N - 1;
+        float t = (float)a[r] * sx;
+        t = t * p.s_w[nn];
+        if (p.bias) t = t + p.bias[nn];
+        if (p.x0) {
+            const float pr = xz * p.w0[nn];
+            t = t + pr;
+        }
+        y[r] = t;
+    }
+    if (EPI == EPI_F32) {
+        float *o = reinterpret_cast<float *>(p.out) + m * p.ldo + n;
+        if (full) {
+            *reinterpret_cast<v4f *>(o) = v4f{y[0], y[1], y[2], y[3]};
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < p.N) o[r] = y[r];
+        }
+    } else {
+        unsigned short h[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            h[r] = (EPI == EPI_F16) ? f32_to_f16_bits(y[r]) : f32_to_bf16_bits(y[r]);
+        unsigned short *o = reinterpret_cast<unsigned short *>(p.out) + m * p.ldo + n;
+        if (full) {
+            *reinterpret_cast<v4us *>(o) = v4us{h[0], h[1], h[2], h[3]};
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < p.N) o[r] = h[r];
+        }
+    }
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int W_BITS, int EPI, int DMA_POS>
 __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmArgs p)
 {
     constexpr int NWAVES = WARPS_M * WARPS_N;
@@ -57,9 +118,13 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
     constexpr int TN = BN / WARPS_N / 16;          // weight fragments per wave
     constexpr int X_FRAGS = (BM / 16) * 2;         // 1 KiB DMA pieces per stage (2 k-tiles)
     constexpr int W_PIECES = (W_BITS == 4) ? (BN / 16) : (BN / 16) * 2;
+    constexpr int PIECES = X_FRAGS + W_PIECES;
+    constexpr int LPW = PIECES / NWAVES;           // DMA instructions per wave per stage
     constexpr int X_BYTES = X_FRAGS * 1024;
-    constexpr int STAGE_BYTES = X_BYTES + W_PIECES * 1024;
+    constexpr int STAGE_BYTES = PIECES * 1024;
     static_assert(BM % (WARPS_M * 16) == 0 && BN % (WARPS_N * 16) == 0, "tile shape");
+    static_assert(PIECES % NWAVES == 0, "DMA pieces must divide evenly over the waves");
+    static_assert(STAGES == 2 || STAGES == 3, "ring depth");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -68,55 +133,61 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WARPS_N, wn = wave % WARPS_N;
 
-    // block -> tile: m-blocks fastest so the blocks sharing one weight panel run together
+    // ---- workgroup -> (split, bn, bm), XCD-aware and bijective ------------------------
     const int m_blocks = (int)ceil_div(p.M, BM);
-    const int bm = blockIdx.x % m_blocks;
-    const int bn = blockIdx.x / m_blocks;
+    const int total = gridDim.x;
+    int wid;
+    {
+        const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+        const int q = total >> 3, r = total & 7;
+        wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm = wid % m_blocks;
+    const int rest = wid / m_blocks;
+    const int split = rest % p.splits;
+    const int bn = rest / p.splits;
     const long m0 = (long)bm * BM;
     const long nt0 = (long)bn * (BN / 16);
 
-    const long kps = p.K_pad / 128;  // k-steps
+    const long kps = p.K_pad / 128;  // k-steps in the whole reduction
+    const long k_begin = kps * split / p.splits;
+    const long k_end = kps * (split + 1) / p.splits;
+    const int nk = (int)(k_end - k_begin);
 
-    // ---- per-lane DMA source addresses ----------------------------------------------
-    // activations: piece f = mt*2 + kt handled by wave (f % NWAVES)
-    constexpr int X_PER_WAVE = (X_FRAGS + NWAVES - 1) / NWAVES;
-    constexpr int W_PER_WAVE = (W_PIECES + NWAVES - 1) / NWAVES;
-    const int8_t *xsrc[X_PER_WAVE];
+    // ---- per-lane DMA source addresses (piece f = wave + i*NWAVES) ----------------------
+    const char *src[LPW];
+    int step_bytes[LPW];
 #pragma unroll
-    for (int i = 0; i < X_PER_WAVE; ++i) {
+    for (int i = 0; i < LPW; ++i) {
         const int f = wave + i * NWAVES;
-        const int mt = f >> 1, kt = f & 1;
-        long row = m0 + mt * 16 + (lane & 15);
-        if (row >= p.M) row = p.M - 1;
-        xsrc[i] = p.a + row * p.lda + kt * 64 + (lane >> 4) * 16;
-    }
-    const uint8_t *wsrc[W_PER_WAVE];
-#pragma unroll
-    for (int i = 0; i < W_PER_WAVE; ++i) {
-        const int f = wave + i * NWAVES;
-        if (W_BITS == 4) {
-            long nt = nt0 + f;
+        if (f < X_FRAGS) {
+            const int mt = f >> 1, kt = f & 1;
+            long row = m0 + mt * 16 + (lane & 15);
+            if (row >= p.M) row = p.M - 1;
+            src[i] = reinterpret_cast<const char *>(p.a) + row * p.lda + kt * 64 + (lane >> 4) * 16 +
+                     k_begin * 128;
+            step_bytes[i] = 128;
+        } else if (W_BITS == 4) {
+            long nt = nt0 + (f - X_FRAGS);
             if (nt >= p.n_tiles) nt = p.n_tiles - 1;
-            wsrc[i] = p.w + ((nt * kps) * 64 + lane) * 16;            // + kp*1024 per step
+            src[i] = reinterpret_cast<const char *>(p.w) + ((nt * kps + k_begin) * 64 + lane) * 16;
+            step_bytes[i] = 1024;
         } else {
-            long nt = nt0 + (f >> 1);
+            const int g = f - X_FRAGS;
+            long nt = nt0 + (g >> 1);
             if (nt >= p.n_tiles) nt = p.n_tiles - 1;
-            wsrc[i] = p.w + ((nt * kps * 2 + (f & 1)) * 64 + lane) * 16;  // + kp*2048 per step
+            src[i] = reinterpret_cast<const char *>(p.w) +
+                     (((nt * kps + k_begin) * 2 + (g & 1)) * 64 + lane) * 16;
+            step_bytes[i] = 2048;
         }
     }
 
-    auto issue_stage = [&](int stage, long kp) {
+    auto issue_stage = [&](int stage, int it) {
         char *base = smem + stage * STAGE_BYTES;
 #pragma unroll
-        for (int i = 0; i < X_PER_WAVE; ++i) {
+        for (int i = 0; i < LPW; ++i) {
             const int f = wave + i * NWAVES;
-            if (X_FRAGS % NWAVES == 0 || f < X_FRAGS) dma16(xsrc[i] + kp * 128, base + f * 1024);
-        }
-#pragma unroll
-        for (int i = 0; i < W_PER_WAVE; ++i) {
-            const int f = wave + i * NWAVES;
-            if (W_PIECES % NWAVES == 0 || f < W_PIECES)
-                dma16(wsrc[i] + kp * (W_BITS == 4 ? 1024 : 2048), base + X_BYTES + f * 1024);
+            dma16(src[i] + (long)it * step_bytes[i], base + f * 1024);
         }
     };
 
@@ -126,11 +197,24 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = v4i{0, 0, 0, 0};
 
-    issue_stage(0, 0);
-    for (long kp = 0; kp < kps; ++kp) {
-        const int cur = (int)(kp & 1);
-        __syncthreads();  // hipcc drains vmcnt(0) ahead of the barrier: stage `cur` has landed
-        if (kp + 1 < kps) issue_stage(cur ^ 1, kp + 1);
+    // ---- main loop ------------------------------------------------------------------------
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) issue_stage(s, s);
+
+    int cur = 0;
+    for (int it = 0; it < nk; ++it) {
+        // stage `it` has landed when at most the (STAGES-2) younger stages are outstanding
+        if (STAGES == 3 && it + 1 < nk) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();   // everyone's pieces landed; everyone left stage it-1
+        const bool more = it + STAGES - 1 < nk;
+        int nxt = cur + STAGES - 1;
+        if (nxt >= STAGES) nxt -= STAGES;
+        if (DMA_POS == 0 && more) issue_stage(nxt, it + STAGES - 1);
 
         const char *xs = smem + cur * STAGE_BYTES;
         const char *ws = xs + X_BYTES;
@@ -142,6 +226,10 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
                 const int mt = wm * TM + j;
                 xf[j] = *reinterpret_cast<const v4i *>(xs + (mt * 2 + kt) * 1024 + lane * 16);
             }
+            // the DMA of the stage after next is issued behind the first fragment reads, so its
+            // issue slots overlap MFMA execution instead of delaying the first MFMA of the step
+            if (DMA_POS == 1 && kt == 0 && more) issue_stage(nxt, it + STAGES - 1);
+            if (DMA_POS == 2 && kt == 1 && more) issue_stage(nxt, it + STAGES - 1);
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
                 const int nt = wn * TN + i;
@@ -160,88 +248,161 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
                     acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf, xf[j], acc[i][j], 0, 0, 0);
             }
         }
+        if (++cur == STAGES) cur = 0;
     }
 
-    // ---- epilogue ---------------------------------------------------------------------
+    // ---- epilogue ---------------------------------------------------------------------------
+    // Code executed once per workgroup is instruction-fetch bound (cold I-cache), so the
+    // epilogue is kept SMALL: each wave parks its raw int32 accumulators in a private LDS
+    // slab with a handful of unrolled ds_write_b128, then a ROLLED loop re-reads them
+    // row-contiguously, dequantises and stores 16 B (fp16) / 32 B per lane: whole 128-byte
+    // row segments, edges handled in the same loop.
     // D layout: col = lane & 15 -> m, row = (lane >> 4) * 4 + r -> n
+    constexpr int WN_COLS = TN * 16;                 // columns of the wave's sub-tile
+    constexpr int SLAB_LD = WN_COLS * 4 + 16;        // bytes per slab row (+16: conflict-free)
+    constexpr int RING_BYTES = STAGES * STAGE_BYTES;
+    constexpr int PASS_MT =                          // m-tiles parked per pass (slab must fit)
+        (TM % 4 == 0 && NWAVES * 64 * SLAB_LD <= RING_BYTES) ? 4
+        : (TM % 2 == 0 && NWAVES * 32 * SLAB_LD <= RING_BYTES) ? 2 : 1;
+    constexpr int PASS_ROWS = PASS_MT * 16;
+    constexpr int SLAB_BYTES = PASS_ROWS * SLAB_LD;
+    constexpr int LANES_PER_ROW = WN_COLS / 8;       // 8 outputs per lane
+    constexpr int ROWS_PER_IT = 64 / LANES_PER_ROW;
+    static_assert(NWAVES * SLAB_BYTES <= STAGES * STAGE_BYTES, "epilogue slab must fit the ring");
+    static_assert(TM % PASS_MT == 0 && 64 % LANES_PER_ROW == 0 && PASS_ROWS % ROWS_PER_IT == 0, "epilogue geometry");
+
+    __syncthreads();                                 // every wave has left the operand ring
+    char *slab = smem + wave * SLAB_BYTES;
     const int ml = lane & 15, nq = (lane >> 4) * 4;
+    const bool to_partial = p.splits > 1;
+    const int lrow = lane / LANES_PER_ROW;
+    const int c8 = (lane % LANES_PER_ROW) * 8;
+    const long n = nt0 * 16 + wn * WN_COLS + c8;     // first of this lane's 8 output channels
+    const bool n_full = (n + 8 <= p.N) && p.vec_ok;
+
+    float swv[8], bsv[8], wzv[8];
+    if (EPI != EPI_I32 && !to_partial) {
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-        const long m = m0 + (wm * TM + j) * 16 + ml;
-        if (m >= p.M) continue;
-        float sx = p.sx0, xz = 0.0f;
-        if (EPI != EPI_I32) {
-            if (p.row_sel && p.row_sel[m]) sx = p.sx1;
-            if (p.x0) xz = p.x0[m];
+        for (int e = 0; e < 8; ++e) {
+            const long nn = (n + e < p.N) ? n + e : p.N - 1;
+            swv[e] = p.s_w[nn];
+            bsv[e] = p.bias ? p.bias[nn] : 0.0f;
+            wzv[e] = p.w0 ? p.w0[nn] : 0.0f;
         }
+    }
+
 #pragma unroll
-        for (int i = 0; i < TN; ++i) {
-            const long n = (nt0 + wn * TN + i) * 16 + nq;
-            if (n >= p.N) continue;
-            v4i a = acc[i][j];
+    for (int pass = 0; pass < TM / PASS_MT; ++pass) {
+#pragma unroll
+        for (int jj = 0; jj < PASS_MT; ++jj)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+                *reinterpret_cast<v4i *>(slab + (jj * 16 + ml) * SLAB_LD + (i * 16 + nq) * 4) =
+                    acc[i][pass * PASS_MT + jj];
+        // the slab is wave-private: LDS operations of one wave complete in order
+#pragma unroll 1
+        for (int r0 = 0; r0 < PASS_ROWS; r0 += ROWS_PER_IT) {
+            const int row = r0 + lrow;
+            const long m = m0 + (wm * TM + pass * PASS_MT) * 16 + row;
+            v4i q0 = *reinterpret_cast<const v4i *>(slab + row * SLAB_LD + c8 * 4);
+            v4i q1 = *reinterpret_cast<const v4i *>(slab + row * SLAB_LD + c8 * 4 + 16);
+            if (m >= p.M || n >= p.N) continue;
+            int a[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
             if (W_BITS == 4) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a[r] >>= 4;
+                for (int e = 0; e < 8; ++e) a[e] >>= 4;
             }
-            const bool full = (n + 4 <= p.N);
-            if (EPI == EPI_I32) {
-                int *o = reinterpret_cast<int *>(p.out) + m * p.ldo + n;
-                if (full && (p.ldo % 4 == 0)) {
-                    *reinterpret_cast<v4i *>(o) = a;
+            if (to_partial || EPI == EPI_I32) {
+                int *o = to_partial ? p.partial + ((long)split * p.M + m) * p.N + n
+                                    : reinterpret_cast<int *>(p.out) + m * p.ldo + n;
+                if (n_full) {
+                    *reinterpret_cast<v4i *>(o) = v4i{a[0], a[1], a[2], a[3]};
+                    *reinterpret_cast<v4i *>(o + 4) = v4i{a[4], a[5], a[6], a[7]};
                 } else {
+                    for (int e = 0; e < 8; ++e)
+                        if (n + e < p.N) o[e] = a[e];
+                }
+                continue;
+            }
+            const float sx = (p.row_sel && p.row_sel[m]) ? p.sx1 : p.sx0;
+            const float xz = p.x0 ? p.x0[m] : 0.0f;
+            float y[8];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (n + r < p.N) o[r] = a[r];
+            for (int e = 0; e < 8; ++e) {
+                float t = (float)a[e] * sx;
+                t = t * swv[e];
+                if (p.bias) t = t + bsv[e];
+                if (p.x0) {
+                    const float pr = xz * wzv[e];
+                    t = t + pr;
+                }
+                y[e] = t;
+            }
+            if (EPI == EPI_F32) {
+                float *o = reinterpret_cast<float *>(p.out) + m * p.ldo + n;
+                if (n_full) {
+                    *reinterpret_cast<v4f *>(o) = v4f{y[0], y[1], y[2], y[3]};
+                    *reinterpret_cast<v4f *>(o + 4) = v4f{y[4], y[5], y[6], y[7]};
+                } else {
+                    for (int e = 0; e < 8; ++e)
+                        if (n + e < p.N) o[e] = y[e];
                 }
             } else {
-                float y[4];
+                v8us h;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const long nn = (n + r < p.N) ? n + r : p.N - 1;
-                    float t = (float)a[r] * sx;
-                    t = t * p.s_w[nn];
-                    if (p.bias) t = t + p.bias[nn];
-                    if (p.x0) {
-                        const float pr = xz * p.w0[nn];
-                        t = t + pr;
-                    }
-                    y[r] = t;
-                }
-                if (EPI == EPI_F32) {
-                    float *o = reinterpret_cast<float *>(p.out) + m * p.ldo + n;
-                    if (full && (p.ldo % 4 == 0)) {
-                        *reinterpret_cast<v4f *>(o) = v4f{y[0], y[1], y[2], y[3]};
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (n + r < p.N) o[r] = y[r];
-                    }
+                for (int e = 0; e < 8; ++e)
+                    h[e] = (EPI == EPI_F16) ? f32_to_f16_bits(y[e]) : f32_to_bf16_bits(y[e]);
+                unsigned short *o = reinterpret_cast<unsigned short *>(p.out) + m * p.ldo + n;
+                if (n_full) {
+                    *reinterpret_cast<v8us *>(o) = h;
                 } else {
-                    unsigned short h[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        h[r] = (EPI == EPI_F16) ? f32_to_f16_bits(y[r]) : f32_to_bf16_bits(y[r]);
-                    unsigned short *o = reinterpret_cast<unsigned short *>(p.out) + m * p.ldo + n;
-                    if (full && (p.ldo % 4 == 0)) {
-                        *reinterpret_cast<v4us *>(o) = v4us{h[0], h[1], h[2], h[3]};
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (n + r < p.N) o[r] = h[r];
-                    }
+                    for (int e = 0; e < 8; ++e)
+                        if (n + e < p.N) o[e] = h[e];
                 }
             }
         }
     }
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int W_BITS, int EPI>
+// Combine split-K partials (fixed order s = 0..splits-1; integer sums are exact) and apply
+// the same epilogue.  One thread per 4 consecutive output channels.
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p)
+{
+    const long quads_per_row = ceil_div(p.N, 4);
+    const long total = p.M * quads_per_row;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const long m = i / quads_per_row;
+        const long n = (i - m * quads_per_row) * 4;
+        v4i a = {0, 0, 0, 0};
+        const bool vec = (n + 4 <= p.N) && (p.N % 4 == 0);
+        for (int s = 0; s < p.splits; ++s) {
+            const int *src = p.partial + ((long)s * p.M + m) * p.N + n;
+            if (vec) {
+                const v4i t = *reinterpret_cast<const v4i *>(src);
+                a += t;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < p.N) a[r] += src[r];
+            }
+        }
+        float sx = p.sx0, xz = 0.0f;
+        if (EPI != EPI_I32) {
+            if (p.row_sel && p.row_sel[m]) sx = p.sx1;
+            if (p.x0) xz = p.x0[m];
+        }
+        store_quad<EPI>(p, m, n, a, sx, xz);
+    }
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int W_BITS, int EPI, int DMA_POS = 1>
 static int launch_gemm(const GemmArgs &p, hipStream_t st)
 {
-    constexpr int X_BYTES = (BM / 16) * 2 * 1024;
-    constexpr int W_BYTES = ((W_BITS == 4) ? (BN / 16) : (BN / 16) * 2) * 1024;
-    constexpr int SMEM = 2 * (X_BYTES + W_BYTES);
-    auto kern = gemm_w4a8_kernel<BM, BN, WARPS_M, WARPS_N, W_BITS, EPI>;
+    constexpr int PIECES = (BM / 16) * 2 + ((W_BITS == 4) ? (BN / 16) : (BN / 16) * 2);
+    constexpr int SMEM = STAGES * PIECES * 1024;
+    auto kern = gemm_w4a8_kernel<BM, BN, WARPS_M, WARPS_N, STAGES, W_BITS, EPI, DMA_POS>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)kern,
@@ -251,21 +412,77 @@ static int launch_gemm(const GemmArgs &p, hipStream_t st)
     }
     const long m_blocks = ceil_div(p.M, BM);
     const long n_blocks = ceil_div(p.n_tiles * 16, BN);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(m_blocks * n_blocks)), dim3(WARPS_M * WARPS_N * 64),
-                       SMEM, st, p);
-    return check_launch("gemm_w4a8");
+    hipLaunchKernelGGL(kern, dim3((unsigned)(m_blocks * n_blocks * p.splits)),
+                       dim3(WARPS_M * WARPS_N * 64), SMEM, st, p);
+    int rc = check_launch("gemm_w4a8");
+    if (rc != MQ_OK || p.splits == 1) return rc;
+    long blocks = ceil_div(p.M * ceil_div(p.N, 4), 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel<EPI>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    return check_launch("splitk_reduce");
+}
+
+// Tile / split-K plan, from measurements on MI355X (profiles/ and DESIGN.md):
+//   * a 256x256 tile (16 waves) moves ~24 B/clk/CU through L1 at full MFMA rate against ~48 for
+//     128x128, and reaches ~2.0 POP/s when the output alone fills the chip (>= 192 tiles);
+//   * long reductions with few output tiles (down_proj: 42 tiles, K = 19968) are split over K
+//     so that ~250 workgroups run, integer partials are combined by splitk_reduce_kernel;
+//   * everything else is latency bound (~10 us floor per launch): 128x128 tiles, no split.
+struct Plan {
+    int tile;    // index into dispatch_tile
+    int splits;
+};
+
+static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes, int force_tile,
+                      int force_splits)
+{
+    const long kps = K_pad / 128;
+    const long t256 = ceil_div(M, 256) * ceil_div(N, 256);
+    Plan pl = {0, 1};
+    if (t256 >= 192) {
+        pl.tile = 3;
+    } else if (have_ws && kps >= 64 && t256 >= 8) {
+        long s = (252 + t256 - 1) / t256;
+        if (s > 8) s = 8;
+        while (s > 1 && ((size_t)(s * M * N * 4) > ws_bytes || kps / s < 8)) --s;
+        if (s > 1) { pl.tile = 3; pl.splits = (int)s; }
+    }
+    if (force_tile >= 0) pl.tile = force_tile;
+    if (force_splits > 0) pl.splits = force_splits;
+    if (pl.splits > kps) pl.splits = (int)kps;
+    if (pl.splits < 1) pl.splits = 1;
+    return pl;
 }
 
 template <int W_BITS, int EPI>
-static int dispatch_tile(const GemmArgs &p, hipStream_t st)
+static int dispatch_tile(const GemmArgs &p, int tile, hipStream_t st)
 {
-    return launch_gemm<128, 128, 2, 2, W_BITS, EPI>(p, st);
+    switch (tile) {
+    case 1:
+        if constexpr (W_BITS == 4) return launch_gemm<256, 256, 2, 4, 3, W_BITS, EPI>(p, st);
+        else return launch_gemm<256, 128, 4, 2, 3, W_BITS, EPI>(p, st);  // int8 weights: 3 x 64 KiB would not fit
+    case 2: return launch_gemm<256, 128, 4, 2, 3, W_BITS, EPI>(p, st);
+    case 3:
+        if constexpr (W_BITS == 4) return launch_gemm<256, 256, 4, 4, 3, W_BITS, EPI>(p, st);
+        else return launch_gemm<256, 128, 4, 2, 3, W_BITS, EPI>(p, st);
+    case 4: return launch_gemm<128, 256, 2, 4, 3, W_BITS, EPI>(p, st);
+    case 6: if constexpr (W_BITS == 4) return launch_gemm<256, 256, 4, 4, 3, W_BITS, EPI, 0>(p, st); else break;
+    case 7: if constexpr (W_BITS == 4) return launch_gemm<256, 256, 4, 4, 3, W_BITS, EPI, 2>(p, st); else break;
+    case 8: if constexpr (W_BITS == 4) return launch_gemm<256, 256, 2, 4, 3, W_BITS, EPI, 0>(p, st); else break;
+    case 9: if constexpr (W_BITS == 4) return launch_gemm<256, 256, 2, 4, 3, W_BITS, EPI, 2>(p, st); else break;
+    case 5: return launch_gemm<256, 128, 2, 4, 3, W_BITS, EPI>(p, st);
+    default: break;
+    }
+    return launch_gemm<128, 128, 2, 2, 3, W_BITS, EPI>(p, st);
 }
+
+static int g_force_tile = -1, g_force_splits = 0;
 
 static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, long M, long N,
                        long K_pad, float s_x0, float s_x1, const uint8_t *row_sel,
                        const float *s_w, const float *bias, const float *x0, const float *w0,
-                       void *out, int epi, long ldo, void *stream)
+                       void *out, int epi, long ldo, void *workspace, size_t workspace_bytes,
+                       void *stream)
 {
     MQ_REQUIRE(M >= 0 && N >= 0 && K_pad >= 0, "mq_gemm_w4a8: negative shape");
     if (M == 0 || N == 0) return MQ_OK;
@@ -278,27 +495,38 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
     MQ_REQUIRE(ldo >= N, "mq_gemm_w4a8: ldo < N");
     MQ_REQUIRE(epi == EPI_I32 || s_w, "mq_gemm_w4a8: s_w is required");
     MQ_REQUIRE((x0 == nullptr) == (w0 == nullptr), "mq_gemm_w4a8: x0 and w0 go together");
-    // int32 headroom: |acc| <= K * 128 * 2^(w_bits-1) (* 16 for the high-nibble trick)
-    MQ_REQUIRE(K_pad <= (w_bits == 4 ? 131072L : 131072L), "mq_gemm_w4a8: K too large for int32 accumulation");
+    // int32 headroom: |acc| <= K * 128 * 8 * 16 (int4 in the high nibble) or K * 128 * 128
+    MQ_REQUIRE(K_pad <= 131072L, "mq_gemm_w4a8: K too large for int32 accumulation");
+    MQ_REQUIRE(!workspace || ((uintptr_t)workspace) % 16 == 0, "mq_gemm_w4a8: workspace must be 16-byte aligned");
     GemmArgs p;
     p.a = a; p.lda = lda; p.w = (const uint8_t *)w; p.M = M; p.N = N; p.K_pad = K_pad;
     p.n_tiles = ceil_div(N, 16);
     p.sx0 = s_x0; p.sx1 = s_x1; p.row_sel = row_sel; p.s_w = s_w; p.bias = bias; p.x0 = x0; p.w0 = w0;
     p.out = out; p.ldo = ldo;
+    const Plan pl = make_plan(M, N, K_pad, workspace != nullptr, workspace_bytes, g_force_tile,
+                              workspace ? g_force_splits : 0);
+    p.splits = pl.splits;
+    p.partial = (int32_t *)workspace;
+    auto al16 = [](const void *q) { return q == nullptr || ((uintptr_t)q) % 16 == 0; };
+    const size_t osz = (epi == EPI_F16 || epi == EPI_BF16) ? 2 : 4;
+    p.vec_ok = (N % 8 == 0) && (ldo % 8 == 0) && (((uintptr_t)out) % 16 == 0);
+    (void)al16; (void)osz;
+    if (p.splits > 1)
+        MQ_REQUIRE((size_t)p.splits * M * N * 4 <= workspace_bytes, "mq_gemm_w4a8: workspace too small for split-K");
     hipStream_t st = (hipStream_t)stream;
     if (w_bits == 4) {
         switch (epi) {
-        case EPI_F16: return dispatch_tile<4, EPI_F16>(p, st);
-        case EPI_BF16: return dispatch_tile<4, EPI_BF16>(p, st);
-        case EPI_F32: return dispatch_tile<4, EPI_F32>(p, st);
-        case EPI_I32: return dispatch_tile<4, EPI_I32>(p, st);
+        case EPI_F16: return dispatch_tile<4, EPI_F16>(p, pl.tile, st);
+        case EPI_BF16: return dispatch_tile<4, EPI_BF16>(p, pl.tile, st);
+        case EPI_F32: return dispatch_tile<4, EPI_F32>(p, pl.tile, st);
+        case EPI_I32: return dispatch_tile<4, EPI_I32>(p, pl.tile, st);
         }
     } else {
         switch (epi) {
-        case EPI_F16: return dispatch_tile<8, EPI_F16>(p, st);
-        case EPI_BF16: return dispatch_tile<8, EPI_BF16>(p, st);
-        case EPI_F32: return dispatch_tile<8, EPI_F32>(p, st);
-        case EPI_I32: return dispatch_tile<8, EPI_I32>(p, st);
+        case EPI_F16: return dispatch_tile<8, EPI_F16>(p, pl.tile, st);
+        case EPI_BF16: return dispatch_tile<8, EPI_BF16>(p, pl.tile, st);
+        case EPI_F32: return dispatch_tile<8, EPI_F32>(p, pl.tile, st);
+        case EPI_I32: return dispatch_tile<8, EPI_I32>(p, pl.tile, st);
         }
     }
     return fail(MQ_EINVAL, "mq_gemm_w4a8: unknown output dtype %d", epi);
@@ -314,12 +542,42 @@ extern "C" int mq_gemm_w4a8(const int8_t *a, long lda, const void *w, int w_bits
     if (out_dtype != MQ_F16 && out_dtype != MQ_BF16 && out_dtype != MQ_F32)
         return mq::fail(MQ_EINVAL, "mq_gemm_w4a8: unknown output dtype %d", out_dtype);
     return mq::gemm_common(a, lda, w, w_bits, M, N, K_pad, s_x0, s_x1, row_sel, s_w, bias, x0, w0,
-                           out, out_dtype, ldo, stream);
+                           out, out_dtype, ldo, nullptr, 0, stream);
+}
+
+extern "C" int mq_gemm_w4a8_ws(const int8_t *a, long lda, const void *w, int w_bits, long M, long N,
+                               long K_pad, float s_x0, float s_x1, const uint8_t *row_sel,
+                               const float *s_w, const float *bias, const float *x0,
+                               const float *w0, void *out, int out_dtype, long ldo,
+                               void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (out_dtype != MQ_F16 && out_dtype != MQ_BF16 && out_dtype != MQ_F32)
+        return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_ws: unknown output dtype %d", out_dtype);
+    return mq::gemm_common(a, lda, w, w_bits, M, N, K_pad, s_x0, s_x1, row_sel, s_w, bias, x0, w0,
+                           out, out_dtype, ldo, workspace, workspace_bytes, stream);
 }
 
 extern "C" int mq_gemm_w4a8_i32(const int8_t *a, long lda, const void *w, int w_bits, long M,
                                 long N, long K_pad, int32_t *acc, long ldacc, void *stream)
 {
     return mq::gemm_common(a, lda, w, w_bits, M, N, K_pad, 1.0f, 1.0f, nullptr, nullptr, nullptr,
-                           nullptr, nullptr, acc, mq::EPI_I32, ldacc, stream);
+                           nullptr, nullptr, acc, mq::EPI_I32, ldacc, nullptr, 0, stream);
+}
+
+extern "C" int mq_gemm_w4a8_i32_ws(const int8_t *a, long lda, const void *w, int w_bits, long M,
+                                   long N, long K_pad, int32_t *acc, long ldacc, void *workspace,
+                                   size_t workspace_bytes, void *stream)
+{
+    return mq::gemm_common(a, lda, w, w_bits, M, N, K_pad, 1.0f, 1.0f, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, acc, mq::EPI_I32, ldacc, workspace, workspace_bytes,
+                           stream);
+}
+
+// Tuning / test hook: force a tile shape (-1 = heuristic; 0: 128x128, 1: 256x256, 2: 256x128)
+// and a split-K factor (0 = heuristic).  Process-wide; not part of the drop-in surface.
+extern "C" int mq_gemm_debug_force(int tile, int splits)
+{
+    mq::g_force_tile = tile;
+    mq::g_force_splits = splits;
+    return MQ_OK;
 }

@@ -5,16 +5,23 @@
 // 115-128 (matmul_hadU_cuda: third-party FHT over the last m elements, then hadK @ .),
 // fake_quant/quant_utils.py:334-341 (casts), and uniform.py:20-33 when quantizing.
 //
-// One workgroup (4 waves) owns one activation row, held in LDS as fp32:
+// One workgroup (4 waves) owns one activation row at a time, staged in LDS:
 //   A. butterflies in ascending stride, exactly the (a+b, a-b) order of the reference:
 //      strides 1,2,4 inside a lane's 8 registers, strides 8..256 with wavefront shuffles
 //      (lane ^ stride/8), strides >= 512 through LDS; then * 1/sqrt(n) (fp32 scalar) and the
-//      cast to x's dtype that the FHT extension performs for half inputs;
+//      cast to x's dtype that the FHT extension performs for half inputs.  In that mode the
+//      values ARE half-precision numbers, so the LDS copy is stored as 16-bit (half the
+//      footprint: three workgroups per CU instead of one);
 //   B. the K x K +-1 stage on the matrix core: V_MFMA_F32_16X16X4_F32 is an exact k-ordered
 //      fp32 fma chain (fma(+-1, y, acc) == acc +- y), so ascending k-steps reproduce the
-//      oracle's sequential add/sub chain bit for bit.  hadK lives in LDS as sign bits;
+//      oracle's sequential add/sub chain bit for bit.  hadK is re-packed once per workgroup
+//      into word-aligned sign rows; a lane derives its +-1.0f operand with three VALU ops.
+//      A unit of work is (16 output rows j) x (64 columns i); column tile g of a unit holds
+//      the columns 4*c + g, so one 8-byte LDS read feeds four MFMAs and the four results of
+//      a lane are adjacent in memory (one 4-byte / 8-byte store per accumulator row);
 //   C. cast to x's dtype, then either store or quantize (IEEE divide, rint, clamp) to int8.
 #include <math.h>
+#include <stdlib.h>
 
 #include "mq_common.h"
 
@@ -36,51 +43,131 @@ struct HadArgs {
     long K_pad, ldq;
     int vec_ok;
     float inv_sqrt_n;  // 1.0f / sqrtf((float)n), computed on the host in IEEE fp32
+    int row_bytes;     // LDS bytes per k-row of the staged copy
+    int swz;           // XOR-swizzle odd k-rows by 128 B (row_bytes % 256 == 0)
+    int y_bytes;       // LDS bytes of the staged row
+    int dbg;           // tuning only: 1 skip phase A, 2 skip MFMAs, 4 skip emit
 };
 
 constexpr int HAD_THREADS = 256;
 constexpr int HAD_WAVES = HAD_THREADS / 64;
-constexpr int HAD_G = 4;  // 16-wide column tiles accumulated per A-operand fetch
+
+// storage of the staged row in LDS: 16-bit when the values are exactly half-precision
+template <int DT, bool HALF_LDS> struct Stage;
+template <int DT> struct Stage<DT, true> {
+    typedef unsigned short T;
+    static __device__ __forceinline__ T st(float f) { return Elem<DT>::st(f); }
+    static __device__ __forceinline__ float ld(T v) { return Elem<DT>::ld(v); }
+};
+template <int DT> struct Stage<DT, false> {
+    typedef float T;
+    static __device__ __forceinline__ T st(float f) { return f; }
+    static __device__ __forceinline__ float ld(T v) { return v; }
+};
 
 template <int DT, bool QUANT>
-__device__ __forceinline__ void had_emit(const HadArgs &p, long row, long col, float v, float s)
+__device__ __forceinline__ int had_finish(const HadArgs &p, long row, long col, float v, float s,
+                                          float *vout)
 {
     v = Elem<DT>::rnd(v);
-    if (QUANT) {
-        int q;
-        if (p.skip_col0 && col == 0) {
-            if (p.x0_out) p.x0_out[row] = v;
-            q = 0;
-        } else {
-            q = quant_level(v, s, -128.0f, 127.0f);
-        }
-        p.qout[row * p.ldq + col] = (int8_t)q;
-    } else {
-        typedef typename Elem<DT>::T T;
-        reinterpret_cast<T *>(p.out)[row * p.ldo + col] = Elem<DT>::st(v);
+    *vout = v;
+    if (!QUANT) return 0;
+    if (p.skip_col0 && col == 0) {
+        if (p.x0_out) p.x0_out[row] = v;
+        return 0;
     }
+    return quant_level(v, s, -128.0f, 127.0f);
 }
 
 template <int DT, bool QUANT>
+__device__ __forceinline__ void had_emit1(const HadArgs &p, long row, long col, float v, float s)
+{
+    float r;
+    const int q = had_finish<DT, QUANT>(p, row, col, v, s, &r);
+    if (QUANT) {
+        p.qout[row * p.ldq + col] = (int8_t)q;
+    } else {
+        typedef typename Elem<DT>::T T;
+        reinterpret_cast<T *>(p.out)[row * p.ldo + col] = Elem<DT>::st(r);
+    }
+}
+
+// four adjacent columns col..col+3 of one row
+template <int DT, bool QUANT>
+__device__ __forceinline__ void had_emit4(const HadArgs &p, long row, long col, const float v[4],
+                                          float s, bool aligned)
+{
+    float r[4];
+    int q[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) q[e] = had_finish<DT, QUANT>(p, row, col + e, v[e], s, &r[e]);
+    if (QUANT) {
+        int8_t *o = p.qout + row * p.ldq + col;
+        if (aligned) {
+            *reinterpret_cast<unsigned *>(o) = (q[0] & 0xff) | ((q[1] & 0xff) << 8) |
+                                               ((q[2] & 0xff) << 16) | ((unsigned)(q[3] & 0xff) << 24);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (int8_t)q[e];
+        }
+    } else {
+        typedef typename Elem<DT>::T T;
+        T *o = reinterpret_cast<T *>(p.out) + row * p.ldo + col;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = Elem<DT>::st(r[e]);
+    }
+}
+
+template <int DT, bool QUANT, bool HALF_LDS>
 __global__ __launch_bounds__(HAD_THREADS) void hadamard_kernel(HadArgs p)
 {
     typedef typename Elem<DT>::T T;
+    typedef Stage<DT, HALF_LDS> S;
+    typedef typename S::T YT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *y = reinterpret_cast<float *>(smem);
-    const uint8_t *hb = reinterpret_cast<const uint8_t *>(smem + (size_t)p.n * 4);
+    char *ybase = smem;
+    unsigned *hw = reinterpret_cast<unsigned *>(smem + p.y_bytes);  // [K][WPR] sign words
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const long n = p.n;
     const int K = p.K, m = p.m;
+    const int WPR = (K + 31) / 32;
     const float scale = p.inv_sqrt_n;
     const bool mid_round = (DT != MQ_F32) && !p.fp32_had;
+    const int row_bytes = p.row_bytes;
+    const int swz = p.swz;
+    constexpr int ESZ = (int)sizeof(YT);
 
+    // byte offset of element (k, i) of the staged row
+    auto yoff = [&](int k, int i) -> int {
+        int c = i * ESZ;
+        if (swz) c ^= (k & 1) << 7;
+        return k * row_bytes + c;
+    };
+
+    // ---- hadK sign rows, word aligned: bit b of hw[j*WPR + w] = (hadK[j][32w + b] > 0) ----
+    // The packbits stream is first copied into LDS (the staged-row area is still free), then
+    // re-packed from there: global memory is touched once, coalesced.
     if (K > 1) {
-        uint8_t *hbw = reinterpret_cast<uint8_t *>(smem + (size_t)n * 4);
+        uint8_t *raw = reinterpret_cast<uint8_t *>(ybase);
         const int nbytes = (K * K + 7) / 8;
-        for (int i = tid; i < nbytes; i += HAD_THREADS) hbw[i] = p.had_bits[i];
+        for (int t = tid; t < nbytes; t += HAD_THREADS) raw[t] = p.had_bits[t];
+        __syncthreads();
+        for (int t = tid; t < K * WPR; t += HAD_THREADS) {
+            const int j = t / WPR, w = t - j * WPR;
+            unsigned word = 0;
+            for (int b = 0; b < 32; ++b) {
+                const int k = 32 * w + b;
+                if (k < K) {
+                    const int bit = j * K + k;
+                    word |= (unsigned)((raw[bit >> 3] >> (7 - (bit & 7))) & 1u) << b;
+                }
+            }
+            hw[t] = word;
+        }
+        __syncthreads();
     }
 
     for (long row = blockIdx.x; row < p.M; row += gridDim.x) {
@@ -88,26 +175,39 @@ __global__ __launch_bounds__(HAD_THREADS) void hadamard_kernel(HadArgs p)
         const float s = (p.row_sel && p.row_sel[row]) ? p.s1 : p.s0;
 
         // ---------------- A: butterflies ------------------------------------------------
-        if (m >= 8) {
+        if (p.dbg & 1) {
+        } else if (m >= 8) {
             const long nchunks = ceil_div(n, 512);
-            for (long c = wave; c < nchunks; c += HAD_WAVES) {
-                const long idx = c * 512 + lane * 8;
-                float v[8];
+            constexpr int NB = 4;   // chunks whose global loads are in flight together
+            for (long cb = wave; cb < nchunks; cb += HAD_WAVES * NB) {
+              float vb[NB][8];
+#pragma unroll
+              for (int u = 0; u < NB; ++u) {
+                const long idx = (cb + (long)u * HAD_WAVES) * 512 + lane * 8;
                 if (idx + 8 <= p.n_in && p.vec_ok) {
                     if (sizeof(T) == 2) {
                         const v8us a = *reinterpret_cast<const v8us *>(xr + idx);
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) v[i] = Elem<DT>::ld((T)a[i]);
+                        for (int i = 0; i < 8; ++i) vb[u][i] = Elem<DT>::ld((T)a[i]);
                     } else {
                         const v4f a = *reinterpret_cast<const v4f *>((const float *)xr + idx);
                         const v4f b = *reinterpret_cast<const v4f *>((const float *)xr + idx + 4);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+                        for (int i = 0; i < 4; ++i) { vb[u][i] = a[i]; vb[u][4 + i] = b[i]; }
                     }
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = (idx + i < p.n_in) ? Elem<DT>::ld(xr[idx + i]) : 0.0f;
+                    for (int i = 0; i < 8; ++i) vb[u][i] = (idx + i < p.n_in) ? Elem<DT>::ld(xr[idx + i]) : 0.0f;
                 }
+              }
+#pragma unroll
+              for (int u = 0; u < NB; ++u) {
+                const long c = cb + (long)u * HAD_WAVES;
+                if (c >= nchunks) break;                       // wave-uniform
+                const long idx = c * 512 + lane * 8;
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = vb[u][i];
 #pragma unroll
                 for (int h = 1; h < 8; h <<= 1) {
 #pragma unroll
@@ -136,33 +236,48 @@ __global__ __launch_bounds__(HAD_THREADS) void hadamard_kernel(HadArgs p)
                         v[i] = t;
                     }
                 }
-                if (idx + 8 <= n) {
-                    *reinterpret_cast<v4f *>(y + idx) = v4f{v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<v4f *>(y + idx + 4) = v4f{v[4], v[5], v[6], v[7]};
-                } else {
+                if (idx < n) {   // n is a multiple of 8 here (m >= 8)
+                    const int k = (int)(idx / m), i0 = (int)(idx - (long)k * m);
+                    char *dst = ybase + yoff(k, i0);
+                    if (HALF_LDS) {
+                        v8us h;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        if (idx + i < n) y[idx + i] = v[i];
+                        for (int i = 0; i < 8; ++i) h[i] = (unsigned short)S::st(v[i]);
+                        *reinterpret_cast<v8us *>(dst) = h;
+                    } else {
+                        *reinterpret_cast<v4f *>(dst) = v4f{v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<v4f *>(dst + 16) = v4f{v[4], v[5], v[6], v[7]};
+                    }
                 }
+              }
             }
         } else {
-            for (long i = tid; i < n; i += HAD_THREADS) y[i] = (i < p.n_in) ? Elem<DT>::ld(xr[i]) : 0.0f;
+            for (long i = tid; i < n; i += HAD_THREADS) {
+                const int k = (int)(i / m), i0 = (int)(i - (long)k * m);
+                *reinterpret_cast<YT *>(ybase + yoff(k, i0)) =
+                    S::st((i < p.n_in) ? Elem<DT>::ld(xr[i]) : 0.0f);
+            }
         }
         __syncthreads();
-        if (m > 512 || m < 8) {
+        if (m > 512 || m < 8) {   // remaining strides through LDS (fp32 staging: HALF_LDS is off)
             for (long h = (m < 8) ? 1 : 512; h < m; h <<= 1) {
                 for (long b = tid; b < n / 2; b += HAD_THREADS) {
                     const long i = (b / h) * 2 * h + (b % h);
-                    const float a0 = y[i], a1 = y[i + h];
-                    y[i] = a0 + a1;
-                    y[i + h] = a0 - a1;
+                    const int k = (int)(i / m), i0 = (int)(i - (long)k * m);
+                    YT *pa = reinterpret_cast<YT *>(ybase + yoff(k, i0));
+                    YT *pb = reinterpret_cast<YT *>(ybase + yoff(k, i0 + (int)h));
+                    const float a0 = S::ld(*pa), a1 = S::ld(*pb);
+                    *pa = S::st(a0 + a1);
+                    *pb = S::st(a0 - a1);
                 }
                 __syncthreads();
             }
             for (long i = tid; i < n; i += HAD_THREADS) {
-                float t = y[i] * scale;
+                const int k = (int)(i / m), i0 = (int)(i - (long)k * m);
+                YT *py = reinterpret_cast<YT *>(ybase + yoff(k, i0));
+                float t = S::ld(*py) * scale;
                 if (mid_round) t = Elem<DT>::rnd(t);
-                y[i] = t;
+                *py = S::st(t);
             }
             __syncthreads();
         }
@@ -172,84 +287,119 @@ __global__ __launch_bounds__(HAD_THREADS) void hadamard_kernel(HadArgs p)
             for (long idx = (long)tid * 8; idx < n; idx += HAD_THREADS * 8) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
-                    if (idx + i < n) had_emit<DT, QUANT>(p, row, idx + i, y[idx + i], s);
+                    if (idx + i < n)
+                        had_emit1<DT, QUANT>(p, row, idx + i,
+                                             S::ld(*reinterpret_cast<const YT *>(ybase + yoff(0, (int)(idx + i)))), s);
             }
-        } else if (m >= 16) {
+        } else if (m >= 64) {
             const int JT = (K + 15) / 16;
-            const int IT = m / 16;
-            const int IG = (IT + HAD_G - 1) / HAD_G;
+            const int CG = m / 64;
             const int ksteps = K / 4;
-            for (int u = wave; u < JT * IG; u += HAD_WAVES) {
-                const int jt = u / IG, ig = u - jt * IG;
-                v4f acc[HAD_G];
+            const int lc = lane & 15, lk = lane >> 4;
+            for (int u = wave; u < JT * CG; u += HAD_WAVES) {
+                const int jt = u / CG, cg = u - jt * CG;
+                v4f acc[4];
 #pragma unroll
-                for (int g = 0; g < HAD_G; ++g) acc[g] = v4f{0.f, 0.f, 0.f, 0.f};
-                const int ja = jt * 16 + (lane & 15);
+                for (int g = 0; g < 4; ++g) acc[g] = v4f{0.f, 0.f, 0.f, 0.f};
+                const int ja = jt * 16 + lc;
                 const bool jvalid = ja < K;
-                int bit = ja * K + (lane >> 4);
-                const float *yb = y + (long)(lane >> 4) * m + ig * (HAD_G * 16) + (lane & 15);
-                for (int ks = 0; ks < ksteps; ++ks) {
-                    float a = 0.0f;
-                    if (jvalid) {
-                        const unsigned byte = hb[bit >> 3];
-                        a = ((byte >> (7 - (bit & 7))) & 1u) ? 1.0f : -1.0f;
-                    }
-                    bit += 4;
-                    const float *yk = yb + (long)ks * 4 * m;
+                const unsigned *hrow = hw + (jvalid ? ja : 0) * WPR;
+                const int col0 = cg * 64 + 4 * lc;           // this lane's 4 adjacent columns
+                for (int w = 0; w < WPR; ++w) {
+                    const unsigned word = hrow[w];
 #pragma unroll
-                    for (int g = 0; g < HAD_G; ++g) {
-                        if (ig * HAD_G + g < IT) {
-                            const float b = yk[g * 16];
-                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[g], 0, 0, 0);
+                    for (int q = 0; q < 8; ++q) {
+                        const int ks = w * 8 + q;
+                        if (ks < ksteps) {                     // wave-uniform
+                            // +-1.0f from bit (4q + lk): bit -> sign, 0xBF800000 is -1.0f
+                            unsigned t = word << (31 - 4 * q - lk);
+                            t = (t & 0x80000000u) ^ 0xBF800000u;
+                            const float a = jvalid ? __uint_as_float(t) : 0.0f;
+                            const int k = ks * 4 + lk;
+                            const char *src = ybase + yoff(k, col0);
+                            float b[4];
+                            if (HALF_LDS) {
+                                const v4us hv = *reinterpret_cast<const v4us *>(src);
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) b[g] = S::ld((YT)hv[g]);
+                            } else {
+                                const v4f fv = *reinterpret_cast<const v4f *>(src);
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) b[g] = fv[g];
+                            }
+                            if (!(p.dbg & 2)) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+                                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[g], acc[g], 0, 0, 0);
+                            } else { acc[0][0] += a * b[0]; }
                         }
                     }
                 }
 #pragma unroll
-                for (int g = 0; g < HAD_G; ++g) {
-                    const int it = ig * HAD_G + g;
-                    if (it >= IT) continue;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int j = jt * 16 + (lane >> 4) * 4 + r;
-                        if (j < K) had_emit<DT, QUANT>(p, row, (long)j * m + it * 16 + (lane & 15), acc[g][r], s);
+                for (int r = 0; r < 4; ++r) {
+                    const int j = jt * 16 + lk * 4 + r;
+                    if (j < K && !(p.dbg & 4)) {
+                        const float v4[4] = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+                        had_emit4<DT, QUANT>(p, row, (long)j * m + col0, v4, s, (p.ldq & 3) == 0);
                     }
                 }
             }
         } else {
+            // narrow co-factor (m < 64): scalar chain per output element
             for (long o = tid; o < n; o += HAD_THREADS) {
                 const int j = (int)(o / m), i = (int)(o - (long)j * m);
                 float acc = 0.0f;
                 for (int k = 0; k < K; ++k) {
-                    const int bit = j * K + k;
-                    const float v = y[(long)k * m + i];
-                    acc = ((hb[bit >> 3] >> (7 - (bit & 7))) & 1u) ? (acc + v) : (acc - v);
+                    const float v = S::ld(*reinterpret_cast<const YT *>(ybase + yoff(k, i)));
+                    acc = ((hw[j * WPR + (k >> 5)] >> (k & 31)) & 1u) ? (acc + v) : (acc - v);
                 }
-                had_emit<DT, QUANT>(p, row, o, acc, s);
+                had_emit1<DT, QUANT>(p, row, o, acc, s);
             }
         }
         if (QUANT) {
             for (long c = n + tid; c < p.K_pad; c += HAD_THREADS) p.qout[row * p.ldq + c] = 0;
         }
-        __syncthreads();  // y is reused by the next row
+        __syncthreads();  // the staged row is reused by the next row
     }
 }
 
-template <int DT, bool QUANT>
-static int launch_hadamard(const HadArgs &p, hipStream_t st)
+template <int DT, bool QUANT, bool HALF_LDS>
+static int launch_hadamard(HadArgs p, hipStream_t st)
 {
-    const size_t lds = (size_t)p.n * 4 + (((size_t)p.K * p.K + 7) / 8 + 15) / 16 * 16;
+    const int esz = HALF_LDS ? 2 : 4;
+    p.row_bytes = p.m * esz;
+    p.swz = (p.K > 1 && p.row_bytes % 256 == 0) ? 1 : 0;
+    long yb = p.n * esz;
+    const long raw_bits = ((long)p.K * p.K + 7) / 8;      // staging area doubles as the bit buffer
+    if (p.K > 1 && raw_bits > yb) yb = raw_bits;
+    p.y_bytes = (int)((yb + 15) / 16 * 16);
+    const size_t wpr = (p.K + 31) / 32;
+    const size_t lds = (size_t)p.y_bytes + (p.K > 1 ? (size_t)p.K * wpr * 4 : 0);
     if (lds > 160 * 1024) return fail(MQ_EUNSUPPORTED, "mq_hadamard: n=%ld needs %zu B of LDS (> 160 KiB)", p.n, lds);
-    auto kern = hadamard_kernel<DT, QUANT>;
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail((int)e, "hadamard: set smem attr: %s", hipGetErrorString(e));
-    int cus = 256;
+    auto kern = hadamard_kernel<DT, QUANT, HALF_LDS>;
+    static size_t lds_granted = 0;   // per instantiation; raised outside any stream capture (first call)
+    if (lds > lds_granted) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail((int)e, "hadamard: set smem attr: %s", hipGetErrorString(e));
+        lds_granted = 160 * 1024;
+    }
     long per_cu = (160 * 1024) / (long)lds;
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
-    long blocks = (long)cus * per_cu;
+    long blocks = 256L * per_cu;
     if (blocks > p.M) blocks = p.M;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(HAD_THREADS), lds, st, p);
     return check_launch("hadamard");
+}
+
+template <int DT, bool QUANT>
+static int launch_hadamard_dt(const HadArgs &p, hipStream_t st)
+{
+    // 16-bit staging is exact only when the scaled butterflies are rounded to x's dtype AND no
+    // later butterfly pass runs through LDS (m <= 512, m >= 8)
+    const bool half_ok = (DT != MQ_F32) && !p.fp32_had && p.m >= 8 && p.m <= 512;
+    if (DT != MQ_F32 && half_ok) return launch_hadamard<DT, QUANT, (DT != MQ_F32)>(p, st);
+    return launch_hadamard<DT, QUANT, false>(p, st);
 }
 
 static int hadamard_common(HadArgs p, int x_dtype, bool quant, void *stream)
@@ -259,6 +409,7 @@ static int hadamard_common(HadArgs p, int x_dtype, bool quant, void *stream)
     MQ_REQUIRE(p.K >= 1 && p.n % p.K == 0, "mq_hadamard: K=%d does not divide n=%ld", p.K, p.n);
     p.m = (int)(p.n / p.K);
     p.inv_sqrt_n = 1.0f / sqrtf((float)p.n);
+    { const char *e = getenv("MQ_HAD_DEBUG"); p.dbg = e ? atoi(e) : 0; }
     MQ_REQUIRE((p.m & (p.m - 1)) == 0, "mq_hadamard: n/K=%d is not a power of two", p.m);
     MQ_REQUIRE(p.K == 1 || (p.K % 4 == 0 && p.had_bits), "mq_hadamard: K=%d needs had_bits and K %% 4 == 0", p.K);
     MQ_REQUIRE(p.ldx >= p.n_in, "mq_hadamard: ldx < n_in");
@@ -267,17 +418,18 @@ static int hadamard_common(HadArgs p, int x_dtype, bool quant, void *stream)
     hipStream_t st = (hipStream_t)stream;
     if (quant) {
         MQ_REQUIRE(p.qout && p.K_pad >= p.n && p.ldq >= p.K_pad, "mq_hadamard_quant_i8: bad output geometry");
+        MQ_REQUIRE(((uintptr_t)p.qout) % 4 == 0, "mq_hadamard_quant_i8: out must be 4-byte aligned");
         switch (x_dtype) {
-        case MQ_F16: return launch_hadamard<MQ_F16, true>(p, st);
-        case MQ_BF16: return launch_hadamard<MQ_BF16, true>(p, st);
-        case MQ_F32: return launch_hadamard<MQ_F32, true>(p, st);
+        case MQ_F16: return launch_hadamard_dt<MQ_F16, true>(p, st);
+        case MQ_BF16: return launch_hadamard_dt<MQ_BF16, true>(p, st);
+        case MQ_F32: return launch_hadamard_dt<MQ_F32, true>(p, st);
         }
     } else {
         MQ_REQUIRE(p.out && p.ldo >= p.n, "mq_hadamard: bad output geometry");
         switch (x_dtype) {
-        case MQ_F16: return launch_hadamard<MQ_F16, false>(p, st);
-        case MQ_BF16: return launch_hadamard<MQ_BF16, false>(p, st);
-        case MQ_F32: return launch_hadamard<MQ_F32, false>(p, st);
+        case MQ_F16: return launch_hadamard_dt<MQ_F16, false>(p, st);
+        case MQ_BF16: return launch_hadamard_dt<MQ_BF16, false>(p, st);
+        case MQ_F32: return launch_hadamard_dt<MQ_F32, false>(p, st);
         }
     }
     return fail(MQ_EINVAL, "mq_hadamard: unknown dtype %d", x_dtype);

@@ -168,32 +168,54 @@ def prepack(q: torch.Tensor, bits: int, zero_col0: bool = False) -> torch.Tensor
 
 
 # --------------------------------------------------------------------------- GEMM
+_SPLITK_WS = {}
+
+
+def splitk_workspace(device, nbytes: int = 64 << 20) -> torch.Tensor:
+    """Per-device scratch for split-K partial sums (grow-only, reused by every call on the
+    device's current stream order)."""
+    key = (device.index or 0)
+    ws = _SPLITK_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        _SPLITK_WS[key] = ws
+    return ws
+
+
+def gemm_debug_force(tile: int = -1, splits: int = 0) -> None:
+    """Tuning hook: force the tile shape (0: 128x128, 1: 256x256, 2: 256x128) / split-K."""
+    call("mq_gemm_debug_force", tile, splits)
+
+
 def gemm_w4a8(a: torch.Tensor, w_img: torch.Tensor, w_bits: int, N: int, s_x0: float,
               s_w: torch.Tensor, *, s_x1: Optional[float] = None,
               row_sel: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
               x0: Optional[torch.Tensor] = None, w0: Optional[torch.Tensor] = None,
               out_dtype: torch.dtype = torch.float16, M: Optional[int] = None,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, use_workspace: bool = True) -> torch.Tensor:
     _need_cuda(a, w_img, s_w, row_sel, bias, x0, w0, out)
     assert a.dtype == torch.int8 and a.dim() == 2 and a.stride(1) == 1
     M = a.shape[0] if M is None else M
     K_pad = a.shape[1]
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=a.device)
-    call("mq_gemm_w4a8", a.data_ptr(), a.stride(0), w_img.data_ptr(), w_bits, M, N, K_pad,
+    ws = splitk_workspace(a.device) if use_workspace else None
+    call("mq_gemm_w4a8_ws", a.data_ptr(), a.stride(0), w_img.data_ptr(), w_bits, M, N, K_pad,
          float(s_x0), float(s_x0 if s_x1 is None else s_x1), _ptr(row_sel), s_w.data_ptr(),
          _ptr(bias), _ptr(x0), _ptr(w0), out.data_ptr(), dtype_code(out.dtype), out.stride(0),
-         _stream())
+         _ptr(ws), 0 if ws is None else ws.numel(), _stream())
     return out
 
 
-def gemm_w4a8_i32(a: torch.Tensor, w_img: torch.Tensor, w_bits: int, N: int) -> torch.Tensor:
+def gemm_w4a8_i32(a: torch.Tensor, w_img: torch.Tensor, w_bits: int, N: int,
+                  use_workspace: bool = True) -> torch.Tensor:
     _need_cuda(a, w_img)
     assert a.dtype == torch.int8 and a.dim() == 2 and a.stride(1) == 1
     M, K_pad = a.shape
     acc = torch.empty((M, N), dtype=torch.int32, device=a.device)
-    call("mq_gemm_w4a8_i32", a.data_ptr(), a.stride(0), w_img.data_ptr(), w_bits, M, N, K_pad,
-         acc.data_ptr(), acc.stride(0), _stream())
+    ws = splitk_workspace(a.device) if use_workspace else None
+    call("mq_gemm_w4a8_i32_ws", a.data_ptr(), a.stride(0), w_img.data_ptr(), w_bits, M, N, K_pad,
+         acc.data_ptr(), acc.stride(0), _ptr(ws), 0 if ws is None else ws.numel(), _stream())
     return acc
 
 

@@ -115,6 +115,7 @@ class Prefill:
         outs: Dict[tuple, torch.Tensor] = {}
         sels: Dict[int, torch.Tensor] = {}
         scales: Dict[tuple, tuple] = {}
+        pending: Dict[tuple, list] = {}
         li = 0
         for spec in specs:
             key = (spec.M, spec.k_in)
@@ -153,10 +154,40 @@ class Prefill:
                 bias = None
                 if spec.bias:
                     bias = (torch.randn((spec.n,), generator=gen, device=self.device) * 0.1).float()
+                del w
+                if share_groups and spec.group:
+                    # Linears fed by the same tensor (q/k/v, gate/up) carry identical static scales
+                    # (their observers saw the same activations): quantize once, ONE GEMM over the
+                    # concatenated output channels.
+                    pending.setdefault((spec.group, c), []).append((spec, q, s_w, bias, s0, s1, x, row_sel))
+                    continue
                 lin = W4A8Linear(q, s_w, w_bits, bias, s0, s1 if spec.msq else None, had=had, w0=w0,
                                  in_features=spec.k_in)
                 self.layers.append(Layer(spec, c, lin, x, row_sel, outs[okey]))
-                del w, q
+                del q
+        for (gname, c), members in pending.items():
+            spec0 = members[0][0]
+            assert all(abs(mb[4] - members[0][4]) == 0 and mb[6] is members[0][6] for mb in members)
+            q = torch.cat([mb[1] for mb in members], dim=0)
+            s_w = torch.cat([mb[2] for mb in members], dim=0)
+            bias = None
+            if members[0][3] is not None:
+                bias = torch.cat([mb[3] for mb in members], dim=0)
+            n_total = q.shape[0]
+            fused = LinearSpec(spec0.name.rsplit(".", 1)[0] + "." + gname + "[" +
+                               "+".join(mb[0].name.rsplit(".", 1)[1] for mb in members) + "]",
+                               spec0.M, spec0.k_in, spec0.k, n_total, spec0.count, bias is not None,
+                               msq=spec0.msq, group=gname)
+            okey = (fused.M, n_total)
+            if okey not in outs:
+                outs[okey] = torch.empty((fused.M, n_total), dtype=dtype, device=self.device)
+            lin = W4A8Linear(q, s_w, w_bits, bias, members[0][4],
+                             members[0][5] if spec0.msq else None, in_features=spec0.k_in)
+            L = Layer(fused, c, lin, members[0][6], members[0][7], outs[okey])
+            L.order_name = spec0.name
+            self.layers.append(L)
+            del q
+        pending.clear()
         self.layers = self._execution_order(self.layers)
         torch.cuda.synchronize(self.device)
 
@@ -165,7 +196,7 @@ class Prefill:
         """Model order: a tower's per-block Linears run back to back, block after block."""
         by_name: Dict[str, List[Layer]] = {}
         for L in layers:
-            by_name.setdefault(L.spec.name, []).append(L)
+            by_name.setdefault(getattr(L, "order_name", L.spec.name), []).append(L)
         ordered: List[Layer] = []
 
         def take(names, reps):
@@ -202,17 +233,9 @@ class Prefill:
     # ---------------------------------------------------------------------------------
     def step(self):
         """One pass of the hot path over the whole prefill."""
-        prev_group = None
-        prev_a = prev_x0 = None
         for L in self.layers:
-            lin = L.lin
-            gkey = (L.spec.group, L.idx) if (self.share_groups and L.spec.group) else None
-            if gkey is not None and gkey == prev_group:
-                a, x0 = prev_a, prev_x0          # same input, same scales: quantized once
-            else:
-                a, x0 = lin.quantize(L.x, L.row_sel)
-            lin.gemm(a, x0, self.dtype, L.row_sel, L.out)
-            prev_group, prev_a, prev_x0 = gkey, a, x0
+            a, x0 = L.lin.quantize(L.x, L.row_sel)
+            L.lin.gemm(a, x0, self.dtype, L.row_sel, L.out)
 
     def step_gemm_only(self):
         """Only the GEMM launches of step() (stale int8 activations): kernel attribution."""
@@ -222,12 +245,8 @@ class Prefill:
             L.lin.gemm(a, x0, self.dtype, L.row_sel, L.out)
 
     def step_quant_only(self):
-        prev_group = None
         for L in self.layers:
-            gkey = (L.spec.group, L.idx) if (self.share_groups and L.spec.group) else None
-            if gkey is None or gkey != prev_group:
-                L.lin.quantize(L.x, L.row_sel)
-            prev_group = gkey
+            L.lin.quantize(L.x, L.row_sel)
 
     # -- accounting --------------------------------------------------------------------
     def gemm_launches(self) -> int:

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""GEMM micro-benchmark over the distinct Qwen2-VL-7B shapes: TOP/s per tile config.
+Usage (GPU box): python tools/gemm_bench.py [--configs 0:1,1:1,2:1,1:6] [--shapes llm|all]"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mquant_amd import ops  # noqa: E402
+
+SHAPES = {
+    "k128": (768, 3584, 128), "k512": (768, 3584, 512), "k1024": (768, 3584, 1024),
+    "vis.qkv": (1024, 3840, 1280), "vis.proj": (1024, 1280, 1280), "vis.fc1": (1024, 5120, 1280),
+    "vis.fc2": (1024, 1280, 5120), "llm.q/o": (768, 3584, 3584), "llm.kv": (768, 512, 3584),
+    "llm.qkv*": (768, 4608, 3584), "llm.gate": (768, 18944, 3584), "llm.gate_up*": (768, 37888, 3584),
+    "llm.down": (768, 3584, 19968),
+}
+
+
+def bench(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3  # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="-1:0,0:1,2:1,1:1")
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    cfgs = [tuple(int(v) for v in c.split(":")) for c in args.configs.split(",")]
+    dev = torch.device("cuda:0")
+    ops.splitk_workspace(dev, 512 << 20)
+    print(f"{'shape':14s} {'M':>5s} {'N':>6s} {'K':>6s} | " + " | ".join(f"t{t}s{s}: us   TOP/s" for t, s in cfgs))
+    for name, (M, N, K) in SHAPES.items():
+        if args.only and args.only not in name:
+            continue
+        a = torch.randint(-128, 128, (M, K), dtype=torch.int8, device=dev)
+        q = torch.randint(-8, 8, (N, K), dtype=torch.int8, device=dev)
+        img = ops.prepack(q, 4)
+        s_w = torch.full((N,), 0.01, device=dev)
+        out = torch.empty((M, N), dtype=torch.float16, device=dev)
+        ref = None
+        cols = []
+        for tile, splits in cfgs:
+            ops.gemm_debug_force(tile, splits)
+            acc = ops.gemm_w4a8_i32(a, img, 4, N)
+            if ref is None:
+                ref = acc
+            ok = bool(torch.equal(acc, ref))
+            us = bench(lambda: ops.gemm_w4a8(a, img, 4, N, 0.02, s_w, out=out))
+            cols.append(f"{us:8.1f} {2.0 * M * N * K / us / 1e6:7.0f}{'' if ok else ' MISMATCH'}")
+        print(f"{name:14s} {M:5d} {N:6d} {K:6d} | " + " | ".join(cols))
+    ops.gemm_debug_force(-1, 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Hadamard(+quant) micro-benchmark on the two online-rotation geometries of Qwen2-VL-7B."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fake_quant import hadamard_utils as hu  # noqa: E402
+from mquant_amd import ops  # noqa: E402
+
+
+def bench(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+dev = torch.device("cuda:0")
+for name, M, n_in, n in [("vis.fc2", 1024, 5120, 5120), ("llm.down", 768, 18944, 19968),
+                         ("qwenvl.c_proj", 768, 11008, 11008), ("pow2.8192", 1024, 8192, 8192)]:
+    _, K = hu.get_hadK(n)
+    bits = hu.had_sign_bits(K, dev) if K > 1 else None
+    for dt in (torch.float16, torch.float32):
+        x = torch.randn((M, n_in), device=dev, dtype=torch.float32).to(dt)
+        out = torch.empty((M, (n + 127) // 128 * 128), dtype=torch.int8, device=dev)
+        us = bench(lambda: ops.hadamard_quant_i8(x, n, K, bits, 0.05, out=out))
+        byts = M * n_in * x.element_size() + M * n
+        print(f"{name:14s} {str(dt):14s} M={M} n={n} K={K}: {us:8.1f} us  {byts / us / 1e3:7.1f} GB/s")
