@@ -61,13 +61,24 @@ del _k
 _BITS_CACHE: dict = {}
 
 
+def sign_words(had: np.ndarray) -> np.ndarray:
+    """+-1 matrix (K, K) -> uint32 [K, ceil(K/32)] word-aligned sign rows: bit b of word w of
+    row j is 1 when had[j, 32*w + b] > 0.  This is the operand layout of the gfx950 kernel."""
+    K = had.shape[0]
+    wpr = (K + 31) // 32
+    bits = np.zeros((K, wpr * 32), dtype=np.uint8)
+    bits[:, :K] = (np.asarray(had) > 0)
+    packed = np.packbits(bits.reshape(K, wpr, 32), axis=-1, bitorder="little")
+    return np.ascontiguousarray(packed).view("<u4").reshape(K, wpr)
+
+
 def had_sign_bits(K: int, device) -> torch.Tensor:
-    """Packed sign bits of hadK (numpy.packbits order) on ``device``: the kernel's operand."""
+    """Word-aligned sign rows of hadK (see ``sign_words``) on ``device``, cached."""
     device = torch.device(device)
     key = (K, device.type, device.index)
     t = _BITS_CACHE.get(key)
     if t is None:
-        t = torch.from_numpy(_signs()[K].copy()).to(device)
+        t = torch.from_numpy(sign_words(_had_np(K)).view(np.int32).copy()).to(device)
         _BITS_CACHE[key] = t
     return t
 
@@ -139,8 +150,8 @@ def _bits_for(hadK, K: int, device):
     if hadK is None or (tuple(hadK.shape) == ref.shape and
                         np.array_equal(np.sign(hadK.detach().cpu().float().numpy()), ref)):
         return had_sign_bits(K, device)
-    packed = np.packbits((hadK.detach().cpu().float().numpy() > 0).astype(np.uint8).reshape(-1))
-    return torch.from_numpy(packed).to(device)
+    words = sign_words(hadK.detach().cpu().float().numpy())
+    return torch.from_numpy(words.view(np.int32).copy()).to(device)
 
 
 def _hadamard_torch(X: torch.Tensor, hadK, K: int) -> torch.Tensor:

@@ -86,8 +86,9 @@ int mq_fakequant_act(const void *x, int x_dtype, long M, long K, long ldx,
  *   fake_quant/quant_utils.py:334-341 (and :378-383 when quantizing).
  *   y = (H_K (x) H_{n/K}) [x ; 0] / sqrt(n),  flat index = k*(n/K) + j.
  * x: [M, n_in] (n_in <= n: zero padded up to n, the forward-pre-hook's job).
- * had_bits: K*K sign bits of hadK, row-major, bit=1 means +1, packed MSB-first
- *           per byte (numpy.packbits order); NULL when K == 1.
+ * had_words: the signs of hadK as word-aligned rows: uint32 [K][ceil(K/32)], bit b of
+ *           word w of row j is 1 when hadK[j][32*w + b] == +1 (unused high bits 0);
+ *           NULL when K == 1.  (hadK itself is data: fake_quant/hadamard_utils.py:201-.)
  * fp32_had: 0 = the extension's behaviour for half inputs (butterflies in fp32,
  *           result rounded to x's dtype before the K x K stage and again after),
  *           1 = --fp32_had (fp32 throughout, one final cast to x's dtype).
@@ -99,14 +100,17 @@ int mq_fakequant_act(const void *x, int x_dtype, long M, long K, long ldx,
  *           reach HBM.
  * ------------------------------------------------------------------------- */
 int mq_hadamard(const void *x, int x_dtype, long M, long n_in, long ldx,
-                long n, int K, const uint8_t *had_bits, int fp32_had,
+                long n, int K, const uint32_t *had_words, int fp32_had,
                 void *out, long ldo, void *stream);
 
 int mq_hadamard_quant_i8(const void *x, int x_dtype, long M, long n_in, long ldx,
-                         long n, int K, const uint8_t *had_bits, int fp32_had,
+                         long n, int K, const uint32_t *had_words, int fp32_had,
                          float scale0, float scale1, const uint8_t *row_sel,
                          int skip_col0, float *x0_out,
                          int8_t *out, long K_pad, long ldo, void *stream);
+
+/* Tuning hook (process-wide, not part of the drop-in surface): 256 or 512 threads per row. */
+int mq_hadamard_debug_threads(int threads);
 
 /* ---------------------------------------------------------------------------
  * Weight formats.

@@ -29,6 +29,7 @@ SIGNATURES = {
     "mq_fakequant_act": (_i, [_vp, _i, _l, _l, _l, _f, _f, _vp, _vp, _vp, _i, _vp, _l, _vp]),
     "mq_hadamard": (_i, [_vp, _i, _l, _l, _l, _l, _i, _vp, _i, _vp, _l, _vp]),
     "mq_hadamard_quant_i8": (_i, [_vp, _i, _l, _l, _l, _l, _i, _vp, _i, _f, _f, _vp, _i, _vp, _vp, _l, _l, _vp]),
+    "mq_hadamard_debug_threads": (_i, [_i]),
     "mq_pack_i4": (_i, [_vp, _l, _l, _vp, _vp]),
     "mq_unpack_i4": (_i, [_vp, _l, _l, _vp, _vp]),
     "mq_weight_levels": (_i, [_vp, _i, _l, _l, _l, _vp, _i, _i, _vp, _vp]),

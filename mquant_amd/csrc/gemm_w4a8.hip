@@ -51,7 +51,8 @@ struct GemmArgs {
     void *out;
     long ldo;
     int splits;        // split-K factor (1 = none)
-    int vec_ok;        // N, ldo multiples of 4 and 16-byte aligned parameter vectors
+    int vec_ok;        // N, ldo multiples of 8 and a 16-byte aligned output
+    int par_ok;        // s_w / bias / w0 16-byte aligned
     int32_t *partial;  // [splits][M][N] when splits > 1
 };
 
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
         (TM % 4 == 0 && NWAVES * 64 * SLAB_LD <= RING_BYTES) ? 4
         : (TM % 2 == 0 && NWAVES * 32 * SLAB_LD <= RING_BYTES) ? 2 : 1;
     constexpr int PASS_ROWS = PASS_MT * 16;
-    constexpr int SLAB_BYTES = PASS_ROWS * SLAB_LD;
+    constexpr int SLAB_BYTES = PASS_ROWS * SLAB_LD + PASS_ROWS * 8;
     constexpr int LANES_PER_ROW = WN_COLS / 8;       // 8 outputs per lane
     constexpr int ROWS_PER_IT = 64 / LANES_PER_ROW;
     static_assert(NWAVES * SLAB_BYTES <= STAGES * STAGE_BYTES, "epilogue slab must fit the ring");
@@ -280,16 +281,33 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
     const long n = nt0 * 16 + wn * WN_COLS + c8;     // first of this lane's 8 output channels
     const bool n_full = (n + 8 <= p.N) && p.vec_ok;
 
+    // per-channel parameters of this lane's 8 outputs: two 16-byte loads each when aligned
     float swv[8], bsv[8], wzv[8];
     if (EPI != EPI_I32 && !to_partial) {
+        if (n_full && p.par_ok) {
+            const v4f s0 = *reinterpret_cast<const v4f *>(p.s_w + n), s1 = *reinterpret_cast<const v4f *>(p.s_w + n + 4);
+            v4f b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0, z0 = b0, z1 = b0;
+            if (p.bias) { b0 = *reinterpret_cast<const v4f *>(p.bias + n); b1 = *reinterpret_cast<const v4f *>(p.bias + n + 4); }
+            if (p.w0) { z0 = *reinterpret_cast<const v4f *>(p.w0 + n); z1 = *reinterpret_cast<const v4f *>(p.w0 + n + 4); }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const long nn = (n + e < p.N) ? n + e : p.N - 1;
-            swv[e] = p.s_w[nn];
-            bsv[e] = p.bias ? p.bias[nn] : 0.0f;
-            wzv[e] = p.w0 ? p.w0[nn] : 0.0f;
+            for (int e = 0; e < 4; ++e) {
+                swv[e] = s0[e]; swv[4 + e] = s1[e];
+                bsv[e] = b0[e]; bsv[4 + e] = b1[e];
+                wzv[e] = z0[e]; wzv[4 + e] = z1[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const long nn = (n + e < p.N) ? n + e : p.N - 1;
+                swv[e] = (n < p.N) ? p.s_w[nn] : 0.0f;
+                bsv[e] = (p.bias && n < p.N) ? p.bias[nn] : 0.0f;
+                wzv[e] = (p.w0 && n < p.N) ? p.w0[nn] : 0.0f;
+            }
         }
     }
+    // per-row parameters (activation scale set, split term) are fetched once per pass, one row
+    // per lane, and parked behind the slab so the store loop never waits on global memory
+    float *rowpar = reinterpret_cast<float *>(slab + PASS_ROWS * SLAB_LD);   // [PASS_ROWS][2]
 
 #pragma unroll
     for (int pass = 0; pass < TM / PASS_MT; ++pass) {
@@ -299,6 +317,16 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
             for (int i = 0; i < TN; ++i)
                 *reinterpret_cast<v4i *>(slab + (jj * 16 + ml) * SLAB_LD + (i * 16 + nq) * 4) =
                     acc[i][pass * PASS_MT + jj];
+        if (EPI != EPI_I32 && !to_partial && lane < PASS_ROWS) {
+            const long mr = m0 + (wm * TM + pass * PASS_MT) * 16 + lane;
+            float sxl = p.sx0, xzl = 0.0f;
+            if (mr < p.M) {
+                if (p.row_sel && p.row_sel[mr]) sxl = p.sx1;
+                if (p.x0) xzl = p.x0[mr];
+            }
+            rowpar[lane * 2] = sxl;
+            rowpar[lane * 2 + 1] = xzl;
+        }
         // the slab is wave-private: LDS operations of one wave complete in order
 #pragma unroll 1
         for (int r0 = 0; r0 < PASS_ROWS; r0 += ROWS_PER_IT) {
@@ -324,8 +352,8 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
                 }
                 continue;
             }
-            const float sx = (p.row_sel && p.row_sel[m]) ? p.sx1 : p.sx0;
-            const float xz = p.x0 ? p.x0[m] : 0.0f;
+            const float sx = rowpar[row * 2];
+            const float xz = rowpar[row * 2 + 1];
             float y[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -427,7 +455,8 @@ static int launch_gemm(const GemmArgs &p, hipStream_t st)
 //     128x128, and reaches ~2.0 POP/s when the output alone fills the chip (>= 192 tiles);
 //   * long reductions with few output tiles (down_proj: 42 tiles, K = 19968) are split over K
 //     so that ~250 workgroups run, integer partials are combined by splitk_reduce_kernel;
-//   * everything else is latency bound (~10 us floor per launch): 128x128 tiles, no split.
+//   * everything else is latency bound (~8 us floor per launch + ~0.3 us per k-step): 64x128
+//     tiles put two or three workgroups on every CU and measured 10-30 % faster than 128x128.
 struct Plan {
     int tile;    // index into dispatch_tile
     int splits;
@@ -438,7 +467,8 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
 {
     const long kps = K_pad / 128;
     const long t256 = ceil_div(M, 256) * ceil_div(N, 256);
-    Plan pl = {0, 1};
+    const long t128 = ceil_div(M, 128) * ceil_div(N, 128);
+    Plan pl = {t128 >= 400 ? 12 : 10, 1};   // 128x128 (8 waves) / 64x128: more, smaller workgroups
     if (t256 >= 192) {
         pl.tile = 3;
     } else if (have_ws && kps >= 64 && t256 >= 8) {
@@ -471,6 +501,9 @@ static int dispatch_tile(const GemmArgs &p, int tile, hipStream_t st)
     case 8: if constexpr (W_BITS == 4) return launch_gemm<256, 256, 2, 4, 3, W_BITS, EPI, 0>(p, st); else break;
     case 9: if constexpr (W_BITS == 4) return launch_gemm<256, 256, 2, 4, 3, W_BITS, EPI, 2>(p, st); else break;
     case 5: return launch_gemm<256, 128, 2, 4, 3, W_BITS, EPI>(p, st);
+    case 10: return launch_gemm<64, 128, 2, 2, 3, W_BITS, EPI>(p, st);
+    case 11: return launch_gemm<128, 64, 2, 2, 3, W_BITS, EPI>(p, st);
+    case 12: return launch_gemm<128, 128, 4, 2, 3, W_BITS, EPI>(p, st);
     default: break;
     }
     return launch_gemm<128, 128, 2, 2, 3, W_BITS, EPI>(p, st);
@@ -510,7 +543,8 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
     auto al16 = [](const void *q) { return q == nullptr || ((uintptr_t)q) % 16 == 0; };
     const size_t osz = (epi == EPI_F16 || epi == EPI_BF16) ? 2 : 4;
     p.vec_ok = (N % 8 == 0) && (ldo % 8 == 0) && (((uintptr_t)out) % 16 == 0);
-    (void)al16; (void)osz;
+    p.par_ok = al16(s_w) && al16(bias) && al16(w0);
+    (void)osz;
     if (p.splits > 1)
         MQ_REQUIRE((size_t)p.splits * M * N * 4 <= workspace_bytes, "mq_gemm_w4a8: workspace too small for split-K");
     hipStream_t st = (hipStream_t)stream;

@@ -21,7 +21,6 @@
 //      a lane are adjacent in memory (one 4-byte / 8-byte store per accumulator row);
 //   C. cast to x's dtype, then either store or quantize (IEEE divide, rint, clamp) to int8.
 #include <math.h>
-#include <stdlib.h>
 
 #include "mq_common.h"
 
@@ -46,11 +45,8 @@ struct HadArgs {
     int row_bytes;     // LDS bytes per k-row of the staged copy
     int swz;           // XOR-swizzle odd k-rows by 128 B (row_bytes % 256 == 0)
     int y_bytes;       // LDS bytes of the staged row
-    int dbg;           // tuning only: 1 skip phase A, 2 skip MFMAs, 4 skip emit
 };
 
-constexpr int HAD_THREADS = 256;
-constexpr int HAD_WAVES = HAD_THREADS / 64;
 
 // storage of the staged row in LDS: 16-bit when the values are exactly half-precision
 template <int DT, bool HALF_LDS> struct Stage;
@@ -118,9 +114,11 @@ __device__ __forceinline__ void had_emit4(const HadArgs &p, long row, long col, 
     }
 }
 
-template <int DT, bool QUANT, bool HALF_LDS>
-__global__ __launch_bounds__(HAD_THREADS) void hadamard_kernel(HadArgs p)
+template <int DT, bool QUANT, bool HALF_LDS, int THREADS>
+__global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
 {
+    constexpr int HAD_THREADS = THREADS;
+    constexpr int HAD_WAVES = THREADS / 64;
     typedef typename Elem<DT>::T T;
     typedef Stage<DT, HALF_LDS> S;
     typedef typename S::T YT;
@@ -147,27 +145,10 @@ __global__ __launch_bounds__(HAD_THREADS) void hadamard_kernel(HadArgs p)
         return k * row_bytes + c;
     };
 
-    // ---- hadK sign rows, word aligned: bit b of hw[j*WPR + w] = (hadK[j][32w + b] > 0) ----
-    // The packbits stream is first copied into LDS (the staged-row area is still free), then
-    // re-packed from there: global memory is touched once, coalesced.
+    // ---- hadK sign rows (word aligned by the caller): bit b of hw[j*WPR + w] = hadK[j][32w+b] > 0
     if (K > 1) {
-        uint8_t *raw = reinterpret_cast<uint8_t *>(ybase);
-        const int nbytes = (K * K + 7) / 8;
-        for (int t = tid; t < nbytes; t += HAD_THREADS) raw[t] = p.had_bits[t];
-        __syncthreads();
-        for (int t = tid; t < K * WPR; t += HAD_THREADS) {
-            const int j = t / WPR, w = t - j * WPR;
-            unsigned word = 0;
-            for (int b = 0; b < 32; ++b) {
-                const int k = 32 * w + b;
-                if (k < K) {
-                    const int bit = j * K + k;
-                    word |= (unsigned)((raw[bit >> 3] >> (7 - (bit & 7))) & 1u) << b;
-                }
-            }
-            hw[t] = word;
-        }
-        __syncthreads();
+        const unsigned *gw = reinterpret_cast<const unsigned *>(p.had_bits);
+        for (int t = tid; t < K * WPR; t += THREADS) hw[t] = gw[t];
     }
 
     for (long row = blockIdx.x; row < p.M; row += gridDim.x) {
@@ -175,8 +156,7 @@ __global__ __launch_bounds__(HAD_THREADS) void hadamard_kernel(HadArgs p)
         const float s = (p.row_sel && p.row_sel[row]) ? p.s1 : p.s0;
 
         // ---------------- A: butterflies ------------------------------------------------
-        if (p.dbg & 1) {
-        } else if (m >= 8) {
+        if (m >= 8) {
             const long nchunks = ceil_div(n, 512);
             constexpr int NB = 4;   // chunks whose global loads are in flight together
             for (long cb = wave; cb < nchunks; cb += HAD_WAVES * NB) {
@@ -305,40 +285,45 @@ __global__ __launch_bounds__(HAD_THREADS) void hadamard_kernel(HadArgs p)
                 const bool jvalid = ja < K;
                 const unsigned *hrow = hw + (jvalid ? ja : 0) * WPR;
                 const int col0 = cg * 64 + 4 * lc;           // this lane's 4 adjacent columns
-                for (int w = 0; w < WPR; ++w) {
+                // k = 4*ks + lk, so (k & 1) == (lk & 1): the row swizzle is a per-lane constant
+                const char *yp = ybase + yoff(lk, col0);
+                const int kstride = 4 * row_bytes;           // bytes per k-step
+                const unsigned sh0 = 31u - (unsigned)lk;
+                auto kstep = [&](unsigned word, int q, const char *src) {
+                    // +-1.0f from bit (4q + lk): move it to the sign position; 0xBF800000 is -1.0f
+                    unsigned t = word << (sh0 - 4u * (unsigned)q);
+                    t = (t & 0x80000000u) ^ 0xBF800000u;
+                    const float a = jvalid ? __uint_as_float(t) : 0.0f;
+                    float b[4];
+                    if (HALF_LDS) {
+                        const v4us hv = *reinterpret_cast<const v4us *>(src);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) b[g] = S::ld((YT)hv[g]);
+                    } else {
+                        const v4f fv = *reinterpret_cast<const v4f *>(src);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) b[g] = fv[g];
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[g], acc[g], 0, 0, 0);
+                };
+                const int full_words = ksteps >> 3, tail = ksteps & 7;
+                for (int w = 0; w < full_words; ++w) {
                     const unsigned word = hrow[w];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int ks = w * 8 + q;
-                        if (ks < ksteps) {                     // wave-uniform
-                            // +-1.0f from bit (4q + lk): bit -> sign, 0xBF800000 is -1.0f
-                            unsigned t = word << (31 - 4 * q - lk);
-                            t = (t & 0x80000000u) ^ 0xBF800000u;
-                            const float a = jvalid ? __uint_as_float(t) : 0.0f;
-                            const int k = ks * 4 + lk;
-                            const char *src = ybase + yoff(k, col0);
-                            float b[4];
-                            if (HALF_LDS) {
-                                const v4us hv = *reinterpret_cast<const v4us *>(src);
+                    for (int q = 0; q < 8; ++q) kstep(word, q, yp + (w * 8 + q) * kstride);
+                }
+                if (tail) {
+                    const unsigned word = hrow[full_words];
 #pragma unroll
-                                for (int g = 0; g < 4; ++g) b[g] = S::ld((YT)hv[g]);
-                            } else {
-                                const v4f fv = *reinterpret_cast<const v4f *>(src);
-#pragma unroll
-                                for (int g = 0; g < 4; ++g) b[g] = fv[g];
-                            }
-                            if (!(p.dbg & 2)) {
-#pragma unroll
-                            for (int g = 0; g < 4; ++g)
-                                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[g], acc[g], 0, 0, 0);
-                            } else { acc[0][0] += a * b[0]; }
-                        }
-                    }
+                    for (int q = 0; q < 7; ++q)
+                        if (q < tail) kstep(word, q, yp + (full_words * 8 + q) * kstride);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int j = jt * 16 + lk * 4 + r;
-                    if (j < K && !(p.dbg & 4)) {
+                    if (j < K) {
                         const float v4[4] = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
                         had_emit4<DT, QUANT>(p, row, (long)j * m + col0, v4, s, (p.ldq & 3) == 0);
                     }
@@ -363,20 +348,18 @@ __global__ __launch_bounds__(HAD_THREADS) void hadamard_kernel(HadArgs p)
     }
 }
 
-template <int DT, bool QUANT, bool HALF_LDS>
-static int launch_hadamard(HadArgs p, hipStream_t st)
+template <int DT, bool QUANT, bool HALF_LDS, int THREADS>
+static int launch_hadamard_t(HadArgs p, hipStream_t st)
 {
     const int esz = HALF_LDS ? 2 : 4;
     p.row_bytes = p.m * esz;
     p.swz = (p.K > 1 && p.row_bytes % 256 == 0) ? 1 : 0;
     long yb = p.n * esz;
-    const long raw_bits = ((long)p.K * p.K + 7) / 8;      // staging area doubles as the bit buffer
-    if (p.K > 1 && raw_bits > yb) yb = raw_bits;
     p.y_bytes = (int)((yb + 15) / 16 * 16);
     const size_t wpr = (p.K + 31) / 32;
     const size_t lds = (size_t)p.y_bytes + (p.K > 1 ? (size_t)p.K * wpr * 4 : 0);
     if (lds > 160 * 1024) return fail(MQ_EUNSUPPORTED, "mq_hadamard: n=%ld needs %zu B of LDS (> 160 KiB)", p.n, lds);
-    auto kern = hadamard_kernel<DT, QUANT, HALF_LDS>;
+    auto kern = hadamard_kernel<DT, QUANT, HALF_LDS, THREADS>;
     static size_t lds_granted = 0;   // per instantiation; raised outside any stream capture (first call)
     if (lds > lds_granted) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -388,8 +371,21 @@ static int launch_hadamard(HadArgs p, hipStream_t st)
     if (per_cu < 1) per_cu = 1;
     long blocks = 256L * per_cu;
     if (blocks > p.M) blocks = p.M;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(HAD_THREADS), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), lds, st, p);
     return check_launch("hadamard");
+}
+
+static int g_had_threads = 0;   // 0: choose by shape
+
+template <int DT, bool QUANT, bool HALF_LDS>
+static int launch_hadamard(const HadArgs &p, hipStream_t st)
+{
+    // 8 waves per row pay off once the K x K stage has enough (16 rows x 64 columns) units to
+    // keep them busy (down_proj: 10 x 2 = 20 units; measured 83 -> 76 us), else 4 waves
+    const int units = (p.K > 1 && p.m >= 64) ? ((p.K + 15) / 16) * (p.m / 64) : 0;
+    const int threads = g_had_threads ? g_had_threads : (units >= 16 ? 512 : 256);
+    if (threads == 512) return launch_hadamard_t<DT, QUANT, HALF_LDS, 512>(p, st);
+    return launch_hadamard_t<DT, QUANT, HALF_LDS, 256>(p, st);
 }
 
 template <int DT, bool QUANT>
@@ -409,9 +405,8 @@ static int hadamard_common(HadArgs p, int x_dtype, bool quant, void *stream)
     MQ_REQUIRE(p.K >= 1 && p.n % p.K == 0, "mq_hadamard: K=%d does not divide n=%ld", p.K, p.n);
     p.m = (int)(p.n / p.K);
     p.inv_sqrt_n = 1.0f / sqrtf((float)p.n);
-    { const char *e = getenv("MQ_HAD_DEBUG"); p.dbg = e ? atoi(e) : 0; }
     MQ_REQUIRE((p.m & (p.m - 1)) == 0, "mq_hadamard: n/K=%d is not a power of two", p.m);
-    MQ_REQUIRE(p.K == 1 || (p.K % 4 == 0 && p.had_bits), "mq_hadamard: K=%d needs had_bits and K %% 4 == 0", p.K);
+    MQ_REQUIRE(p.K == 1 || (p.K % 4 == 0 && p.had_bits && ((uintptr_t)p.had_bits) % 4 == 0), "mq_hadamard: K=%d needs 4-byte aligned had_words and K %% 4 == 0", p.K);
     MQ_REQUIRE(p.ldx >= p.n_in, "mq_hadamard: ldx < n_in");
     const size_t esz = (x_dtype == MQ_F32) ? 4 : 2;
     p.vec_ok = (((uintptr_t)p.x) % 16 == 0) && ((p.ldx * esz) % 16 == 0);
@@ -437,24 +432,30 @@ static int hadamard_common(HadArgs p, int x_dtype, bool quant, void *stream)
 
 }  // namespace mq
 
+extern "C" int mq_hadamard_debug_threads(int threads)
+{
+    mq::g_had_threads = (threads == 512 || threads == 256) ? threads : 0;
+    return MQ_OK;
+}
+
 extern "C" int mq_hadamard(const void *x, int x_dtype, long M, long n_in, long ldx, long n, int K,
-                           const uint8_t *had_bits, int fp32_had, void *out, long ldo, void *stream)
+                           const uint32_t *had_words, int fp32_had, void *out, long ldo, void *stream)
 {
     mq::HadArgs p;
     memset(&p, 0, sizeof(p));
-    p.x = x; p.M = M; p.n_in = n_in; p.ldx = ldx; p.n = n; p.K = K; p.had_bits = had_bits;
+    p.x = x; p.M = M; p.n_in = n_in; p.ldx = ldx; p.n = n; p.K = K; p.had_bits = reinterpret_cast<const uint8_t *>(had_words);
     p.fp32_had = fp32_had; p.out = out; p.ldo = ldo; p.s0 = p.s1 = 1.0f;
     return mq::hadamard_common(p, x_dtype, false, stream);
 }
 
 extern "C" int mq_hadamard_quant_i8(const void *x, int x_dtype, long M, long n_in, long ldx, long n,
-                                    int K, const uint8_t *had_bits, int fp32_had, float scale0,
+                                    int K, const uint32_t *had_words, int fp32_had, float scale0,
                                     float scale1, const uint8_t *row_sel, int skip_col0,
                                     float *x0_out, int8_t *out, long K_pad, long ldo, void *stream)
 {
     mq::HadArgs p;
     memset(&p, 0, sizeof(p));
-    p.x = x; p.M = M; p.n_in = n_in; p.ldx = ldx; p.n = n; p.K = K; p.had_bits = had_bits;
+    p.x = x; p.M = M; p.n_in = n_in; p.ldx = ldx; p.n = n; p.K = K; p.had_bits = reinterpret_cast<const uint8_t *>(had_words);
     p.fp32_had = fp32_had; p.s0 = scale0; p.s1 = scale1; p.row_sel = row_sel;
     p.skip_col0 = skip_col0; p.x0_out = x0_out; p.qout = out; p.K_pad = K_pad; p.ldq = ldo;
     return mq::hadamard_common(p, x_dtype, true, stream);

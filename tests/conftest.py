@@ -28,5 +28,13 @@ def had_table(golden_dir):
     for k in (12, 20, 28, 36, 40, 52, 60, 108, 140, 156, 172):
         bits = np.unpackbits(t[f"had{k}"])[: k * k].reshape(k, k).astype(np.int8)
         mats[k] = bits * 2 - 1
+    def words(h):
+        K = h.shape[0]
+        wpr = (K + 31) // 32
+        bits = np.zeros((K, wpr * 32), dtype=np.uint8)
+        bits[:, :K] = h > 0
+        return np.packbits(bits.reshape(K, wpr, 32), axis=-1, bitorder="little").view("<u4").reshape(K, wpr).view(np.int32)
+
     return {"mats": mats, "packed": {k: t[f"had{k}"] for k in mats},
+            "words": {k: words(m) for k, m in mats.items()},
             "n2k": dict(zip(t["n"].tolist(), t["K"].tolist()))}

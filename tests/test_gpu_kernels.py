@@ -120,7 +120,7 @@ def test_hadamard_matches_oracle(had_table, n_in, n, dtype, fp32_had):
     M = 5
     x = make_x(100 + n, (M, n_in))
     xt = to_dev(x, dtype)
-    bits = None if K == 1 else to_dev(had_table["packed"][K])
+    bits = None if K == 1 else to_dev(had_table["words"][K])
     y = ops().hadamard(xt, n, K, bits, fp32_had=fp32_had)
     mode = MODE[dtype]
     mid = 0 if (fp32_had or dtype == torch.float32) else mode
@@ -137,7 +137,7 @@ def test_hadamard_quant_fused(had_table, n_in, n, dtype, split):
     M = 6
     x = make_x(200 + n, (M, n_in))
     xt = to_dev(x, dtype)
-    bits = None if K == 1 else to_dev(had_table["packed"][K])
+    bits = None if K == 1 else to_dev(had_table["words"][K])
     sel = (np.arange(M) % 2).astype(np.uint8)
     mode = MODE[dtype]
     rot = oracle.hadamard(as_f32(xt), n, K, None if K == 1 else had_table["mats"][K],
@@ -161,7 +161,7 @@ def test_hadamard_golden_reference(had_table, golden_dir):
     for n in [64, 1280, 3584, 4096, 5120, 11008, 14336, 19968, 30720]:
         K = had_table["n2k"][n]
         x = make_x(100 + n, (2 if n <= 5120 else 1, n))
-        bits = None if K == 1 else to_dev(had_table["packed"][K])
+        bits = None if K == 1 else to_dev(had_table["words"][K])
         y32 = ops().hadamard(to_dev(x), n, K, bits)
         np.testing.assert_array_equal(as_f32(y32), g[f"cuda_{n}"])
         y16 = ops().hadamard(to_dev(x, torch.float16), n, K, bits)

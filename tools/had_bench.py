@@ -24,7 +24,11 @@ def bench(fn, iters=20):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
+from mquant_amd._lib import call
 dev = torch.device("cuda:0")
+threads = int(os.environ.get("HAD_THREADS", "0"))
+call("mq_hadamard_debug_threads", threads)
+print("threads per row:", threads)
 for name, M, n_in, n in [("vis.fc2", 1024, 5120, 5120), ("llm.down", 768, 18944, 19968),
                          ("qwenvl.c_proj", 768, 11008, 11008), ("pow2.8192", 1024, 8192, 8192)]:
     _, K = hu.get_hadK(n)
