@@ -1,0 +1,98 @@
+"""GPTQ (Frantar et al., arXiv:2210.17323) for nn.Linear: Hessian accumulation over calibration
+inputs, damped Cholesky inverse, column-blocked quantization with error feedback, optional
+activation ordering.  Host-side torch code (offline, one-shot); the reference's counterpart is
+``fake_quant/gptq/gptq_utils.py:171-310``."""
+import logging
+import math
+
+import torch
+
+torch.backends.cuda.matmul.allow_tf32 = False
+torch.backends.cudnn.allow_tf32 = False
+
+
+class GPTQ:
+    def __init__(self, layer):
+        self.layer = layer
+        self.dev = layer.weight.device
+        self.rows, self.columns = layer.weight.shape[0], layer.weight.data.flatten(1).shape[1]
+        self.H = torch.zeros((self.columns, self.columns), device=self.dev)
+        self.nsamples = 0
+        self.quantizer = None
+
+    def add_batch(self, inp, out=None):
+        """Running mean of 2 x x^T over every token seen so far."""
+        if inp.dim() == 2:
+            inp = inp.unsqueeze(0)
+        batch = inp.shape[0]
+        x = inp.reshape(-1, inp.shape[-1]).t().float()
+        self.H *= self.nsamples / (self.nsamples + batch)
+        self.nsamples += batch
+        x = math.sqrt(2 / self.nsamples) * x
+        self.H += x @ x.t()
+
+    def fasterquant(self, blocksize=128, percdamp=0.01, groupsize=-1, actorder=False,
+                    static_groups=False):
+        W = self.layer.weight.data.clone().float()
+        if not self.quantizer.ready():
+            self.quantizer.find_params(W)
+        H = self.H
+        self.H = None
+        dead = torch.diag(H) == 0
+        H[dead, dead] = 1
+        W[:, dead] = 0
+        groups = None
+        if static_groups:
+            import copy
+            groups = []
+            for i in range(0, self.columns, groupsize):
+                g = copy.deepcopy(self.quantizer)
+                g.find_params(W[:, i:i + groupsize])
+                groups.append(g)
+        perm = invperm = None
+        if actorder:
+            perm = torch.argsort(torch.diag(H), descending=True)
+            W, H = W[:, perm], H[perm][:, perm]
+            invperm = torch.argsort(perm)
+        Q = torch.zeros_like(W)
+        idx = torch.arange(self.columns, device=self.dev)
+        H[idx, idx] += percdamp * torch.mean(torch.diag(H))
+        try:
+            Hinv = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H)), upper=True)
+        except Exception:   # not positive definite: plain RTN, as upstream
+            self.layer.weight.data = self.quantizer.quantize(W if perm is None else W[:, invperm]).to(
+                self.layer.weight.data.dtype)
+            return
+        for i1 in range(0, self.columns, blocksize):
+            i2 = min(i1 + blocksize, self.columns)
+            W1 = W[:, i1:i2].clone()
+            Q1 = torch.zeros_like(W1)
+            E1 = torch.zeros_like(W1)
+            Hb = Hinv[i1:i2, i1:i2]
+            for i in range(i2 - i1):
+                w, d = W1[:, i], Hb[i, i]
+                if groupsize != -1:
+                    if not static_groups:
+                        if (i1 + i) % groupsize == 0:
+                            self.quantizer.find_params(W[:, (i1 + i):(i1 + i + groupsize)])
+                    else:
+                        col = i1 + i
+                        self.quantizer = groups[(int(perm[col]) if actorder else col) // groupsize]
+                q = self.quantizer.quantize(w.unsqueeze(1)).flatten()
+                Q1[:, i] = q
+                err = (w - q) / d
+                W1[:, i:] -= err.unsqueeze(1) @ Hb[i, i:].unsqueeze(0)
+                E1[:, i] = err
+            Q[:, i1:i2] = Q1
+            W[:, i2:] -= E1 @ Hinv[i1:i2, i2:]
+        if actorder:
+            Q = Q[:, invperm]
+        self.layer.weight.data = Q.reshape(self.layer.weight.shape).to(self.layer.weight.data.dtype)
+        if torch.any(torch.isnan(self.layer.weight.data)):
+            logging.warning("NaN in weights")
+            raise ValueError("NaN in weights")
+
+    def free(self):
+        self.H = None
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
