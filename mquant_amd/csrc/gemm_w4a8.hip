@@ -44,7 +44,8 @@ struct GemmArgs {
     long lda;
     const uint8_t *w;
     long M, N, K_pad;
-    long n_tiles;  // N_pad / 16
+    long n_tiles;  // ceil(N / 16)
+    long n_pairs;  // ceil(N / 32): 16-channel tile pairs in the W4 image
     float sx0, sx1;
     const uint8_t *row_sel;
     const float *s_w, *bias, *x0, *w0;
@@ -111,165 +112,27 @@ __device__ __forceinline__ void store_quad(const GemmArgs &p, long m, long n, v4
     }
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int W_BITS, int EPI, int DMA_POS>
-__global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmArgs p)
+// ---- epilogue -------------------------------------------------------------------------------
+// Code executed once per workgroup is instruction-fetch bound (cold I-cache), so the epilogue is
+// kept SMALL: each wave parks its raw int32 accumulators in a private LDS slab with a handful of
+// unrolled ds_write_b128, then a ROLLED loop re-reads them row-contiguously, dequantises and
+// stores 16 B (fp16) / 32 B per lane: whole 128-byte row segments, edges in the same loop.
+template <int TM, int TN, int NWAVES, int RING_BYTES, int W_BITS, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][TM], char *smem,
+                                              int wave, int lane, int wm, int wn, long m0, long nt0,
+                                              int split)
 {
-    constexpr int NWAVES = WARPS_M * WARPS_N;
-    constexpr int TM = BM / WARPS_M / 16;          // activation fragments per wave
-    constexpr int TN = BN / WARPS_N / 16;          // weight fragments per wave
-    constexpr int X_FRAGS = (BM / 16) * 2;         // 1 KiB DMA pieces per stage (2 k-tiles)
-    constexpr int W_PIECES = (W_BITS == 4) ? (BN / 16) : (BN / 16) * 2;
-    constexpr int PIECES = X_FRAGS + W_PIECES;
-    constexpr int LPW = PIECES / NWAVES;           // DMA instructions per wave per stage
-    constexpr int X_BYTES = X_FRAGS * 1024;
-    constexpr int STAGE_BYTES = PIECES * 1024;
-    static_assert(BM % (WARPS_M * 16) == 0 && BN % (WARPS_N * 16) == 0, "tile shape");
-    static_assert(PIECES % NWAVES == 0, "DMA pieces must divide evenly over the waves");
-    static_assert(STAGES == 2 || STAGES == 3, "ring depth");
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WARPS_N, wn = wave % WARPS_N;
-
-    // ---- workgroup -> (split, bn, bm), XCD-aware and bijective ------------------------
-    const int m_blocks = (int)ceil_div(p.M, BM);
-    const int total = gridDim.x;
-    int wid;
-    {
-        const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
-        const int q = total >> 3, r = total & 7;
-        wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int bm = wid % m_blocks;
-    const int rest = wid / m_blocks;
-    const int split = rest % p.splits;
-    const int bn = rest / p.splits;
-    const long m0 = (long)bm * BM;
-    const long nt0 = (long)bn * (BN / 16);
-
-    const long kps = p.K_pad / 128;  // k-steps in the whole reduction
-    const long k_begin = kps * split / p.splits;
-    const long k_end = kps * (split + 1) / p.splits;
-    const int nk = (int)(k_end - k_begin);
-
-    // ---- per-lane DMA source addresses (piece f = wave + i*NWAVES) ----------------------
-    const char *src[LPW];
-    int step_bytes[LPW];
-#pragma unroll
-    for (int i = 0; i < LPW; ++i) {
-        const int f = wave + i * NWAVES;
-        if (f < X_FRAGS) {
-            const int mt = f >> 1, kt = f & 1;
-            long row = m0 + mt * 16 + (lane & 15);
-            if (row >= p.M) row = p.M - 1;
-            src[i] = reinterpret_cast<const char *>(p.a) + row * p.lda + kt * 64 + (lane >> 4) * 16 +
-                     k_begin * 128;
-            step_bytes[i] = 128;
-        } else if (W_BITS == 4) {
-            long nt = nt0 + (f - X_FRAGS);
-            if (nt >= p.n_tiles) nt = p.n_tiles - 1;
-            src[i] = reinterpret_cast<const char *>(p.w) + ((nt * kps + k_begin) * 64 + lane) * 16;
-            step_bytes[i] = 1024;
-        } else {
-            const int g = f - X_FRAGS;
-            long nt = nt0 + (g >> 1);
-            if (nt >= p.n_tiles) nt = p.n_tiles - 1;
-            src[i] = reinterpret_cast<const char *>(p.w) +
-                     (((nt * kps + k_begin) * 2 + (g & 1)) * 64 + lane) * 16;
-            step_bytes[i] = 2048;
-        }
-    }
-
-    auto issue_stage = [&](int stage, int it) {
-        char *base = smem + stage * STAGE_BYTES;
-#pragma unroll
-        for (int i = 0; i < LPW; ++i) {
-            const int f = wave + i * NWAVES;
-            dma16(src[i] + (long)it * step_bytes[i], base + f * 1024);
-        }
-    };
-
-    v4i acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = v4i{0, 0, 0, 0};
-
-    // ---- main loop ------------------------------------------------------------------------
-#pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s)
-        if (s < nk) issue_stage(s, s);
-
-    int cur = 0;
-    for (int it = 0; it < nk; ++it) {
-        // stage `it` has landed when at most the (STAGES-2) younger stages are outstanding
-        if (STAGES == 3 && it + 1 < nk) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();   // everyone's pieces landed; everyone left stage it-1
-        const bool more = it + STAGES - 1 < nk;
-        int nxt = cur + STAGES - 1;
-        if (nxt >= STAGES) nxt -= STAGES;
-        if (DMA_POS == 0 && more) issue_stage(nxt, it + STAGES - 1);
-
-        const char *xs = smem + cur * STAGE_BYTES;
-        const char *ws = xs + X_BYTES;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            v4i xf[TM];
-#pragma unroll
-            for (int j = 0; j < TM; ++j) {
-                const int mt = wm * TM + j;
-                xf[j] = *reinterpret_cast<const v4i *>(xs + (mt * 2 + kt) * 1024 + lane * 16);
-            }
-            // the DMA of the stage after next is issued behind the first fragment reads, so its
-            // issue slots overlap MFMA execution instead of delaying the first MFMA of the step
-            if (DMA_POS == 1 && kt == 0 && more) issue_stage(nxt, it + STAGES - 1);
-            if (DMA_POS == 2 && kt == 1 && more) issue_stage(nxt, it + STAGES - 1);
-#pragma unroll
-            for (int i = 0; i < TN; ++i) {
-                const int nt = wn * TN + i;
-                v4i wf;
-                if (W_BITS == 4) {
-                    const v2i pk = *reinterpret_cast<const v2i *>(ws + nt * 1024 + lane * 16 + kt * 8);
-                    wf[0] = (pk[0] << 4) & 0xF0F0F0F0;
-                    wf[1] = pk[0] & 0xF0F0F0F0;
-                    wf[2] = (pk[1] << 4) & 0xF0F0F0F0;
-                    wf[3] = pk[1] & 0xF0F0F0F0;
-                } else {
-                    wf = *reinterpret_cast<const v4i *>(ws + (nt * 2 + kt) * 1024 + lane * 16);
-                }
-#pragma unroll
-                for (int j = 0; j < TM; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf, xf[j], acc[i][j], 0, 0, 0);
-            }
-        }
-        if (++cur == STAGES) cur = 0;
-    }
-
-    // ---- epilogue ---------------------------------------------------------------------------
-    // Code executed once per workgroup is instruction-fetch bound (cold I-cache), so the
-    // epilogue is kept SMALL: each wave parks its raw int32 accumulators in a private LDS
-    // slab with a handful of unrolled ds_write_b128, then a ROLLED loop re-reads them
-    // row-contiguously, dequantises and stores 16 B (fp16) / 32 B per lane: whole 128-byte
-    // row segments, edges handled in the same loop.
     // D layout: col = lane & 15 -> m, row = (lane >> 4) * 4 + r -> n
     constexpr int WN_COLS = TN * 16;                 // columns of the wave's sub-tile
     constexpr int SLAB_LD = WN_COLS * 4 + 16;        // bytes per slab row (+16: conflict-free)
-    constexpr int RING_BYTES = STAGES * STAGE_BYTES;
     constexpr int PASS_MT =                          // m-tiles parked per pass (slab must fit)
-        (TM % 4 == 0 && NWAVES * 64 * SLAB_LD <= RING_BYTES) ? 4
-        : (TM % 2 == 0 && NWAVES * 32 * SLAB_LD <= RING_BYTES) ? 2 : 1;
+        (TM % 4 == 0 && NWAVES * 64 * (SLAB_LD + 8) <= RING_BYTES) ? 4
+        : (TM % 2 == 0 && NWAVES * 32 * (SLAB_LD + 8) <= RING_BYTES) ? 2 : 1;
     constexpr int PASS_ROWS = PASS_MT * 16;
     constexpr int SLAB_BYTES = PASS_ROWS * SLAB_LD + PASS_ROWS * 8;
     constexpr int LANES_PER_ROW = WN_COLS / 8;       // 8 outputs per lane
     constexpr int ROWS_PER_IT = 64 / LANES_PER_ROW;
-    static_assert(NWAVES * SLAB_BYTES <= STAGES * STAGE_BYTES, "epilogue slab must fit the ring");
+    static_assert(NWAVES * SLAB_BYTES <= RING_BYTES, "epilogue slab must fit the ring");
     static_assert(TM % PASS_MT == 0 && 64 % LANES_PER_ROW == 0 && PASS_ROWS % ROWS_PER_IT == 0, "epilogue geometry");
 
     __syncthreads();                                 // every wave has left the operand ring
@@ -392,6 +255,153 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
     }
 }
 
+template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int W_BITS, int EPI, int DMA_POS>
+__global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmArgs p)
+{
+    constexpr int NWAVES = WARPS_M * WARPS_N;
+    constexpr int TM = BM / WARPS_M / 16;          // activation fragments per wave
+    constexpr int TN = BN / WARPS_N / 16;          // weight fragments per wave
+    constexpr int X_FRAGS = (BM / 16) * 2;         // 1 KiB DMA pieces per stage (2 k-tiles)
+    constexpr int W_PIECES = (W_BITS == 4) ? (BN / 16) : (BN / 16) * 2;
+    constexpr int PIECES = X_FRAGS + W_PIECES;
+    constexpr int LPW = PIECES / NWAVES;           // DMA instructions per wave per stage
+    constexpr int X_BYTES = X_FRAGS * 1024;
+    constexpr int STAGE_BYTES = PIECES * 1024;
+    static_assert(BM % (WARPS_M * 16) == 0 && BN % (WARPS_N * 16) == 0, "tile shape");
+    static_assert(PIECES % NWAVES == 0, "DMA pieces must divide evenly over the waves");
+    static_assert(STAGES == 2 || STAGES == 3, "ring depth");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+
+    // ---- workgroup -> (split, bn, bm), XCD-aware and bijective ------------------------
+    const int m_blocks = (int)ceil_div(p.M, BM);
+    const int total = gridDim.x;
+    int wid;
+    {
+        const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+        const int q = total >> 3, r = total & 7;
+        wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm = wid % m_blocks;
+    const int rest = wid / m_blocks;
+    const int split = rest % p.splits;
+    const int bn = rest / p.splits;
+    const long m0 = (long)bm * BM;
+    const long nt0 = (long)bn * (BN / 16);
+
+    const long kps = p.K_pad / 128;  // k-steps in the whole reduction
+    const long k_begin = kps * split / p.splits;
+    const long k_end = kps * (split + 1) / p.splits;
+    const int nk = (int)(k_end - k_begin);
+
+    // ---- per-lane DMA source addresses (piece f = wave + i*NWAVES) ----------------------
+    const char *src[LPW];
+    int step_bytes[LPW];
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+        const int f = wave + i * NWAVES;
+        if (f < X_FRAGS) {
+            const int mt = f >> 1, kt = f & 1;
+            long row = m0 + mt * 16 + (lane & 15);
+            if (row >= p.M) row = p.M - 1;
+            src[i] = reinterpret_cast<const char *>(p.a) + row * p.lda + kt * 64 + (lane >> 4) * 16 +
+                     k_begin * 128;
+            step_bytes[i] = 128;
+        } else if (W_BITS == 4) {
+            // piece g = (n-tile pair, k-tile of the step): image [ntp][kt][lane][16 B]
+            const int g = f - X_FRAGS;
+            long ntp = nt0 / 2 + (g >> 1);
+            if (ntp >= p.n_pairs) ntp = p.n_pairs - 1;
+            src[i] = reinterpret_cast<const char *>(p.w) +
+                     (((ntp * kps + k_begin) * 2 + (g & 1)) * 64 + lane) * 16;
+            step_bytes[i] = 2048;
+        } else {
+            const int g = f - X_FRAGS;
+            long nt = nt0 + (g >> 1);
+            if (nt >= p.n_tiles) nt = p.n_tiles - 1;
+            src[i] = reinterpret_cast<const char *>(p.w) +
+                     (((nt * kps + k_begin) * 2 + (g & 1)) * 64 + lane) * 16;
+            step_bytes[i] = 2048;
+        }
+    }
+
+    auto issue_stage = [&](int stage, int it) {
+        char *base = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const int f = wave + i * NWAVES;
+            dma16(src[i] + (long)it * step_bytes[i], base + f * 1024);
+        }
+    };
+
+    v4i acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+
+    // ---- main loop ------------------------------------------------------------------------
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) issue_stage(s, s);
+
+    int cur = 0;
+    for (int it = 0; it < nk; ++it) {
+        // stage `it` has landed when at most the (STAGES-2) younger stages are outstanding
+        if (STAGES == 3 && it + 1 < nk) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();   // everyone's pieces landed; everyone left stage it-1
+        const bool more = it + STAGES - 1 < nk;
+        int nxt = cur + STAGES - 1;
+        if (nxt >= STAGES) nxt -= STAGES;
+        if (DMA_POS == 0 && more) issue_stage(nxt, it + STAGES - 1);
+
+        const char *xs = smem + cur * STAGE_BYTES;
+        const char *ws = xs + X_BYTES;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            v4i xf[TM];
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int mt = wm * TM + j;
+                xf[j] = *reinterpret_cast<const v4i *>(xs + (mt * 2 + kt) * 1024 + lane * 16);
+            }
+            // the DMA of the stage after next is issued behind the first fragment reads, so its
+            // issue slots overlap MFMA execution instead of delaying the first MFMA of the step
+            if (DMA_POS == 1 && kt == 0 && more) issue_stage(nxt, it + STAGES - 1);
+            if (DMA_POS == 2 && kt == 1 && more) issue_stage(nxt, it + STAGES - 1);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int nt = wn * TN + i;
+                v4i wf;
+                if (W_BITS == 4) {
+                    const v2i pk = *reinterpret_cast<const v2i *>(ws + ((nt >> 1) * 2 + kt) * 1024 + lane * 16 + (nt & 1) * 8);
+                    wf[0] = (pk[0] << 4) & 0xF0F0F0F0;
+                    wf[1] = pk[0] & 0xF0F0F0F0;
+                    wf[2] = (pk[1] << 4) & 0xF0F0F0F0;
+                    wf[3] = pk[1] & 0xF0F0F0F0;
+                } else {
+                    wf = *reinterpret_cast<const v4i *>(ws + (nt * 2 + kt) * 1024 + lane * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf, xf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (++cur == STAGES) cur = 0;
+    }
+
+    gemm_epilogue<TM, TN, NWAVES, STAGES * STAGE_BYTES, W_BITS, EPI>(p, acc, smem, wave, lane, wm, wn, m0, nt0, split);
+}
+
 // Combine split-K partials (fixed order s = 0..splits-1; integer sums are exact) and apply
 // the same epilogue.  One thread per 4 consecutive output channels.
 template <int EPI>
@@ -423,6 +433,196 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p)
         }
         store_quad<EPI>(p, m, n, a, sx, xz);
     }
+}
+
+// =================================================================================================
+// Software-pipelined variant for the large GEMMs (256 x 256 tile, 8 waves, int4 weights).
+//
+// The K loop advances in 64-wide k-tiles ("phases"); a 6-slot LDS ring (6 x 24 KiB) keeps four
+// k-tiles of LDS-DMA in flight.  The MFMA operands are double buffered in registers: while the 32
+// MFMAs of k-tile p issue, the ds_reads of k-tile p+1 fill the other register set, so no LDS
+// latency is exposed after the per-phase barrier:
+//
+//   phase p:  s_waitcnt vmcnt(9)  (k-tile p+1 landed; p+2..p+4 stay in flight)
+//             s_barrier           (p+1 visible to all; everybody has finished reading slot of p-1)
+//             DMA k-tile p+5 -> slot (p+5) % 6 (== slot of p-1)
+//             ds_read fragments of k-tile p+1 -> frag[(p+1) & 1]
+//             32 x V_MFMA_I32_16X16X64_I8 on frag[p & 1]
+// =================================================================================================
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_w4a8_pipe_kernel(GemmArgs p)
+{
+    constexpr int BM = 256, BN = 256, WARPS_N = 4, NWAVES = 8, TM = 8, TN = 4;
+    constexpr int RING = 6, X_PIECES = BM / 16, W_PIECES = BN / 32, PIECES = X_PIECES + W_PIECES;
+    constexpr int LPW = PIECES / NWAVES;                    // 3 DMA instructions per wave per k-tile
+    constexpr int SLOT_BYTES = PIECES * 1024, X_BYTES = X_PIECES * 1024;
+    static_assert(PIECES % NWAVES == 0, "DMA pieces must divide evenly over the waves");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+
+    const int m_blocks = (int)ceil_div(p.M, BM);
+    const int total = gridDim.x;
+    int wid;
+    {
+        const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+        const int q = total >> 3, r = total & 7;
+        wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm = wid % m_blocks;
+    const int rest = wid / m_blocks;
+    const int split = rest % p.splits;
+    const int bn = rest / p.splits;
+    const long m0 = (long)bm * BM;
+    const long nt0 = (long)bn * (BN / 16);
+
+    const long kts = p.K_pad / 64;
+    const long kt_begin = kts * split / p.splits;
+    const long kt_end = kts * (split + 1) / p.splits;
+    const int nt = (int)(kt_end - kt_begin);                // k-tiles of this workgroup
+
+    const char *src[LPW];
+    int step_bytes[LPW];
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+        const int f = wave + i * NWAVES;
+        if (f < X_PIECES) {
+            long row = m0 + f * 16 + (lane & 15);
+            if (row >= p.M) row = p.M - 1;
+            src[i] = reinterpret_cast<const char *>(p.a) + row * p.lda + (lane >> 4) * 16 + kt_begin * 64;
+            step_bytes[i] = 64;
+        } else {
+            long ntp = nt0 / 2 + (f - X_PIECES);
+            if (ntp >= p.n_pairs) ntp = p.n_pairs - 1;
+            src[i] = reinterpret_cast<const char *>(p.w) + ((ntp * kts + kt_begin) * 64 + lane) * 16;
+            step_bytes[i] = 1024;
+        }
+    }
+    auto issue = [&](int slot, int t) {
+        char *base = smem + slot * SLOT_BYTES;
+#pragma unroll
+        for (int i = 0; i < LPW; ++i)
+            dma16(src[i] + (long)t * step_bytes[i], base + (wave + i * NWAVES) * 1024);
+    };
+    // wait until at most `newer` k-tiles issued after the wanted one are still in flight
+    auto wait_newer = [&](int newer) {
+        switch (newer) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW) : "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPW) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPW) : "memory"); break;
+        }
+    };
+
+    struct Frag {
+        v4i x[TM];      // activation fragments (MFMA B operand)
+        v4i wpk[TN / 2];  // packed weights: two n-tiles per 16 bytes
+    };
+    auto load_frag = [&](Frag &fr, int slot) {
+        const char *xs = smem + slot * SLOT_BYTES;
+        const char *ws = xs + X_BYTES;
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+            fr.x[j] = *reinterpret_cast<const v4i *>(xs + (wm * TM + j) * 1024 + lane * 16);
+#pragma unroll
+        for (int i = 0; i < TN / 2; ++i)
+            fr.wpk[i] = *reinterpret_cast<const v4i *>(ws + (wn * (TN / 2) + i) * 1024 + lane * 16);
+    };
+
+    v4i acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+
+    auto mfmas = [&](const Frag &fr) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int lo = fr.wpk[i >> 1][(i & 1) * 2], hi = fr.wpk[i >> 1][(i & 1) * 2 + 1];
+            v4i wf;
+            wf[0] = (lo << 4) & 0xF0F0F0F0;
+            wf[1] = lo & 0xF0F0F0F0;
+            wf[2] = (hi << 4) & 0xF0F0F0F0;
+            wf[3] = hi & 0xF0F0F0F0;
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf, fr.x[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // ---- prologue: k-tiles 0..4 in flight, k-tile 0 into registers --------------------------------
+    const int pre = nt < RING - 1 ? nt : RING - 1;
+    for (int t = 0; t < pre; ++t) issue(t, t);
+    wait_newer(pre - 1);
+    __builtin_amdgcn_s_barrier();
+    Frag fa, fb;
+    load_frag(fa, 0);
+
+    int slot_next = 1;          // slot of k-tile p+1
+    int slot_fill = RING - 1;   // slot of k-tile p+5
+    auto advance = [&]() {
+        if (++slot_next == RING) slot_next = 0;
+        if (++slot_fill == RING) slot_fill = 0;
+    };
+    // steady state: no conditionals inside, so the compiler can emit COUNTED lgkmcnt waits (the
+    // ds_reads of the next k-tile stay in flight under the MFMAs of the current one)
+    auto phase_steady = [&](const Frag &cur, Frag &nxt, int pidx) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPW) : "memory");   // k-tile p+1 landed
+        __builtin_amdgcn_s_barrier();
+        issue(slot_fill, pidx + RING - 1);
+        load_frag(nxt, slot_next);
+        mfmas(cur);
+        advance();
+    };
+    auto phase_tail = [&](const Frag &cur, Frag &nxt, int pidx) {
+        const bool has_next = pidx + 1 < nt;
+        if (has_next) {
+            const int last_issued = (pidx + RING - 2 < nt - 1) ? pidx + RING - 2 : nt - 1;
+            wait_newer(last_issued - (pidx + 1));
+        }
+        __builtin_amdgcn_s_barrier();
+        if (pidx + RING - 1 < nt) issue(slot_fill, pidx + RING - 1);
+        if (has_next) load_frag(nxt, slot_next);
+        mfmas(cur);
+        advance();
+    };
+    int pidx = 0;
+    for (; pidx + RING < nt; pidx += 2) {     // both phases of the pair are in steady state
+        phase_steady(fa, fb, pidx);
+        phase_steady(fb, fa, pidx + 1);
+    }
+    for (; pidx < nt; pidx += 2) {
+        phase_tail(fa, fb, pidx);
+        if (pidx + 1 < nt) phase_tail(fb, fa, pidx + 1);
+    }
+
+    gemm_epilogue<TM, TN, NWAVES, RING * SLOT_BYTES, 4, EPI>(p, acc, smem, wave, lane, wm, wn, m0, nt0, split);
+}
+
+template <int EPI>
+static int launch_gemm_pipe(const GemmArgs &p, hipStream_t st)
+{
+    constexpr int SMEM = 6 * 24 * 1024;
+    auto kern = gemm_w4a8_pipe_kernel<EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) return fail((int)e, "gemm: set smem attr: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const long m_blocks = ceil_div(p.M, 256);
+    const long n_blocks = ceil_div(p.n_tiles * 16, 256);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(m_blocks * n_blocks * p.splits)), dim3(512), SMEM, st, p);
+    int rc = check_launch("gemm_w4a8_pipe");
+    if (rc != MQ_OK || p.splits == 1) return rc;
+    long blocks = ceil_div(p.M * ceil_div(p.N, 4), 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel<EPI>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    return check_launch("splitk_reduce");
 }
 
 template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int W_BITS, int EPI, int DMA_POS = 1>
@@ -501,6 +701,9 @@ static int dispatch_tile(const GemmArgs &p, int tile, hipStream_t st)
     case 8: if constexpr (W_BITS == 4) return launch_gemm<256, 256, 2, 4, 3, W_BITS, EPI, 0>(p, st); else break;
     case 9: if constexpr (W_BITS == 4) return launch_gemm<256, 256, 2, 4, 3, W_BITS, EPI, 2>(p, st); else break;
     case 5: return launch_gemm<256, 128, 2, 4, 3, W_BITS, EPI>(p, st);
+    case 13: if constexpr (W_BITS == 4) return launch_gemm_pipe<EPI>(p, st); else break;
+    case 14: if constexpr (W_BITS == 4) return launch_gemm<256, 256, 2, 8, 3, W_BITS, EPI>(p, st); else break;
+    case 15: if constexpr (W_BITS == 4) return launch_gemm<256, 256, 8, 2, 3, W_BITS, EPI>(p, st); else break;
     case 10: return launch_gemm<64, 128, 2, 2, 3, W_BITS, EPI>(p, st);
     case 11: return launch_gemm<128, 64, 2, 2, 3, W_BITS, EPI>(p, st);
     case 12: return launch_gemm<128, 128, 4, 2, 3, W_BITS, EPI>(p, st);
@@ -534,6 +737,7 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
     GemmArgs p;
     p.a = a; p.lda = lda; p.w = (const uint8_t *)w; p.M = M; p.N = N; p.K_pad = K_pad;
     p.n_tiles = ceil_div(N, 16);
+    p.n_pairs = ceil_div(N, 32);
     p.sx0 = s_x0; p.sx1 = s_x1; p.row_sel = row_sel; p.s_w = s_w; p.bias = bias; p.x0 = x0; p.w0 = w0;
     p.out = out; p.ldo = ldo;
     const Plan pl = make_plan(M, N, K_pad, workspace != nullptr, workspace_bytes, g_force_tile,

@@ -1,10 +1,10 @@
 // weight_formats.hip -- int4 wire format (reference quant_utils.py:61-94), weight levels,
 // and the pre-tiled images mq_gemm_w4a8 streams into LDS with lane-linear 16-byte DMA.
 //
-// W4 image  [nt = N_pad/16][kp = K_pad/128][lane = 0..63][16 B]
-//   lane l owns output channel n = 16*nt + (l & 15) and, for each half h in {0,1}
-//   (bytes 8h..8h+7), the 16 reduction indices k0..k0+15, k0 = 128*kp + 64*h + 16*(l >> 4):
-//   exactly the B-fragment of one V_MFMA_I32_16X16X64_I8 per half.
+// W4 image  [ntp = N_pad/32][kt = K_pad/64][lane = 0..63][16 B]      (N_pad = ceil32(N))
+//   one 1 KiB piece = the B-fragments of TWO adjacent 16-channel tiles for ONE 64-wide k-tile of
+//   V_MFMA_I32_16X16X64_I8: bytes 8h..8h+7 of lane l belong to channel n = 32*ntp + 16*h + (l & 15)
+//   and hold the 16 reduction indices k0..k0+15, k0 = 64*kt + 16*(l >> 4).
 //   Inside a half, little-endian words P0,P1; nibble i = bits [4i,4i+4):
 //     P0 nibble 2j   -> k0 + j        P0 nibble 2j+1 -> k0 + 4 + j
 //     P1 nibble 2j   -> k0 + 8 + j    P1 nibble 2j+1 -> k0 + 12 + j     (j = 0..3)
@@ -68,18 +68,18 @@ __device__ __forceinline__ int level_at(const int8_t *q, long N, long K, long n,
 __global__ void prepack_w4_kernel(const int8_t *__restrict__ q, long N, long K, long N_pad,
                                   long K_pad, int zero_col0, uint8_t *__restrict__ out)
 {
-    const long kps = K_pad / 128;
-    const long total = (N_pad / 16) * kps * 64;
+    const long kts = K_pad / 64;
+    const long total = (N_pad / 32) * kts * 64;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long)gridDim.x * blockDim.x) {
         const int lane = (int)(i & 63);
         const long frag = i >> 6;
-        const long nt = frag / kps, kp = frag - nt * kps;
-        const long n = nt * 16 + (lane & 15);
+        const long ntp = frag / kts, kt = frag - ntp * kts;
+        const long k0 = kt * 64 + (lane >> 4) * 16;
         unsigned words[4];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const long k0 = kp * 128 + h * 64 + (lane >> 4) * 16;
+            const long n = ntp * 32 + h * 16 + (lane & 15);
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 unsigned wv = 0;
@@ -136,7 +136,8 @@ static unsigned grid_for(long total)
 
 extern "C" size_t mq_prepacked_bytes(long N, long K, int w_bits)
 {
-    const long N_pad = mq::ceil_div(N, 16) * 16, K_pad = mq::ceil_div(K, 128) * 128;
+    const long N_pad = mq::ceil_div(N, w_bits == 4 ? 32 : 16) * (w_bits == 4 ? 32 : 16);
+    const long K_pad = mq::ceil_div(K, 128) * 128;
     return (size_t)(N_pad * K_pad) * (size_t)w_bits / 8;
 }
 
@@ -182,8 +183,8 @@ extern "C" int mq_prepack_w4(const int8_t *q, long N, long K, int zero_col0, uin
 {
     using namespace mq;
     MQ_REQUIRE(N > 0 && K > 0 && q && out, "mq_prepack_w4: bad arguments");
-    const long N_pad = ceil_div(N, 16) * 16, K_pad = ceil_div(K, 128) * 128;
-    const long total = (N_pad / 16) * (K_pad / 128) * 64;
+    const long N_pad = ceil_div(N, 32) * 32, K_pad = ceil_div(K, 128) * 128;
+    const long total = (N_pad / 32) * (K_pad / 64) * 64;
     hipLaunchKernelGGL(prepack_w4_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                        q, N, K, N_pad, K_pad, zero_col0, out);
     return check_launch("prepack_w4");
