@@ -157,10 +157,21 @@ def main():
     torch.cuda.synchronize(dev)
     quant_ms = e0.elapsed_time(e1) / reps
     launches = pf.gemm_launches()
+    traffic, traffic_note = None, "no profiles/r1_traffic.json"
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_traffic.json")
+    if os.path.exists(tpath) and not args.tiny:
+        # HBM bytes per GEMM launch from the PMC passes (tools/pmc_traffic.py); counters cannot be
+        # read inside the timed run, so this is the committed measurement of the same command
+        with open(tpath) as fh:
+            tj = json.load(fh)
+        traffic = tj["kernels"].get("gemm", {}).get("hbm_bytes_per_launch")
+        traffic_note = tj["corrections"]
     achieved = pf.gemm_ops() / (gemm_ms * 1e-3) / 1e12
     roofline = {"bound": "mfma", "kernel": "gemm_w4a8_kernel (V_MFMA_I32_16X16X64_I8)",
                 "achieved": round(achieved, 2), "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
-                "frac": round(achieved / PEAK_INT8_TOPS, 4), "traffic": None,
+                "frac": round(achieved / PEAK_INT8_TOPS, 4), "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_note": traffic_note,
+                "algorithmic_bytes_per_launch": round(pf.gemm_bytes() / launches),
                 "launches_per_step": launches,
                 "avg_launch_us": round(gemm_ms * 1e3 / launches, 3),
                 "algorithmic_ops_per_launch": round(pf.gemm_ops() / launches),

@@ -792,6 +792,122 @@ def calib_qwen2vl_plus(model, args, dataset, calib_num):
     _calibrate_vlmeval(model, args, dataset, calib_num, "generate_kwargs", restore)
 
 
+# ---- Qwen-VL (v1) calibration over the jsonl VQA sets (reference quant_utils.py:722-959) ---------
+def _vqa_entry(folder, train, test, metric, max_new_tokens, question=None, annotation=None):
+    entry = {"train": f"data/{folder}/{train}", "test": f"data/{folder}/{test}"}
+    if question:
+        entry["question"] = f"data/{folder}/{question}"
+    if annotation:
+        entry["annotation"] = f"data/{folder}/{annotation}"
+    entry.update(metric=metric, max_new_tokens=max_new_tokens)
+    return entry
+
+
+#: dataset name -> jsonl files (relative to the working directory), metric and generation length
+ds_collections = {
+    "vqav2_val": _vqa_entry("vqav2", "vqav2_train.jsonl", "vqav2_val.jsonl", "vqa_score", 10,
+                            "v2_OpenEnded_mscoco_val2014_questions.json", "v2_mscoco_val2014_annotations.json"),
+    "vqav2_testdev": _vqa_entry("vqav2", "vqav2_train.jsonl", "vqav2_testdev.jsonl", None, 10),
+    "okvqa_val": _vqa_entry("okvqa", "okvqa_train.jsonl", "okvqa_val.jsonl", "vqa_score", 10,
+                            "OpenEnded_mscoco_val2014_questions.json", "mscoco_val2014_annotations.json"),
+    "textvqa_val": _vqa_entry("textvqa", "textvqa_train.jsonl", "textvqa_val.jsonl", "vqa_score", 10,
+                              "textvqa_val_questions.json", "textvqa_val_annotations.json"),
+    "vizwiz_val": _vqa_entry("vizwiz", "vizwiz_train.jsonl", "vizwiz_val.jsonl", "vqa_score", 10,
+                             "vizwiz_val_questions.json", "vizwiz_val_annotations.json"),
+    "vizwiz_test": _vqa_entry("vizwiz", "vizwiz_train.jsonl", "vizwiz_test.jsonl", None, 10),
+    "docvqa_val": _vqa_entry("docvqa", "train.jsonl", "val.jsonl", "anls", 100, annotation="val/val_v1.0.json"),
+    "docvqa_test": _vqa_entry("docvqa", "train.jsonl", "test.jsonl", None, 100),
+    "chartqa_test_human": _vqa_entry("chartqa", "train_human.jsonl", "test_human.jsonl", "relaxed_accuracy", 100),
+    "chartqa_test_augmented": _vqa_entry("chartqa", "train_augmented.jsonl", "test_augmented.jsonl",
+                                         "relaxed_accuracy", 100),
+    "gqa_testdev": _vqa_entry("gqa", "train.jsonl", "testdev_balanced.jsonl", "accuracy", 10),
+    "ocrvqa_val": _vqa_entry("ocrvqa", "ocrvqa_train.jsonl", "ocrvqa_val.jsonl", "accuracy", 100),
+    "ocrvqa_test": _vqa_entry("ocrvqa", "ocrvqa_train.jsonl", "ocrvqa_test.jsonl", "accuracy", 100),
+    "ai2diagram_test": _vqa_entry("ai2diagram", "train.jsonl", "test.jsonl", "accuracy", 10),
+}
+
+
+class VQADataset(torch.utils.data.Dataset):
+    """One json record per line: image, question, question_id[, answer]."""
+
+    def __init__(self, train, test, prompt, few_shot, use_train=False):
+        with open(train if use_train else test) as fh:
+            self.test = fh.readlines()
+        self.prompt, self.few_shot = prompt, few_shot
+        if few_shot > 0:
+            with open(train) as fh:
+                self.train = fh.readlines()
+
+    def __len__(self):
+        return len(self.test)
+
+    def __getitem__(self, idx):
+        import json
+        import random
+        rec = json.loads(self.test[idx].strip())
+        shots = ""
+        if self.few_shot > 0:
+            for line in random.sample(self.train, self.few_shot):
+                ex = json.loads(line.strip())
+                shots += self.prompt.format(ex["image"], ex["question"]) + f" {ex['answer']}"
+        return {"question": shots + self.prompt.format(rec["image"], rec["question"]),
+                "question_id": rec["question_id"], "annotation": rec.get("answer", None)}
+
+
+def collate_fn(batches, tokenizer):
+    enc = tokenizer([b["question"] for b in batches], return_tensors="pt", padding="longest")
+    return ([b["question_id"] for b in batches], enc.input_ids, enc.attention_mask,
+            [b["annotation"] for b in batches])
+
+
+def calib_vqa(model, tokenizers, args, dataset_name, batch_size, num_workers, seed=0, few_shot=0):
+    """Qwen-VL driver: ``calib_mode`` "v1" = the first ``calib_num`` batches, "v2" = every
+    ``step``-th batch over the whole training split; the last sampled batch runs with
+    ``last_calibrate`` and a single new token.  Then close -> quant."""
+    from copy import deepcopy
+    from tqdm import tqdm
+    tokenizer = deepcopy(tokenizers)
+    tokenizer.padding_side = "left"
+    tokenizer.pad_token_id = tokenizer.eod_id
+    info = ds_collections[dataset_name]
+    dataset = VQADataset(train=info["train"], test=info["test"], prompt="<img>{}</img>{} Answer:",
+                         few_shot=few_shot, use_train=True)
+    loader = torch.utils.data.DataLoader(dataset=dataset, batch_size=batch_size, num_workers=num_workers,
+                                         pin_memory=torch.cuda.is_available(), drop_last=False,
+                                         collate_fn=functools.partial(collate_fn, tokenizer=tokenizer))
+    n_batches = math.ceil(len(dataset) / batch_size)
+    step = n_batches // args.calib_num
+
+    def run(input_ids, attention_mask, max_new_tokens):
+        model.generate(input_ids=input_ids.to(utils.DEV), attention_mask=attention_mask.to(utils.DEV),
+                       do_sample=False, num_beams=1, max_new_tokens=max_new_tokens, min_new_tokens=1,
+                       length_penalty=1, num_return_sequences=1, output_hidden_states=True, use_cache=True,
+                       pad_token_id=tokenizer.eod_id, eos_token_id=tokenizer.eod_id)
+
+    print("Calibrating...")
+    model_open_calibrate(model, args)
+    idx = 0
+    for _, input_ids, attention_mask, _ in tqdm(loader):
+        if args.calib_mode == "v1":
+            idx += 1
+            if idx > args.calib_num:
+                break
+            last = idx == args.calib_num
+        elif args.calib_mode == "v2":
+            take, last = idx % step == 0, idx + step > n_batches
+            idx += 1
+            if not take:
+                continue
+        else:
+            raise ValueError("Invalid calibration mode")
+        if last:
+            model_open_last_calibrate(model, args)
+        run(input_ids, attention_mask, 1 if last else info["max_new_tokens"])
+    model_close_calibrate(model, args)
+    print("Calibrate End...")
+    model_quant(model, args)
+
+
 def calib_layer(wrapper_or_model, batches, args=None):
     """Protocol helper for stand-alone layers / toy models: open -> forward every batch (the
     last one with ``last_calibrate``) -> close -> quant.  ``batches`` are positional inputs."""

@@ -10,6 +10,7 @@ so that  (x Q) (W Q)^T = x W^T  and  (x W^T + b) Q = x (Q^T W)^T + Q^T b.
 import typing
 
 import torch
+import tqdm
 
 from fake_quant import module_util, utils
 from fake_quant.hadamard_utils import (  # noqa: F401  (re-exported like upstream)
@@ -167,6 +168,202 @@ def pad_linear_inputs_(model, match: str, new_in: int) -> int:
             setattr(modules[parent_name] if parent_name else model, leaf, new)
             count += 1
     return count
+
+
+# =============================================================================== Qwen-VL (v1)
+# The "opt" Qwen-VL checkpoint the drivers load (reference model/visual_opt.py:452-523,
+# modeling_qwen_opt.py) has q/k/v split into three Linears, `visual.fc_sub_mean` (mean removal as
+# a Linear behind ln_pre) and `visual.proj_fc` (the old `proj` parameter as a Linear).
+# MiniCPM-V shares the helpers through ``is_minicpmv`` (other attribute paths, same algebra).
+def _pick(obj, *names):
+    for n in names:
+        if hasattr(obj, n):
+            return getattr(obj, n)
+    raise AttributeError(f"none of {names} on {type(obj).__name__}")
+
+
+def _scale_param_(param, gamma):
+    """param <- param / gamma: a positional term added AFTER a norm moves in front of its affine."""
+    param.data = (param.data.double() / gamma.data.double()).to(param.data.dtype)
+
+
+def fuse_qwenvl_layer_norms(model, args):
+    print("fuse qwenvl layer norms")
+    vis = model.transformer.visual
+    if not args.no_fuse_visual_clip:
+        for blk in vis.transformer.resblocks:
+            fuse_ln_linear(blk.ln_1, [blk.attn.q_proj, blk.attn.k_proj, blk.attn.v_proj])
+            fuse_ln_linear(blk.ln_2, [blk.mlp.c_fc])
+            bake_mean_into_linear(blk.attn.out_proj)
+            bake_mean_into_linear(blk.mlp.c_proj)
+        module_util.replace_modules(vis.transformer.resblocks, torch.nn.LayerNorm,
+                                    lambda _: module_util.RMSN(model.config.visual["width"], eps=1e-6),
+                                    replace_layers=False)
+    if not args.no_fuse_visual_cross_attn:
+        pool = vis.attn_pool
+        _scale_param_(pool.pos_embed_kv, pool.ln_kv.weight)
+        fuse_ln_linear(pool.ln_kv, [pool.attn.k_proj, pool.attn.v_proj])
+        _scale_param_(pool.pos_embed, pool.ln_q.weight)
+        fuse_ln_linear(pool.ln_q, [pool.attn.q_proj])
+        pool.query.data = (pool.query.data - pool.query.data.double().mean(dim=-1, keepdim=True)).to(pool.query.data.dtype)
+        bake_mean_into_linear(pool.kv_proj)
+        module_util.replace_modules(pool, torch.nn.LayerNorm,
+                                    lambda _: module_util.RMSN(model.config.visual["output_dim"], eps=1e-6),
+                                    replace_layers=False)
+        fuse_ln_linear(vis.ln_post, [vis.proj_fc])
+        bake_mean_into_linear(pool.attn.out_proj)
+        vis.ln_post = module_util.RMSN(model.config.visual["output_dim"], eps=1e-6)
+    if not args.no_fuse_llm:
+        for layer in model.transformer.h:
+            fuse_ln_linear(layer.ln_2, [layer.mlp.w1, layer.mlp.w2])
+            fuse_ln_linear(layer.ln_1, [layer.attn.q_proj, layer.attn.k_proj, layer.attn.v_proj])
+        fuse_ln_linear(model.transformer.ln_f, [model.lm_head])
+
+
+def _rotate_bias_row_(linear, Q):
+    if linear.bias is not None:
+        rotate_vector_(linear.bias, Q)
+
+
+def rotate_embeddings(model, Q, is_minicpmv=False) -> None:
+    table, proj = ((model.llm.model.embed_tokens, model.resampler.proj_fc) if is_minicpmv
+                   else (model.transformer.wte, model.transformer.visual.proj_fc))
+    rotate_vector_(table.weight, Q)
+    rotate_linear_output_(proj, Q)          # the projector writes into the LLM residual stream
+
+
+def rotate_head(model, Q: torch.Tensor, is_minicpmv=False) -> None:
+    rotate_linear_input_(model.llm.lm_head if is_minicpmv else model.lm_head, Q)
+
+
+def rotate_kv_proj(model, Q: torch.Tensor, is_minicpmv=False) -> None:
+    rotate_linear_input_(model.resampler.kv_proj if is_minicpmv else model.transformer.visual.attn_pool.kv_proj, Q)
+
+
+def rotate_attention_inputs(layer, Q, is_minicpmv=False) -> None:
+    att = layer.self_attn if is_minicpmv else layer.attn
+    for lin in (att.q_proj, att.k_proj, att.v_proj):
+        rotate_linear_input_(lin, Q)
+
+
+def rotate_cross_attention_inputs(layer, Q_q, Q_kv) -> None:
+    rotate_linear_input_(layer.attn.q_proj, Q_q)
+    rotate_linear_input_(layer.attn.k_proj, Q_kv)
+    rotate_linear_input_(layer.attn.v_proj, Q_kv)
+
+
+def rotate_cross_embeddings(model, Q_q, Q_kv, is_minicpmv=False):
+    pool = model.resampler if is_minicpmv else model.transformer.visual.attn_pool
+    rotate_vector_(pool.query, Q_q)
+    if not is_minicpmv:
+        rotate_vector_(pool.pos_embed, Q_q)
+    rotate_linear_output_(pool.kv_proj, Q_kv)
+    rotate_vector_(pool.pos_embed if is_minicpmv else pool.pos_embed_kv, Q_kv)
+
+
+def rotate_attention_output(layer, Q, is_visual=False) -> None:
+    att = _pick(layer, "attn", "self_attn")
+    rotate_linear_output_(_pick(att, "out_proj") if is_visual else _pick(att, "c_proj", "o_proj"), Q)
+
+
+def rotate_mlp_input(layer, Q, is_visual=False, is_minicpmv=False) -> None:
+    if is_visual:
+        targets = [_pick(layer.mlp, "c_fc", "fc1")]
+    else:
+        targets = [layer.mlp.up_proj, layer.mlp.gate_proj] if is_minicpmv else [layer.mlp.w1, layer.mlp.w2]
+    for lin in targets:
+        rotate_linear_input_(lin, Q)
+
+
+def rotate_mlp_output(layer, Q, online_hadamard=False):
+    out = _pick(layer.mlp, "c_proj", "down_proj", "fc2")
+    rotate_linear_output_(out, Q)               # weight and bias; the Hadamard below is input-side only
+    if online_hadamard:
+        apply_exact_had_to_linear(out, had_dim=-1, output=False)
+
+
+def rotate_ov_proj(layer, head_num, head_dim, is_visual=False, is_minicpmv=False):
+    att = _pick(layer, "attn", "self_attn")
+    v_proj = att.v_proj
+    if is_visual:
+        o_proj = att.out_proj
+        Qh = get_orthogonal_matrix(head_dim, mode="hadamard")
+        v_w, v_b = rotate_value_output_heads_(v_proj.weight.data, None if v_proj.bias is None else v_proj.bias.data,
+                                              o_proj, Qh, head_num, head_dim)
+        v_proj.weight.data = v_w
+        if v_b is not None:
+            v_proj.bias.data = v_b
+    else:
+        o_proj = att.o_proj if is_minicpmv else att.c_proj
+        apply_exact_had_to_linear(v_proj, had_dim=head_dim, output=True)
+        apply_exact_had_to_linear(o_proj, had_dim=head_dim, output=False)
+
+
+def rotate_o_ln_proj(layer, Q_o):
+    """Older layout: ``proj`` is a bare parameter and ln_post keeps its bias."""
+    rotate_linear_output_(layer.attn_pool.attn.out_proj, Q_o)
+    rotate_vector_(layer.ln_post.bias, Q_o)
+    layer.proj.data = (Q_o.to(layer.proj.device).double().T @ layer.proj.data.double()).to(layer.proj.data.dtype)
+
+
+def rotate_o_ln_proj_fc(layer, Q_o, is_minicpmv=False):
+    rotate_linear_output_((layer.attn if is_minicpmv else layer.attn_pool.attn).out_proj, Q_o)
+    rotate_linear_input_(layer.proj_fc, Q_o)
+
+
+@torch.inference_mode()
+def rotate_model(model, args):
+    """Qwen-VL (v1, "opt" layout) driver."""
+    print("rotate model")
+    vis = model.transformer.visual
+    vcfg = model.config.visual
+    if args.rotate_visual_clip:
+        heads = vcfg["heads"]
+        Q_v = get_orthogonal_matrix(vcfg["width"], args.rotate_mode)
+        for blk in tqdm.tqdm(vis.transformer.resblocks, unit="layer", desc="Rotating Visual CLIP"):
+            rotate_attention_inputs(blk, Q_v)
+            rotate_attention_output(blk, Q_v, is_visual=True)
+            rotate_mlp_input(blk, Q_v, is_visual=True)
+            rotate_mlp_output(blk, Q_v, args.online_visual_hadamard)
+            rotate_ov_proj(blk, heads, vcfg["width"] // heads, is_visual=True)
+        rotate_kv_proj(model, Q_v)
+        rotate_linear_output_(vis.fc_sub_mean, Q_v)      # the stream enters the ViT through it
+        utils.cleanup_memory()
+
+    if args.rotate_visual_cross_attn:
+        print("\n Rotating Visual Cross Attention \n")
+        pool = vis.attn_pool
+        Q_q = get_orthogonal_matrix(vcfg["output_dim"], args.rotate_mode)
+        Q_kv = get_orthogonal_matrix(vcfg["output_dim"], args.rotate_mode)
+        rotate_cross_embeddings(model, Q_q, Q_kv)
+        rotate_cross_attention_inputs(pool, Q_q, Q_kv)
+        rotate_ov_proj(pool, pool.num_heads, pool.embed_dim // pool.num_heads, is_visual=True)
+        Q_o = get_orthogonal_matrix(vcfg["output_dim"], args.rotate_mode)
+        rotate_o_ln_proj_fc(vis, Q_o)
+        utils.cleanup_memory()
+
+    if args.rotate_llm:
+        cfg = model.config
+        if args.online_llm_hadamard:
+            cfg.need_pad = False
+            from fake_quant.hadamard_utils import auto_pad_size
+            padded = auto_pad_size(cfg.intermediate_size)
+            if padded != cfg.intermediate_size:
+                pad_linear_inputs_(model.transformer.h, "mlp.c_proj", padded)
+                cfg.intermediate_size = padded
+                cfg.need_pad = True
+        Q = get_orthogonal_matrix(cfg.hidden_size, args.rotate_mode)
+        head_dim = cfg.hidden_size // cfg.num_attention_heads
+        rotate_embeddings(model, Q)
+        rotate_head(model, Q)
+        utils.cleanup_memory()
+        for layer in tqdm.tqdm(model.transformer.h, unit="layer", desc="Rotating"):
+            rotate_attention_inputs(layer, Q)
+            rotate_attention_output(layer, Q)
+            rotate_mlp_input(layer, Q)
+            rotate_mlp_output(layer, Q, args.online_llm_hadamard)
+            rotate_ov_proj(layer, cfg.num_attention_heads, head_dim)
+        utils.cleanup_memory()
 
 
 __all__ = [n for n in dir() if not n.startswith("_")] + ["module_util"]

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
     constexpr int STAGE_BYTES = PIECES * 1024;
     static_assert(BM % (WARPS_M * 16) == 0 && BN % (WARPS_N * 16) == 0, "tile shape");
     static_assert(PIECES % NWAVES == 0, "DMA pieces must divide evenly over the waves");
-    static_assert(STAGES == 2 || STAGES == 3, "ring depth");
+    static_assert(STAGES >= 2 && STAGES <= 8 && (STAGES - 2) * LPW < 64, "ring depth (vmcnt is 6 bits)");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -289,8 +289,9 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
     }
     const int bm = wid % m_blocks;
     const int rest = wid / m_blocks;
-    const int split = rest % p.splits;
-    const int bn = rest / p.splits;
+    const int n_blocks = total / (m_blocks * p.splits);
+    const int bn = rest % n_blocks;                // split-K: one XCD works on ONE k-slice, so its
+    const int split = rest / n_blocks;             // L2 holds that slice of A once for all its tiles
     const long m0 = (long)bm * BM;
     const long nt0 = (long)bn * (BN / 16);
 
@@ -353,10 +354,18 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
     int cur = 0;
     for (int it = 0; it < nk; ++it) {
         // stage `it` has landed when at most the (STAGES-2) younger stages are outstanding
-        if (STAGES == 3 && it + 1 < nk) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int younger = nk - 1 - it;
+        if (younger >= STAGES - 2) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPW) : "memory");
+        } else {                                    // drain: fewer stages behind this one
+            switch (younger) {
+            case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STAGES > 7 ? 5 * LPW : 0) : "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STAGES > 6 ? 4 * LPW : 0) : "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STAGES > 5 ? 3 * LPW : 0) : "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STAGES > 4 ? 2 * LPW : 0) : "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STAGES > 3 ? LPW : 0) : "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
         }
         __builtin_amdgcn_s_barrier();   // everyone's pieces landed; everyone left stage it-1
         const bool more = it + STAGES - 1 < nk;
@@ -474,8 +483,9 @@ __global__ __launch_bounds__(512) void gemm_w4a8_pipe_kernel(GemmArgs p)
     }
     const int bm = wid % m_blocks;
     const int rest = wid / m_blocks;
-    const int split = rest % p.splits;
-    const int bn = rest / p.splits;
+    const int n_blocks = total / (m_blocks * p.splits);
+    const int bn = rest % n_blocks;                // split-K: one XCD works on ONE k-slice, so its
+    const int split = rest / n_blocks;             // L2 holds that slice of A once for all its tiles
     const long m0 = (long)bm * BM;
     const long nt0 = (long)bn * (BN / 16);
 
@@ -707,6 +717,15 @@ static int dispatch_tile(const GemmArgs &p, int tile, hipStream_t st)
     case 10: return launch_gemm<64, 128, 2, 2, 3, W_BITS, EPI>(p, st);
     case 11: return launch_gemm<128, 64, 2, 2, 3, W_BITS, EPI>(p, st);
     case 12: return launch_gemm<128, 128, 4, 2, 3, W_BITS, EPI>(p, st);
+    case 16: return launch_gemm<64, 128, 2, 2, 4, W_BITS, EPI>(p, st);
+    case 17: return launch_gemm<64, 128, 2, 2, 5, W_BITS, EPI>(p, st);
+    case 18: return launch_gemm<64, 128, 2, 2, 6, W_BITS, EPI>(p, st);
+    case 19: return launch_gemm<64, 128, 2, 2, 8, W_BITS, EPI>(p, st);
+    case 20: return launch_gemm<128, 128, 4, 2, 4, W_BITS, EPI>(p, st);
+    case 21: return launch_gemm<128, 128, 4, 2, 6, W_BITS, EPI>(p, st);
+    case 22: return launch_gemm<128, 128, 2, 2, 5, W_BITS, EPI>(p, st);
+    case 23: return launch_gemm<64, 64, 2, 2, 8, W_BITS, EPI>(p, st);
+    case 24: return launch_gemm<128, 64, 2, 2, 6, W_BITS, EPI>(p, st);
     default: break;
     }
     return launch_gemm<128, 128, 2, 2, 3, W_BITS, EPI>(p, st);

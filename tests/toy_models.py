@@ -252,6 +252,142 @@ class ToyInternVL(nn.Module):
         return self.language_model.output(self.language_model.model.norm(h))
 
 
+# ------------------------------------------------------------------------------------ Qwen-VL (v1, "opt" layout)
+class MHA(nn.Module):
+    """q/k/v/out Linears as in visual_opt.VisualAttention after the q/k/v split."""
+    def __init__(self, dim, heads, out_name="out_proj", bias=True, out_bias=True):
+        super().__init__()
+        self.heads = heads
+        self.q_proj = nn.Linear(dim, dim, bias=bias)
+        self.k_proj = nn.Linear(dim, dim, bias=bias)
+        self.v_proj = nn.Linear(dim, dim, bias=bias)
+        setattr(self, out_name, nn.Linear(dim, dim, bias=out_bias))
+        self.out_name = out_name
+
+    def forward(self, q_in, k_in, v_in):
+        h = self.heads
+        q = self.q_proj(q_in).view(q_in.shape[0], h, -1)
+        k = self.k_proj(k_in).view(k_in.shape[0], h, -1)
+        v = self.v_proj(v_in).view(v_in.shape[0], h, -1)
+        return getattr(self, self.out_name)(_attend(q, k, v).reshape(q_in.shape[0], -1))
+
+
+class QwenVisMlp(nn.Module):
+    def __init__(self, dim, hidden, owner):
+        super().__init__()
+        self.c_fc = nn.Linear(dim, hidden)
+        self.c_proj = nn.Linear(hidden, dim)
+        self.owner = owner
+
+    def forward(self, x):
+        h = F.gelu(self.c_fc(x))
+        if self.owner[0].online_visual:
+            h = _had(h, self.c_proj.in_features)
+        return self.c_proj(h)
+
+
+class QwenVisBlock(nn.Module):
+    def __init__(self, dim, heads, hidden, owner):
+        super().__init__()
+        self.ln_1 = nn.LayerNorm(dim, eps=1e-6)
+        self.ln_2 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = MHA(dim, heads)
+        self.mlp = QwenVisMlp(dim, hidden, owner)
+
+    def forward(self, x):
+        y = self.ln_1(x)
+        x = x + self.attn(y, y, y)
+        return x + self.mlp(self.ln_2(x))
+
+
+class QwenResampler(nn.Module):
+    def __init__(self, width, dim, heads, queries, patches):
+        super().__init__()
+        self.embed_dim, self.num_heads = dim, heads
+        self.kv_proj = nn.Linear(width, dim, bias=False)
+        self.ln_kv = nn.LayerNorm(dim, eps=1e-6)
+        self.ln_q = nn.LayerNorm(dim, eps=1e-6)
+        self.query = nn.Parameter(torch.randn(queries, dim))
+        self.pos_embed = nn.Parameter(torch.randn(queries, dim))
+        self.pos_embed_kv = nn.Parameter(torch.randn(patches, dim))
+        self.attn = MHA(dim, heads)
+
+    def forward(self, x):
+        kv = self.ln_kv(self.kv_proj(x))
+        return self.attn(self.ln_q(self.query) + self.pos_embed, kv + self.pos_embed_kv, kv)
+
+
+class QwenV1Mlp(nn.Module):
+    def __init__(self, dim, inter, owner):
+        super().__init__()
+        self.w1 = nn.Linear(dim, inter, bias=False)
+        self.w2 = nn.Linear(dim, inter, bias=False)
+        self.c_proj = nn.Linear(inter, dim, bias=False)
+        self.owner = owner
+
+    def forward(self, x):
+        h = self.w1(x) * F.silu(self.w2(x))
+        if self.owner[0].online_llm:
+            h = _had(h, self.c_proj.in_features)
+        return self.c_proj(h)
+
+
+class QwenV1Block(nn.Module):
+    def __init__(self, dim, heads, inter, owner):
+        super().__init__()
+        self.ln_1 = RMSNorm(dim)
+        self.ln_2 = RMSNorm(dim)
+        self.attn = MHA(dim, heads, out_name="c_proj", bias=True, out_bias=False)
+        self.mlp = QwenV1Mlp(dim, inter, owner)
+
+    def forward(self, x):
+        y = self.ln_1(x)
+        x = x + self.attn(y, y, y)
+        return x + self.mlp(self.ln_2(x))
+
+
+class ToyQwenVL(nn.Module):
+    def __init__(self, width=32, vheads=2, vhidden=48, vdepth=2, dim=64, heads=4, inter=96, depth=2,
+                 vocab=50, patches=8, queries=4, patch_dim=24):
+        super().__init__()
+        self.online_visual = self.online_llm = False
+        owner = [self]
+        vis = nn.Module()
+        vis.conv1 = nn.Linear(patch_dim, width, bias=False)          # stands in for the patch conv
+        vis.positional_embedding = nn.Parameter(torch.randn(patches, width))
+        vis.ln_pre = nn.LayerNorm(width, eps=1e-6)
+        vis.fc_sub_mean = nn.Linear(width, width, bias=False)
+        vis.fc_sub_mean.weight.data = torch.eye(width) - 1.0 / width
+        vis.transformer = nn.Module()
+        vis.transformer.resblocks = nn.ModuleList(QwenVisBlock(width, vheads, vhidden, owner) for _ in range(vdepth))
+        vis.attn_pool = QwenResampler(width, dim, heads, queries, patches)
+        vis.ln_post = nn.LayerNorm(dim, eps=1e-6)
+        vis.proj_fc = nn.Linear(dim, dim, bias=True)
+        self.transformer = nn.Module()
+        self.transformer.visual = vis
+        self.transformer.wte = nn.Embedding(vocab, dim)
+        self.transformer.h = nn.ModuleList(QwenV1Block(dim, heads, inter, owner) for _ in range(depth))
+        self.transformer.ln_f = RMSNorm(dim)
+        self.lm_head = nn.Linear(dim, vocab, bias=False)
+        self.config = types.SimpleNamespace(visual=dict(heads=vheads, width=width, output_dim=dim), hidden_size=dim,
+                                            num_attention_heads=heads, intermediate_size=inter)
+        for p in self.parameters():
+            if p.dim() == 1:
+                p.data = torch.randn_like(p) * 0.3 + (1.0 if p.numel() in (width, dim) else 0.0)
+
+    def forward(self, pixels, ids):
+        """pixels [patches, patch_dim], ids [S] -> logits [queries + S, vocab]"""
+        v = self.transformer.visual
+        x = v.fc_sub_mean(v.ln_pre(v.conv1(pixels) + v.positional_embedding))
+        for blk in v.transformer.resblocks:
+            x = blk(x)
+        x = v.proj_fc(v.ln_post(v.attn_pool(x)))
+        h = torch.cat([x, self.transformer.wte(ids)], 0)
+        for layer in self.transformer.h:
+            h = layer(h)
+        return self.lm_head(self.transformer.ln_f(h))
+
+
 def rotation_args(**over):
     base = dict(no_fuse_visual_clip=False, no_fuse_visual_cross_attn=False, no_fuse_llm=False,
                 rotate_visual_clip=True, rotate_visual_cross_attn=True, rotate_llm=True,
@@ -262,10 +398,12 @@ def rotation_args(**over):
 
 def build(kind, seed, **kw):
     torch.manual_seed(seed)
-    model = (ToyQwen2VL if kind == "qwen2vl" else ToyInternVL)(**kw).double().eval()
+    model = {"qwen2vl": ToyQwen2VL, "internvl": ToyInternVL, "qwenvl": ToyQwenVL}[kind](**kw).double().eval()
     g = torch.Generator().manual_seed(seed + 1)
     if kind == "qwen2vl":
         pixels = torch.randn(8, *model.patch, generator=g, dtype=torch.float64)
+    elif kind == "qwenvl":
+        pixels = torch.randn(8, 24, generator=g, dtype=torch.float64)
     else:
         pixels = torch.randn(8, 3, 4, 4, generator=g, dtype=torch.float64)
     ids = torch.randint(0, 50, (5,), generator=g)
