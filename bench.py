@@ -66,6 +66,50 @@ def cpu_baseline(prefill_ops_total: float):
                       f"extrapolated by GEMM ops to the full 327-Linear prefill"}
 
 
+def full_prefill_report(pf, dev, args):
+    """TTFT of the WHOLE synthetic prefill -- the W4A8 Linears chained through
+    torch glue (RMS norm, RoPE, SDPA, activations, fp16 lm_head on the last position) -- one
+    hipGraph replay per sample, HIP events around each replay.  Secondary to ``value``."""
+    import torch
+    from mquant_amd import workload
+    from mquant_amd.full_prefill import FullPrefill
+    try:
+        fp = FullPrefill(pf)
+        fp.calibrate()
+        if args.no_graph:
+            run = fp.step
+        else:
+            fp.step()
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fp.step()
+            run = g.replay
+        for _ in range(20):
+            run()
+        torch.cuda.synchronize(dev)
+        times = []
+        for _ in range(max(args.ttft_iters, 5)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run()
+            e1.record()
+            e1.synchronize()
+            times.append(e0.elapsed_time(e1))
+        times.sort()
+        med = times[len(times) // 2]
+        p90 = times[min(len(times) - 1, int(round(0.9 * (len(times) - 1))))]
+        finite = bool(torch.isfinite(fp.logits.float()).all().item())
+        return {"what": "whole synthetic prefill: W4A8 Linears (this repo's kernels) + torch glue "
+                        "(RMS norm, RoPE, SDPA, GELU/SiLU, residuals, fp16 lm_head on the last position)",
+                "ttft_ms_median": round(med, 4), "ttft_ms_p90": round(p90, 4), "iters": len(times),
+                "llm_tokens_per_s": round(workload.M_LLM / (med * 1e-3), 1),
+                "all_tokens_per_s": round((workload.M_LLM + workload.M_VIS) / (med * 1e-3), 1),
+                "logits_finite": finite}
+    except Exception as exc:      # a report, never a reason to lose the bench line
+        return {"error": repr(exc)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,6 +119,9 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="small shapes (debug only; not a valid bench line)")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels one by one instead of replaying a hipGraph")
     ap.add_argument("--no-fuse", action="store_true", help="one GEMM per Linear (no q/k/v, gate/up fusion)")
+    ap.add_argument("--no-full-prefill", action="store_true",
+                    help="skip the secondary report: whole synthetic prefill incl. attention/norms (torch glue)")
+    ap.add_argument("--ttft-iters", type=int, default=100)
     args = ap.parse_args()
 
     import torch
@@ -194,6 +241,8 @@ def main():
                        "hip_graph": not args.no_graph,
                        "weights_GB": round(pf.weight_bytes() / 1e9, 3)},
             "roofline": roofline}
+    if not (args.tiny or args.no_full_prefill or args.no_fuse):
+        line["full_prefill"] = full_prefill_report(pf, dev, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             line["cpu_baseline"] = cpu_baseline(float(pf.gemm_ops()))

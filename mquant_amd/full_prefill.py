@@ -1,0 +1,109 @@
+"""Whole synthetic Qwen2-VL-7B prefill (SURVEY 8(d) "(ii) full synthetic prefill"): the W4A8
+Linears of ``workload.Prefill`` chained with the operators that sit between them in the model
+-- weight-less RMS norms (LayerNorms are fused away by the rotation pass), rotary embedding,
+PyTorch-ROCm SDPA, GELU / SiLU-gate, residual adds, fp16 ``lm_head`` on the last position
+(it is not wrapped: reference quant_utils.py:560-564).  Those glue operators are torch; only the
+Linears are this repository's kernels.  Used for the TTFT report in bench.py, never for parity.
+
+Static activation scales are re-calibrated on the chained activations (min/max observer kernels,
+one calibration pass) so that the int8 grids are the ones this dataflow would get.
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .workload import M_MERGED, M_TXT, M_VIS, Layer, Prefill
+
+VOCAB = 152064
+VIS_DIM, VIS_HEADS = 1280, 16
+LLM_DIM, LLM_HEADS, LLM_KV_HEADS, HEAD_DIM = 3584, 28, 4, 128
+
+
+def _rope_tables(rows: int, dim: int, device, dtype, base: float = 10000.0):
+    inv = 1.0 / (base ** (torch.arange(0, dim, 2, device=device, dtype=torch.float32) / dim))
+    ang = torch.arange(rows, device=device, dtype=torch.float32)[:, None] * inv[None, :]
+    ang = torch.cat([ang, ang], dim=-1)
+    return ang.cos().to(dtype)[:, None, :], ang.sin().to(dtype)[:, None, :]
+
+
+def _rope(x, cos, sin):
+    """x [T, heads, d]: rotate-half convention."""
+    h = x.shape[-1] // 2
+    rot = torch.cat([-x[..., h:], x[..., :h]], dim=-1)
+    return x * cos + rot * sin
+
+
+class FullPrefill:
+    def __init__(self, pf: Prefill, seed: int = 7):
+        assert pf.share_groups, "the chained prefill uses the fused q/k/v and gate/up GEMMs"
+        self.pf, self.dev, self.dtype = pf, pf.device, pf.dtype
+        by: Dict[str, List[Layer]] = {}
+        for L in pf.layers:
+            by.setdefault(getattr(L, "order_name", L.spec.name), []).append(L)
+        self.by = by
+        g = torch.Generator(device=self.dev).manual_seed(seed)
+        rnd = lambda *shape, std=1.0: (torch.randn(shape, generator=g, device=self.dev) * std).to(self.dtype)
+        self.patches = rnd(M_VIS, 1176)
+        self.text_embeds = rnd(M_TXT, LLM_DIM)
+        self.lm_head = rnd(VOCAB, LLM_DIM, std=0.02)
+        self.vcos, self.vsin = _rope_tables(M_VIS, VIS_DIM // VIS_HEADS, self.dev, self.dtype)
+        self.lcos, self.lsin = _rope_tables(M_MERGED + M_TXT, HEAD_DIM, self.dev, self.dtype, 1e6)
+        self.calibrating = False
+        self.logits = None
+
+    # -- one wrapped Linear (or fused group) -----------------------------------------------
+    def _lin(self, L: Layer, x: torch.Tensor) -> torch.Tensor:
+        if self.calibrating:
+            s0, s1 = self.pf._calibrate(x, L.spec, L.lin.had, L.row_sel)
+            L.lin.s_x0 = s0
+            if L.lin.s_x1 is not None:
+                L.lin.s_x1 = s1
+        return L.lin.forward(x, L.row_sel)
+
+    def calibrate(self):
+        self.calibrating = True
+        self.step()
+        self.calibrating = False
+        torch.cuda.synchronize(self.dev)
+
+    # -- the prefill -----------------------------------------------------------------------
+    def step(self) -> torch.Tensor:
+        by = self.by
+        # vision tower
+        x = self._lin(by["vis.patch_embed"][0], self.patches)
+        for i in range(len(by["vis.attn.qkv"])):
+            h = F.rms_norm(x, (VIS_DIM,), eps=1e-6)
+            q, k, v = self._lin(by["vis.attn.qkv"][i], h).view(M_VIS, 3, VIS_HEADS, -1).unbind(1)
+            q, k = _rope(q, self.vcos, self.vsin), _rope(k, self.vcos, self.vsin)
+            a = F.scaled_dot_product_attention(q.transpose(0, 1)[None], k.transpose(0, 1)[None],
+                                               v.transpose(0, 1)[None])[0]
+            x = x + self._lin(by["vis.attn.proj"][i], a.transpose(0, 1).reshape(M_VIS, VIS_DIM))
+            h = F.rms_norm(x, (VIS_DIM,), eps=1e-6)
+            f = F.gelu(self._lin(by["vis.mlp.fc1"][i], h), approximate="tanh")
+            x = x + self._lin(by["vis.mlp.fc2"][i], f)
+        m = F.rms_norm(x, (VIS_DIM,), eps=1e-6).view(M_MERGED, 4 * VIS_DIM)
+        m = self._lin(by["merger.mlp.2"][0], F.gelu(self._lin(by["merger.mlp.0"][0], m)))
+        # language model: [vision tokens | text tokens]
+        hdn = torch.cat([m, self.text_embeds], dim=0)
+        T = hdn.shape[0]
+        kv = LLM_KV_HEADS * HEAD_DIM
+        for i in range(len(by["llm.q_proj"])):
+            h = F.rms_norm(hdn, (LLM_DIM,), eps=1e-6)
+            qkv = self._lin(by["llm.q_proj"][i], h)                      # fused q|k|v GEMM
+            q = _rope(qkv[:, :LLM_DIM].view(T, LLM_HEADS, HEAD_DIM), self.lcos, self.lsin)
+            k = _rope(qkv[:, LLM_DIM:LLM_DIM + kv].view(T, LLM_KV_HEADS, HEAD_DIM), self.lcos, self.lsin)
+            v = qkv[:, LLM_DIM + kv:].view(T, LLM_KV_HEADS, HEAD_DIM)
+            a = F.scaled_dot_product_attention(q.transpose(0, 1)[None], k.transpose(0, 1)[None],
+                                               v.transpose(0, 1)[None], is_causal=True, enable_gqa=True)[0]
+            hdn = hdn + self._lin(by["llm.o_proj"][i], a.transpose(0, 1).reshape(T, LLM_DIM))
+            h = F.rms_norm(hdn, (LLM_DIM,), eps=1e-6)
+            gu = self._lin(by["llm.gate_proj"][i], h)                    # fused gate|up GEMM
+            half = gu.shape[1] // 2
+            hdn = hdn + self._lin(by["llm.down_proj"][i], F.silu(gu[:, :half]) * gu[:, half:])
+        last = F.rms_norm(hdn[-1:], (LLM_DIM,), eps=1e-6)
+        self.logits = last @ self.lm_head.t()
+        return self.logits
