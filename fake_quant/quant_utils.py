@@ -546,12 +546,23 @@ class WeightQuantizer(torch.nn.Module):
             return sym_quant_dequant(x, scale, self.maxq)
         return asym_quant_dequant(x, scale, zero, self.maxq)
 
+    #: CUDA tensors, symmetric + per-channel: one launch of ``mq_wquant_sym`` (same arithmetic,
+    #: errors of the clip search summed in ascending k) instead of ~10 torch kernels per candidate
+    use_kernel = True
+
     def find_params(self, x):
         if self.bits == 16:
             return
         dev = x.device
         self.maxq = self.maxq.to(dev)
         shape = x.shape
+        if self.use_kernel and x.is_cuda and self.sym and self.perchannel and 2 <= self.bits <= 8:
+            from mquant_amd import ops
+            scale = ops.wquant_sym(x.flatten(1), self.bits, self.mse, self.norm, self.grid, self.maxshrink,
+                                   want_levels=False)[0]
+            self.scale = scale.reshape([-1] + [1] * (len(shape) - 1))
+            self.zero = torch.zeros_like(self.scale)
+            return
         rows = x.flatten(1) if self.perchannel else x.flatten().unsqueeze(0)
         z = torch.zeros(rows.shape[0], device=dev)
         xmin = torch.minimum(rows.min(1)[0], z)

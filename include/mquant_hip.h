@@ -134,6 +134,25 @@ int mq_prepack_w8(const int8_t *q, long N, long K, int zero_col0, int8_t *out, v
 size_t mq_prepacked_bytes(long N, long K, int w_bits);
 
 /* ---------------------------------------------------------------------------
+ * Weight quantizer on the device (offline weight pipeline).
+ * Replaces WeightQuantizer.find_params + WeightQuantizer.quantize for the symmetric
+ * per-output-channel case, quant_utils.py:446-518 (sym_quant_dequant :46-58):
+ *   xmax[n]  = max(|min(min_k w, 0)|, max(max_k w, 0)) clamped to >= 1e-5
+ *   scale[n] = xmax / maxq,  maxq = 2^(bits-1) - 1
+ *   mse != 0: clip search over p = 1 - i/grid, i < (int)(maxshrink*grid):
+ *             err_i = sum_k |s_i*q - w|^norm (fp32, ascending k), first strict minimum wins
+ *   q[n][k]  = clamp(rint(w/scale[n]), -(maxq+1), maxq)
+ * All arithmetic is fp32 on the exactly converted weights for EVERY w_dtype (the reference
+ * promotes half tensors through the fp32 `tmp` of :458-460).  Optional outputs (NULL = skip):
+ *   levels  int8 [N, K]
+ *   packed  uint8 [N, K/2], the reference pack_i4 wire format (:61-69); bits == 4, K even
+ *   wq      fake-quantized weights scale*q cast to w_dtype, [N, ldq] (what quantize() returns)
+ * ------------------------------------------------------------------------- */
+int mq_wquant_sym(const void *w, int w_dtype, long N, long K, long ldw, int bits, int mse,
+                  float norm, int grid, float maxshrink, float *scale, int8_t *levels,
+                  uint8_t *packed, void *wq, long ldq, void *stream);
+
+/* ---------------------------------------------------------------------------
  * Quantized Linear: int8 activations x int4/int8 weights -> int32 -> dequant.
  * Replaces F.linear on fake-quantized tensors, quant_utils.py:384 (and the fp32
  * L1/L2 pair of :374-376 when x0/w0 are given), with

@@ -76,6 +76,20 @@ class W4A8Linear:
         if had is not None:
             assert had.n == self.K, "Hadamard size must equal the (padded) reduction dim"
 
+    @classmethod
+    def from_float(cls, w: torch.Tensor, w_bits: int, s_x0: float, s_x1: Optional[float] = None,
+                   bias: Optional[torch.Tensor] = None, mse: bool = False, had: Optional[HadamardSpec] = None,
+                   split: bool = False, in_features: Optional[int] = None) -> "W4A8Linear":
+        """Quantize floating-point weights on the device (``mq_wquant_sym``: RTN or MSE clip search,
+        reference quant_utils.py:446-518) and freeze.  ``split`` keeps column 0 in fp32 (``w0``)."""
+        w2 = w.reshape(w.shape[0], -1)
+        w0 = w2[:, 0].float() if split else None
+        src = w2[:, 1:] if split else w2          # reference: L2 holds columns 1.., quantized on its own
+        scale, levels, _, _ = ops.wquant_sym(src, w_bits, mse)
+        if split:
+            levels = torch.cat([torch.zeros_like(levels[:, :1]), levels], dim=1)
+        return cls(levels, scale, w_bits, bias, s_x0, s_x1, had=had, w0=w0, in_features=in_features)
+
     # -- the two launches, exposed separately so callers can share one quantization ----
     def quantize(self, x2: torch.Tensor, row_sel: Optional[torch.Tensor] = None):
         M = x2.shape[0]

@@ -155,6 +155,27 @@ def weight_levels(w: torch.Tensor, scale: torch.Tensor, bits: int) -> torch.Tens
     return q
 
 
+def wquant_sym(w: torch.Tensor, bits: int = 4, mse: bool = False, norm: float = 2.4, grid: int = 100,
+               maxshrink: float = 0.8, want_levels: bool = True, want_packed: bool = False,
+               want_wq: bool = False):
+    """Symmetric per-output-channel weight quantizer in one launch (``mq_wquant_sym``).
+    Returns (scale fp32 [N], levels int8 [N, K] | None, packed uint8 [N, K/2] | None, W~ | None)."""
+    _need_cuda(w)
+    w2 = w.reshape(w.shape[0], -1)
+    if w2.stride(-1) != 1:
+        w2 = w2.contiguous()
+    N, K = w2.shape
+    dev = w.device
+    scale = torch.empty((N,), dtype=torch.float32, device=dev)
+    levels = torch.empty((N, K), dtype=torch.int8, device=dev) if want_levels else None
+    packed = torch.empty((N, K // 2), dtype=torch.uint8, device=dev) if want_packed else None
+    wq = torch.empty((N, K), dtype=w.dtype, device=dev) if want_wq else None
+    call("mq_wquant_sym", w2.data_ptr(), dtype_code(w2.dtype), N, K, w2.stride(0), bits, int(mse), float(norm),
+         int(grid), float(maxshrink), scale.data_ptr(), levels.data_ptr() if want_levels else None,
+         packed.data_ptr() if want_packed else None, wq.data_ptr() if want_wq else None, K, _stream())
+    return scale, levels, packed, (wq.reshape(w.shape) if want_wq else None)
+
+
 def prepack(q: torch.Tensor, bits: int, zero_col0: bool = False) -> torch.Tensor:
     """int levels [N, K] -> the pre-tiled image streamed by gemm_w4a8."""
     _need_cuda(q)

@@ -74,14 +74,10 @@ def load_had_bits(K: int, device) -> Optional[torch.Tensor]:
 
 
 def rtn_levels(w: torch.Tensor, bits: int = 4):
-    """Symmetric per-output-channel RTN (reference quant_utils.py:446-518, mse off),
-    evaluated with torch ops on the device: offline preparation, not the timed path."""
-    maxq = (1 << (bits - 1)) - 1
-    wf = w.float()
-    xmax = torch.maximum(wf.amin(1).clamp(max=0).abs(), wf.amax(1).clamp(min=0)).clamp(min=1e-5)
-    scale = xmax / maxq
-    q = torch.clamp(torch.round(wf / scale[:, None]), -(maxq + 1), maxq).to(torch.int8)
-    return q, scale
+    """Symmetric per-output-channel RTN (reference quant_utils.py:446-518, mse off) in one launch
+    of ``mq_wquant_sym``: offline preparation, not the timed path."""
+    scale, levels, _, _ = ops.wquant_sym(w, bits)
+    return levels, scale
 
 
 def minmax_scale(mn: float, mx: float) -> float:

@@ -192,6 +192,11 @@ def linear_fakequant_f32(x, s_x, w_dq, bias=None) -> np.ndarray:
     return out
 
 
+def pow_pos(d, norm):
+    lib().orc_pow_pos.restype = C.c_float
+    return np.float32(lib().orc_pow_pos(C.c_float(d), C.c_float(norm)))
+
+
 def wquant_sym(w, bits=4, mse=False, norm=2.4, grid=100, maxshrink=0.8, want_levels=True):
     w = _f32(w)
     N, K = w.shape

@@ -306,6 +306,60 @@ void orc_linear_fakequant_f32(const float *x, long M, long K,
 /*   err = sum |q - x|^norm; keep the best.                             */
 /*   levels = clamp(round(x/s), -(maxq+1), maxq)  (quant_utils.py:42-45)*/
 /* ------------------------------------------------------------------ */
+/* d^norm for d >= 0, evaluated in double with explicitly ordered +,*,/ only (no libm
+ * transcendental, no contraction), then rounded once to fp32.  The reference calls torch's
+ * fp32 pow (quant_utils.py:490), whose last bit depends on the vector math library in use;
+ * this form is within 1 ulp(fp32) of it and, being plain IEEE arithmetic, is reproduced bit for
+ * bit by the device kernel (mquant_amd/csrc/wquant.hip carries its own copy). */
+static inline double orc_log2_pos(double x)
+{
+    int e;
+    double m = frexp(x, &e);                       /* x = m * 2^e, m in [0.5, 1) */
+    if (m < 0.70710678118654752440) { m = m * 2.0; e -= 1; }
+    const double f = (m - 1.0) / (m + 1.0);        /* |f| <= 0.1716 */
+    const double f2 = f * f;
+    double t = 1.0 / 23.0;                         /* atanh series: ln m = 2 f (1 + f^2/3 + ...) */
+    t = t * f2 + 1.0 / 21.0;
+    t = t * f2 + 1.0 / 19.0;
+    t = t * f2 + 1.0 / 17.0;
+    t = t * f2 + 1.0 / 15.0;
+    t = t * f2 + 1.0 / 13.0;
+    t = t * f2 + 1.0 / 11.0;
+    t = t * f2 + 1.0 / 9.0;
+    t = t * f2 + 1.0 / 7.0;
+    t = t * f2 + 1.0 / 5.0;
+    t = t * f2 + 1.0 / 3.0;
+    t = t * f2 + 1.0;
+    return (double)e + (2.0 * f) * t * 1.44269504088896340736;
+}
+
+static inline double orc_exp2(double y)
+{
+    const double yi = floor(y + 0.5);
+    const double r = (y - yi) * 0.69314718055994530942;   /* |r| <= 0.3466 */
+    double t = 1.0 / 6227020800.0;                 /* Taylor of e^r to r^13 */
+    t = t * r + 1.0 / 479001600.0;
+    t = t * r + 1.0 / 39916800.0;
+    t = t * r + 1.0 / 3628800.0;
+    t = t * r + 1.0 / 362880.0;
+    t = t * r + 1.0 / 40320.0;
+    t = t * r + 1.0 / 5040.0;
+    t = t * r + 1.0 / 720.0;
+    t = t * r + 1.0 / 120.0;
+    t = t * r + 1.0 / 24.0;
+    t = t * r + 1.0 / 6.0;
+    t = t * r + 0.5;
+    t = t * r + 1.0;
+    t = t * r + 1.0;
+    return ldexp(t, (int)yi);
+}
+
+float orc_pow_pos(float d, float norm)
+{
+    if (d == 0.0f) return 0.0f;
+    return (float)orc_exp2((double)norm * orc_log2_pos((double)d));
+}
+
 void orc_wquant_sym(const float *w, long N, long K, int bits, int mse,
                     float norm, int grid, float maxshrink,
                     float *scale, int8_t *levels)
@@ -332,7 +386,7 @@ void orc_wquant_sym(const float *w, long N, long K, int bits, int mse,
                     if (q < -(maxq + 1.0f)) q = -(maxq + 1.0f);
                     if (q > maxq) q = maxq;
                     float d = fabsf(s1 * q - r[k]);
-                    err += powf(d, norm);
+                    err += orc_pow_pos(d, norm);
                 }
                 if (err < best) { best = err; s = s1; }
             }

@@ -27,3 +27,12 @@ def make_ties(scale, levels):
     """Exact x = (k + 0.5) * scale values: round-half-even probes."""
     k = np.asarray(levels, dtype=np.float32)
     return ((k + np.float32(0.5)) * np.float32(scale)).astype(np.float32)
+
+
+def make_wquant_weights(seed, N=40, K=768):
+    """Input of the wquant_* goldens (tools/gen_golden_wquant.py): fp32 before the dtype cast."""
+    w = make_w(seed, (N, K))
+    w[3] = 0.0
+    w[5, 7] = 0.9
+    w[6] *= 40.0
+    return w

@@ -169,3 +169,30 @@ def test_wrapper_forward_integer_restatement(golden_dir, had_table, case):
                         x0=rot[:, 0] if split else None, w0=W[:, 0] if split else None)
     np.testing.assert_allclose(y, g["y"], rtol=0, atol=1e-3)
     assert np.abs(y - g["y"]).max() < 1e-4 * max(1.0, np.abs(g["y"]).max())
+
+
+WQUANT_CASES = ["f32_4b_rtn", "f32_4b_mse", "f32_8b_rtn", "f32_8b_mse", "f16_4b_rtn", "f16_4b_mse",
+                "bf16_4b_rtn", "bf16_4b_mse", "f16_8b_rtn"]
+
+
+def wquant_case(golden_dir, case):
+    """(golden, fp32 view of the weights in the case's dtype, rounding mode of that dtype)."""
+    from golden_inputs import make_wquant_weights
+    g = np.load(os.path.join(golden_dir, f"wquant_{case}.npz"))
+    seed, bits, mse = [int(v) for v in g["meta"]]
+    mode = {"f32": 0, "f16": 1, "bf16": 2}[case.split("_")[0]]
+    w = oracle.round_to(make_wquant_weights(seed), mode)
+    return g, w, mode, bits, bool(mse)
+
+
+@pytest.mark.parametrize("case", WQUANT_CASES)
+def test_weight_quantizer_on_every_weight_dtype(golden_dir, case):
+    """quant_utils.py:446-518 on fp32 / fp16 / bf16 weights: half weights are promoted by the fp32
+    ``tmp`` tensor (:458-460), so scales and errors are fp32 and only W~ is cast back."""
+    g, w, mode, bits, mse = wquant_case(golden_dir, case)
+    scale, levels = oracle.wquant_sym(w, bits=bits, mse=mse)
+    np.testing.assert_array_equal(scale, g["scale"])
+    wq = oracle.round_to(scale[:, None] * levels.astype(np.float32), mode)
+    np.testing.assert_array_equal(wq, g["wq"])
+    if mse:
+        assert (scale < oracle.wquant_sym(w, bits=bits, mse=False)[0]).sum() >= 2      # the search does clip
