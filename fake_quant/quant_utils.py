@@ -320,11 +320,13 @@ class ActQuantWrapper(torch.nn.Module):
         self.weight_quantizers = {}     # sub-module name ("module" / "L2") -> WeightQuantizer
         self.pad_to = None              # folded revise_down_input hook
         self._real = None
+        self._real_frozen = False       # engine installed from a flat checkpoint (no float weights)
 
     # pickled checkpoints must not drag device handles along
     def __getstate__(self):
         state = self.__dict__.copy()
         state["_real"] = None
+        state["_real_frozen"] = False
         return state
 
     def extra_repr(self) -> str:
@@ -362,13 +364,23 @@ class ActQuantWrapper(torch.nn.Module):
 
     # ------------------------------------------------------------------ real-integer backend
     def invalidate_real(self):
-        self._real = None
+        if not getattr(self, "_real_frozen", False):
+            self._real = None
+
+    def install_real(self, engine) -> None:
+        """Adopt an engine rebuilt from a flat checkpoint (mquant_amd.checkpoint.load_quantized):
+        from now on ``forward`` runs it whatever the calibration flags or float weights say."""
+        self._real = engine
+        self._real_frozen = True
+        self.quantizer.msq = engine.s_x1 is not None
 
     def _weight_module(self):
         return ("L2", self.L2) if self.split else ("module", self.module)
 
     def _real_ready(self, x) -> bool:
         qz = self.quantizer
+        if getattr(self, "_real_frozen", False) and self._real is not None:
+            return self.real_quant
         if not (self.real_quant and qz.static and qz.quant and not qz.calibrate):
             return False
         if qz.bits != 8 or self.out_quantizer.bits < 16 or self.online_partial_had:

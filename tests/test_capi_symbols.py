@@ -60,3 +60,15 @@ def test_cpu_tensors_are_rejected_by_every_op():
                lambda: ops.gemm_w4a8_i32(torch.zeros(4, 128, dtype=torch.int8), torch.zeros(1024, dtype=torch.uint8), 4, 16)):
         with pytest.raises(MQuantHipError):
             fn()
+
+
+def test_checkpoint_record_helpers_need_no_gpu():
+    import torch
+    from mquant_amd import checkpoint
+    meta = checkpoint._meta(version=1, w_bits=4, a_bits=8, N=16, K=64, in_features=64, had_K=12, split=1)
+    assert checkpoint.read_meta(meta)["had_K"] == 12 and checkpoint.read_meta(meta)["msq"] == 0
+    tensors = {"model.layers.0.mlp.down_proj.qweight": torch.zeros((16, 32), dtype=torch.uint8),
+               "model.layers.0.mlp.down_proj.meta": meta, "model.norm.weight": torch.ones(4)}
+    recs = checkpoint.split_records(tensors)
+    assert list(recs) == ["model.layers.0.mlp.down_proj"] and set(recs["model.layers.0.mlp.down_proj"]) == {"qweight", "meta"}
+    assert checkpoint.split_records(tensors, prefix="model.") .keys() == {"layers.0.mlp.down_proj"}
