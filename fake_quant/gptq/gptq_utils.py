@@ -22,10 +22,17 @@ class GPTQ:
 
     def add_batch(self, inp, out=None):
         """Running mean of 2 x x^T over every token seen so far."""
-        if inp.dim() == 2:
-            inp = inp.unsqueeze(0)
-        batch = inp.shape[0]
-        x = inp.reshape(-1, inp.shape[-1]).t().float()
+        if isinstance(self.layer, (torch.nn.Conv2d, torch.nn.Conv3d)):
+            # patch embedding: kernel == stride == the whole patch, so unfolding is a reshape
+            # (reference GPTQConv.add_batch, gptq_utils.py:49-60, through nn.Unfold / UnfoldNd)
+            assert tuple(inp.shape[2:]) == tuple(self.layer.kernel_size), "only whole-patch convolutions"
+            batch = inp.shape[0]
+            x = inp.reshape(batch, -1).t().float()
+        else:
+            if inp.dim() == 2:
+                inp = inp.unsqueeze(0)
+            batch = inp.shape[0]
+            x = inp.reshape(-1, inp.shape[-1]).t().float()
         self.H *= self.nsamples / (self.nsamples + batch)
         self.nsamples += batch
         x = math.sqrt(2 / self.nsamples) * x
@@ -33,7 +40,7 @@ class GPTQ:
 
     def fasterquant(self, blocksize=128, percdamp=0.01, groupsize=-1, actorder=False,
                     static_groups=False):
-        W = self.layer.weight.data.clone().float()
+        W = self.layer.weight.data.clone().flatten(1).float()
         if not self.quantizer.ready():
             self.quantizer.find_params(W)
         H = self.H

@@ -1,0 +1,168 @@
+"""GPTQ solver (fake_quant/gptq/gptq_utils.py) against the reference's GPTQ / GPTQConv outputs
+(tests/golden/gptq_*.npz from tools/gen_golden_gptq.py), and the layer-sequential driver on toy
+models."""
+import os
+import sys
+import types
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from golden_inputs import make_w, make_x
+
+torch.set_grad_enabled(False)
+CASES = ["plain", "actorder", "groups", "mse_w8", "wide", "conv2d"]
+
+
+def build(kind, n_out, n_in, seed):
+    if kind == "linear":
+        layer = torch.nn.Linear(n_in, n_out, bias=False)
+        layer.weight.data = torch.from_numpy(make_w(seed, (n_out, n_in))) * 4.0
+        xs = [torch.from_numpy(make_x(seed + 1 + i, (2 * 10, n_in))).reshape(2, 10, n_in) for i in range(3)]
+    else:
+        layer = torch.nn.Conv2d(3, n_out, kernel_size=4, stride=4, bias=False)
+        layer.weight.data = (torch.from_numpy(make_w(seed, (n_out, n_in))) * 4.0).reshape(n_out, 3, 4, 4)
+        xs = [torch.from_numpy(make_x(seed + 1 + i, (12, n_in))).reshape(12, 3, 4, 4) for i in range(3)]
+    return layer, xs
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_solver_matches_reference(golden_dir, case):
+    from fake_quant import quant_utils as qu
+    from fake_quant.gptq.gptq_utils import GPTQ
+    g = np.load(os.path.join(golden_dir, f"gptq_{case}.npz"))
+    seed, n_out, n_in, bits, mse, actorder, groupsize = [int(v) for v in g["meta"]]
+    layer, xs = build("conv" if case == "conv2d" else "linear", n_out, n_in, seed)
+    w_before = layer.weight.data.clone()
+    solver = GPTQ(layer)
+    solver.quantizer = qu.WeightQuantizer()
+    solver.quantizer.configure(bits, perchannel=True, sym=True, mse=bool(mse))
+    for x in xs:
+        solver.add_batch(x, layer(x))
+    if g["H"].size:
+        np.testing.assert_array_equal(solver.H.numpy(), g["H"])
+    solver.fasterquant(percdamp=0.01, groupsize=groupsize, actorder=bool(actorder), static_groups=False)
+    np.testing.assert_array_equal(solver.quantizer.scale.reshape(-1).numpy(), g["scale"])
+    np.testing.assert_array_equal(layer.weight.data.reshape(n_out, -1).numpy(), g["Q"])
+    assert layer.weight.shape == w_before.shape
+    if groupsize == -1:                                            # on the int grid of its scale
+        lv = layer.weight.data.reshape(n_out, -1).numpy() / g["scale"][:, None]
+        np.testing.assert_allclose(lv, np.rint(lv), atol=1e-4)
+    # the point of GPTQ: smaller output error than plain rounding on the calibration inputs
+    rtn = qu.WeightQuantizer()
+    rtn.configure(bits, perchannel=True, sym=True, mse=bool(mse))
+    rtn.find_params(w_before)
+    x = torch.cat([t.reshape(-1, n_in) for t in xs])
+    def out_err(w):
+        return float(((x @ (w.reshape(n_out, -1) - w_before.reshape(n_out, -1)).T) ** 2).sum())
+    assert out_err(layer.weight.data) < out_err(rtn.quantize(w_before))
+
+
+# ------------------------------------------------------------------------------------ drivers
+class ToyVlm:
+    """VLMEvalKit-style wrapper around a toy HF module: .model, .generate(message=, dataset=)."""
+
+    def __init__(self, kind, seed=5):
+        import toy_models
+        self.kind = kind
+        self.model, self.pixels, self.ids = toy_models.build(kind, seed)
+        self.model = self.model.float()
+        self.pixels = self.pixels.float()
+        self.calls = 0
+
+    def generate(self, message, dataset):
+        self.calls += 1
+        g = torch.Generator().manual_seed(int(message))
+        return self.model(self.pixels + 0.1 * torch.randn(self.pixels.shape, generator=g), self.ids)
+
+
+class ToyDataset:
+    def __init__(self, n):
+        self.data = pd.DataFrame({"v": list(range(n))})
+
+    def build_prompt(self, record):
+        return int(record["v"])
+
+
+def gptq_args(**over):
+    base = dict(quant_llm=True, quant_visual_clip=True, quant_cross_attention=True, act_per_tensor=False,
+                visual_w_rtn=False, llm_w_rtn=False, visual_w_bits=4, llm_w_bits=4, w_asym=False,
+                visual_w_clip=False, llm_w_clip=False, visual_split=False, llm_split=False, nsamples=3,
+                percdamp=0.01, w_groupsize=-1, act_order=False, skip_names=[], dataset_name="toy")
+    base.update(over)
+    return types.SimpleNamespace(**base)
+
+
+def _on_grid(weight, quantizer):
+    lv = weight.reshape(weight.shape[0], -1) / quantizer.scale.reshape(-1, 1).to(weight.dtype)
+    return bool(torch.allclose(lv, torch.round(lv), atol=1e-3))
+
+
+@pytest.mark.parametrize("kind", ["qwen2vl", "internvl"])
+def test_layer_sequential_gptq_driver(kind):
+    from fake_quant import quant_utils as qu
+    from fake_quant.gptq import internvl_gptq_plus, qwen2vl_gptq_plus
+    vlm = ToyVlm(kind)
+    args = gptq_args()
+    ref_out = vlm.generate(0, "toy")
+    (qu.qwen2vl_add_act_qaunt if kind == "qwen2vl" else qu.internvl_add_act_qaunt)(vlm, args)
+    driver = (qwen2vl_gptq_plus.qwen2vl_rtn_gptq_fwrd_plus if kind == "qwen2vl"
+              else internvl_gptq_plus.internvl_rtn_gptq_fwrd_plus)
+    quantizers = driver(vlm, ToyDataset(8), "cpu", "toy", args)
+    wrappers = qu.find_qlayers(vlm.model, [qu.ActQuantWrapper])
+    # every wrapped layer got its quantizer under the upstream key, weights sit on the int4 grid,
+    # and the wrapper knows its quantizer (what the real W4A8 path needs)
+    if kind == "qwen2vl":
+        expect = {"model.visual.patch_embed.proj.module", "model.visual.blocks.1.mlp.fc2.module",
+                  "model.visual.merger.mlp.2.module", "model.model.layers.0.self_attn.k_proj.module",
+                  "model.model.layers.1.mlp.down_proj.module"}
+    else:
+        expect = {"model.vision_model.embeddings.patch_embedding", "model.vision_model.encoder.layers.0.attn.qkv.module",
+                  "model.mlp1.3.module", "model.language_model.model.layers.1.attention.wqkv.module",
+                  "model.language_model.model.layers.0.feed_forward.w2.module"}
+    assert expect <= set(quantizers), sorted(quantizers)
+    assert len(quantizers) == len(wrappers)
+    for name, w in wrappers.items():
+        assert "module" in w.weight_quantizers, name
+        assert _on_grid(w.module.weight.data, w.weight_quantizers["module"]), name
+    # forwards were aborted at the captured module: no full generate after the captures finished,
+    # and the catcher is gone
+    out = vlm.generate(0, "toy")
+    assert torch.isfinite(out).all()
+    rel = float((out - ref_out).norm() / ref_out.norm())
+    assert rel < 0.5, rel
+
+
+def test_gptq_beats_rtn_on_block_outputs_and_respects_split():
+    """One toy tower: the error of the final logits is smaller with GPTQ than with RTN, and with
+    --llm_split the solver works on ``down_proj.L2`` (column 0 stays in L1)."""
+    from fake_quant import quant_utils as qu
+    from fake_quant.gptq import qwen2vl_gptq_plus
+    errs = {}
+    for rtn in (True, False):
+        vlm = ToyVlm("qwen2vl", seed=9)
+        want = vlm.generate(3, "toy")
+        args = gptq_args(quant_visual_clip=False, quant_cross_attention=False, llm_w_rtn=rtn, llm_split=not rtn,
+                         nsamples=6)
+        qu.qwen2vl_add_act_qaunt(vlm, args)
+        if not rtn:
+            for layer in vlm.model.model.layers:
+                layer.mlp.down_proj.split = True
+                layer.mlp.down_proj.split_weights()
+        q = qwen2vl_gptq_plus.qwen2vl_rtn_gptq_fwrd_plus(vlm, ToyDataset(8), "cpu", "toy", args)
+        if not rtn:
+            assert "model.model.layers.0.mlp.down_proj.L2" in q and "L2" in vlm.model.model.layers[0].mlp.down_proj.weight_quantizers
+        errs[rtn] = float((vlm.generate(3, "toy") - want).norm())
+    assert errs[False] < errs[True], errs
+
+
+def test_capture_restores_the_module_and_stops_early():
+    from fake_quant.gptq import sequential as seq
+    vlm = ToyVlm("qwen2vl")
+    target = vlm.model.model.layers[0]
+    args = gptq_args()
+    samples = seq.capture_inputs(target, lambda enough: seq.run_calibration_prompts(vlm, ToyDataset(8), "toy", args, enough), 2)
+    assert len(samples) == 2 and vlm.calls == 2 and "forward" not in target.__dict__
+    assert samples[0][0][0].shape == (7, 64)

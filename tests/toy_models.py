@@ -121,6 +121,26 @@ class QwenLlmLayer(nn.Module):
         return x + self.mlp(self.post_attention_layernorm(x))
 
 
+class QwenPatchEmbed(nn.Module):
+    def __init__(self, patch, vdim):
+        super().__init__()
+        self.proj = nn.Conv3d(patch[0], vdim, kernel_size=patch[1:], stride=patch[1:], bias=False)
+        self.embed_dim = vdim
+
+    def forward(self, pixels):
+        return self.proj(pixels).view(pixels.shape[0], -1)
+
+
+class QwenMerger(nn.Module):
+    def __init__(self, vdim, dim):
+        super().__init__()
+        self.ln_q = nn.LayerNorm(vdim, eps=1e-6)
+        self.mlp = nn.Sequential(nn.Linear(4 * vdim, 4 * vdim), nn.GELU(), nn.Linear(4 * vdim, dim))
+
+    def forward(self, x):
+        return self.mlp(self.ln_q(x).view(-1, 4 * x.shape[-1]))
+
+
 class ToyQwen2VL(nn.Module):
     def __init__(self, vdim=32, vheads=2, vhidden=48, vdepth=2, dim=64, heads=4, kv_heads=2, inter=96,
                  depth=2, vocab=50, patch=(3, 2, 4, 4)):
@@ -128,13 +148,9 @@ class ToyQwen2VL(nn.Module):
         self.online_visual = self.online_llm = False
         owner = [self]
         vis = nn.Module()
-        vis.patch_embed = nn.Module()
-        vis.patch_embed.proj = nn.Conv3d(patch[0], vdim, kernel_size=patch[1:], stride=patch[1:], bias=False)
-        vis.patch_embed.embed_dim = vdim
+        vis.patch_embed = QwenPatchEmbed(patch, vdim)
         vis.blocks = nn.ModuleList(VisBlock(vdim, vheads, vhidden, owner) for _ in range(vdepth))
-        vis.merger = nn.Module()
-        vis.merger.ln_q = nn.LayerNorm(vdim, eps=1e-6)
-        vis.merger.mlp = nn.Sequential(nn.Linear(4 * vdim, 4 * vdim), nn.GELU(), nn.Linear(4 * vdim, dim))
+        vis.merger = QwenMerger(vdim, dim)
         self.visual = vis
         self.model = nn.Module()
         self.model.embed_tokens = nn.Embedding(vocab, dim)
@@ -151,10 +167,10 @@ class ToyQwen2VL(nn.Module):
     def forward(self, pixels, ids):
         """pixels [P, C, T, H, W] (P % 4 == 0), ids [S] -> logits [P/4 + S, vocab]"""
         v = self.visual
-        x = v.patch_embed.proj(pixels).view(pixels.shape[0], -1)
+        x = v.patch_embed(pixels)
         for blk in v.blocks:
             x = blk(x)
-        x = v.merger.mlp(v.merger.ln_q(x).view(-1, 4 * x.shape[-1]))
+        x = v.merger(x)
         h = torch.cat([x, self.model.embed_tokens(ids)], 0)
         for layer in self.model.layers:
             h = layer(h)
