@@ -12,6 +12,9 @@ torch.backends.cudnn.allow_tf32 = False
 
 
 class GPTQ:
+    #: CUDA weights + symmetric per-channel quantizer without groups: column loop in one HIP launch
+    use_kernel = True
+
     def __init__(self, layer):
         self.layer = layer
         self.dev = layer.weight.device
@@ -70,7 +73,23 @@ class GPTQ:
             self.layer.weight.data = self.quantizer.quantize(W if perm is None else W[:, invperm]).to(
                 self.layer.weight.data.dtype)
             return
-        for i1 in range(0, self.columns, blocksize):
+        qz = self.quantizer
+        fused = (self.use_kernel and W.is_cuda and groupsize == -1 and blocksize <= 128 and qz.sym
+                 and getattr(qz, "perchannel", False) and 2 <= qz.bits <= 8)
+        if fused:
+            # the per-column loop as ONE launch per block (mq_gptq_block, same operation order)
+            from mquant_amd import ops
+            scale = qz.scale.reshape(-1).to(device=W.device, dtype=torch.float32).contiguous()
+            W = W.contiguous()
+            Hrows = Hinv.contiguous()      # row-major copy for the kernel; the trailing GEMM keeps
+            #                                upstream's operand layout (the upper factor comes back
+            #                                transposed) so that its summation order is unchanged
+            for i1 in range(0, self.columns, blocksize):
+                i2 = min(i1 + blocksize, self.columns)
+                E1 = torch.empty((self.rows, i2 - i1), dtype=torch.float32, device=W.device)
+                ops.gptq_block(W, i1, i2, Hrows, scale, qz.bits, Q, E1)
+                W[:, i2:] -= E1 @ Hinv[i1:i2, i2:]
+        for i1 in ([] if fused else range(0, self.columns, blocksize)):
             i2 = min(i1 + blocksize, self.columns)
             W1 = W[:, i1:i2].clone()
             Q1 = torch.zeros_like(W1)

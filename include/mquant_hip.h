@@ -153,6 +153,20 @@ int mq_wquant_sym(const void *w, int w_dtype, long N, long K, long ldw, int bits
                   uint8_t *packed, void *wq, long ldq, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * GPTQ: the column loop of one lazy-batch block, gptq/gptq_utils.py:258-279 (symmetric
+ * per-channel quantizer, no groups).  For i = 0..cols-1, per output row n:
+ *   q = scale[n]*clamp(rint(w_i/scale[n]), -2^(bits-1), 2^(bits-1)-1);  err = (w_i - q)/Hinv1[i][i];
+ *   w_j -= err*Hinv1[i][j]  (j > i);   Q1[n][i] = q;  Err1[n][i] = err
+ * fp32, the reference's operation order (bit-identical to the torch loop).  W1 is read only
+ * ([N, ldw], the block's columns of the working weights), cols <= 128, Hinv1 points at
+ * Hinv[i1][i1] of the upper Cholesky factor with leading dimension ldh.  The caller applies the
+ * trailing update W[:, i2:] -= Err1 @ Hinv[i1:i2, i2:] (a plain GEMM) as upstream does.
+ * ------------------------------------------------------------------------- */
+int mq_gptq_block(const float *W1, long N, int cols, long ldw, const float *Hinv1, long ldh,
+                  const float *scale, int bits, float *Q1, long ldq, float *Err1, long lde,
+                  void *stream);
+
+/* ---------------------------------------------------------------------------
  * Quantized Linear: int8 activations x int4/int8 weights -> int32 -> dequant.
  * Replaces F.linear on fake-quantized tensors, quant_utils.py:384 (and the fp32
  * L1/L2 pair of :374-376 when x0/w0 are given), with

@@ -176,6 +176,20 @@ def wquant_sym(w: torch.Tensor, bits: int = 4, mse: bool = False, norm: float = 
     return scale, levels, packed, (wq.reshape(w.shape) if want_wq else None)
 
 
+def gptq_block(W: torch.Tensor, i1: int, i2: int, Hinv: torch.Tensor, scale: torch.Tensor, bits: int,
+               Q: torch.Tensor, Err: torch.Tensor) -> None:
+    """Column loop of one GPTQ block (``mq_gptq_block``): reads W[:, i1:i2], writes Q[:, i1:i2] and
+    Err[:, :i2-i1].  W, Q: fp32 [N, columns] row-major; Hinv: fp32 [columns, columns] upper factor."""
+    _need_cuda(W, Hinv, scale, Q, Err)
+    assert W.dtype == Hinv.dtype == Q.dtype == Err.dtype == scale.dtype == torch.float32
+    assert W.stride(1) == 1 and Q.stride(1) == 1 and Err.stride(1) == 1 and Hinv.stride(1) == 1 and scale.is_contiguous()
+    N = W.shape[0]
+    fsz = 4
+    call("mq_gptq_block", W.data_ptr() + i1 * fsz, N, i2 - i1, W.stride(0),
+         Hinv.data_ptr() + (i1 * Hinv.stride(0) + i1) * fsz, Hinv.stride(0), scale.data_ptr(), bits,
+         Q.data_ptr() + i1 * fsz, Q.stride(0), Err.data_ptr(), Err.stride(0), _stream())
+
+
 def prepack(q: torch.Tensor, bits: int, zero_col0: bool = False) -> torch.Tensor:
     """int levels [N, K] -> the pre-tiled image streamed by gemm_w4a8."""
     _need_cuda(q)

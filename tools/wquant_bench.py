@@ -40,5 +40,35 @@ def main():
             print(f"{N:>7d}x{K:<8d} {'mse' if mse else 'rtn':>4s} {ms:10.3f} {passes * N * K * 2 / ms / 1e6:10.1f} {tms:10.2f} {same:12.4f}")
 
 
+def gptq_bench():
+    from fake_quant.gptq.gptq_utils import GPTQ
+    dev = torch.device("cuda:0")
+    torch.linalg.cholesky(torch.eye(256, device=dev) * 2.0)      # rocSOLVER start-up outside the timings
+    print(f"\n{'GPTQ shape':>16s} {'fused ms':>10s} {'torch-loop ms':>14s} {'identical':>10s}")
+    for N, K in ((1280, 1280), (3584, 3584), (1280, 5120), (3584, 19968)):
+        x = torch.randn((2048, K), device=dev)
+        res = {}
+        for fused in (True, False):
+            if not fused and K > 8192:
+                res[fused] = (float("nan"), None)
+                continue
+            torch.manual_seed(0)
+            lin = torch.nn.Linear(K, N, bias=False).to(dev)
+            lin.weight.data = torch.randn((N, K), device=dev) * 0.02
+            solver = GPTQ(lin)
+            solver.use_kernel = fused
+            solver.quantizer = qu.WeightQuantizer()
+            solver.quantizer.configure(4, perchannel=True, sym=True, mse=False)
+            solver.add_batch(x, None)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            solver.fasterquant()
+            torch.cuda.synchronize()
+            res[fused] = ((time.perf_counter() - t0) * 1e3, lin.weight.data.clone())
+        same = "-" if res[False][1] is None else str(bool(torch.equal(res[True][1], res[False][1])))
+        print(f"{N:>7d}x{K:<8d} {res[True][0]:10.1f} {res[False][0]:14.1f} {same:>10s}")
+
+
 if __name__ == "__main__":
     main()
+    gptq_bench()
