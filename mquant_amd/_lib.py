@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401  (must load first: the library then binds to torch's HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmquant_hip.so")
+# MQUANT_HIP_LIB selects another build of the same ABI (kernel experiments); default = in-tree .so
+LIB_PATH = os.environ.get("MQUANT_HIP_LIB") or os.path.join(_HERE, "libmquant_hip.so")
 
 MQ_F16, MQ_BF16, MQ_F32 = 0, 1, 2
 

@@ -39,6 +39,12 @@ __device__ __forceinline__ void dma16(const void *g, void *lds_wave_base)
 
 enum { EPI_F16 = MQ_F16, EPI_BF16 = MQ_BF16, EPI_F32 = MQ_F32, EPI_I32 = 3 };
 
+// Experiment switch for bottleneck hunting (never set in the shipped build): 1 = no DMA inside the
+// k-loop (compute side alone), 2 = no LDS reads / MFMA (DMA side alone).
+#ifndef MQ_EXP
+#define MQ_EXP 0
+#endif
+
 struct GemmArgs {
     const int8_t *a;
     long lda;
@@ -371,7 +377,7 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
         const bool more = it + STAGES - 1 < nk;
         int nxt = cur + STAGES - 1;
         if (nxt >= STAGES) nxt -= STAGES;
-        if (DMA_POS == 0 && more) issue_stage(nxt, it + STAGES - 1);
+        if (MQ_EXP != 1 && DMA_POS == 0 && more) issue_stage(nxt, it + STAGES - 1);
 
         const char *xs = smem + cur * STAGE_BYTES;
         const char *ws = xs + X_BYTES;
@@ -385,8 +391,9 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
             }
             // the DMA of the stage after next is issued behind the first fragment reads, so its
             // issue slots overlap MFMA execution instead of delaying the first MFMA of the step
-            if (DMA_POS == 1 && kt == 0 && more) issue_stage(nxt, it + STAGES - 1);
-            if (DMA_POS == 2 && kt == 1 && more) issue_stage(nxt, it + STAGES - 1);
+            if (MQ_EXP != 1 && DMA_POS == 1 && kt == 0 && more) issue_stage(nxt, it + STAGES - 1);
+            if (MQ_EXP != 1 && DMA_POS == 2 && kt == 1 && more) issue_stage(nxt, it + STAGES - 1);
+            if (MQ_EXP == 2) continue;
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
                 const int nt = wn * TN + i;
@@ -673,12 +680,24 @@ struct Plan {
 };
 
 static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes, int force_tile,
-                      int force_splits)
+                      int force_splits, bool w4 = true)
 {
     const long kps = K_pad / 128;
     const long t256 = ceil_div(M, 256) * ceil_div(N, 256);
     const long t128 = ceil_div(M, 128) * ceil_div(N, 128);
-    Plan pl = {t128 >= 400 ? 12 : 10, 1};   // 128x128 (8 waves) / 64x128: more, smaller workgroups
+    // Small GEMMs are bound by the L2 -> L1 -> LDS path (~22 B/clk/CU measured, tools/probes/
+    // l1_to_lds_rate.hip), i.e. by the bytes the busiest CU has to pull: ceil(tiles/256) x (BM + BN/2)
+    // per unit of K.  Pick the shape that minimises that (measured ranking agrees).
+    static const int cand[][3] = {{10, 64, 128}, {31, 96, 128}, {26, 128, 128}, {35, 192, 128}};
+    Plan pl = {10, 1};
+    long best = -1;
+    for (const auto &c : cand) {
+        if (c[0] == 35 && !w4) continue;
+        const long tiles = ceil_div(M, c[1]) * ceil_div(N, c[2]);
+        const long cost = ceil_div(tiles, 256) * (c[1] + c[2] / 2);
+        if (best < 0 || cost < best) { best = cost; pl.tile = c[0]; }
+    }
+    (void)t128;
     if (t256 >= 192) {
         pl.tile = 3;
     } else if (have_ws && kps >= 64 && t256 >= 8) {
@@ -726,6 +745,16 @@ static int dispatch_tile(const GemmArgs &p, int tile, hipStream_t st)
     case 22: return launch_gemm<128, 128, 2, 2, 5, W_BITS, EPI>(p, st);
     case 23: return launch_gemm<64, 64, 2, 2, 8, W_BITS, EPI>(p, st);
     case 24: return launch_gemm<128, 64, 2, 2, 6, W_BITS, EPI>(p, st);
+    case 25: return launch_gemm<64, 128, 1, 4, 3, W_BITS, EPI>(p, st);
+    case 26: return launch_gemm<128, 128, 2, 4, 3, W_BITS, EPI>(p, st);
+    case 27: return launch_gemm<128, 128, 1, 4, 3, W_BITS, EPI>(p, st);
+    case 28: return launch_gemm<128, 64, 2, 2, 3, W_BITS, EPI>(p, st);
+    case 29: return launch_gemm<128, 256, 2, 4, 3, W_BITS, EPI>(p, st);
+    case 30: return launch_gemm<96, 128, 2, 2, 3, W_BITS, EPI>(p, st);
+    case 31: return launch_gemm<96, 128, 1, 4, 3, W_BITS, EPI>(p, st);
+    case 33: if constexpr (W_BITS == 4) return launch_gemm<64, 256, 1, 4, 3, W_BITS, EPI>(p, st); else break;
+    case 34: if constexpr (W_BITS == 4) return launch_gemm<64, 256, 2, 4, 3, W_BITS, EPI>(p, st); else break;
+    case 35: if constexpr (W_BITS == 4) return launch_gemm<192, 128, 2, 4, 3, W_BITS, EPI>(p, st); else break;
     default: break;
     }
     return launch_gemm<128, 128, 2, 2, 3, W_BITS, EPI>(p, st);
@@ -760,7 +789,7 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
     p.sx0 = s_x0; p.sx1 = s_x1; p.row_sel = row_sel; p.s_w = s_w; p.bias = bias; p.x0 = x0; p.w0 = w0;
     p.out = out; p.ldo = ldo;
     const Plan pl = make_plan(M, N, K_pad, workspace != nullptr, workspace_bytes, g_force_tile,
-                              workspace ? g_force_splits : 0);
+                              workspace ? g_force_splits : 0, w_bits == 4);
     p.splits = pl.splits;
     p.partial = (int32_t *)workspace;
     auto al16 = [](const void *q) { return q == nullptr || ((uintptr_t)q) % 16 == 0; };
