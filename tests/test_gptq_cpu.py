@@ -166,3 +166,108 @@ def test_capture_restores_the_module_and_stops_early():
     samples = seq.capture_inputs(target, lambda enough: seq.run_calibration_prompts(vlm, ToyDataset(8), "toy", args, enough), 2)
     assert len(samples) == 2 and vlm.calls == 2 and "forward" not in target.__dict__
     assert samples[0][0][0].shape == (7, 64)
+
+
+@pytest.mark.parametrize("rtn", [False, True])
+def test_qwenvl_v1_driver(rtn):
+    from fake_quant import quant_utils as qu
+    from fake_quant.gptq import qwenvl_gptq_plus
+    vlm = ToyVlm("qwenvl")
+    args = gptq_args(visual_w_rtn=rtn, llm_w_rtn=rtn)
+    ref_out = vlm.generate(0, "toy")
+    qu.qwenvl_add_act_qaunt(vlm.model, args)
+    quantizers = qwenvl_gptq_plus.qwenvl_rtn_gptq_fwrd_plus(vlm, ToyDataset(8), "cpu", args)
+    wrappers = qu.find_qlayers(vlm.model, [qu.ActQuantWrapper])
+    expect = {"model.transformer.visual.conv1", "model.transformer.visual.transformer.resblocks.1.mlp.c_proj.module",
+              "model.model.transformer.visual.attn_pool.kv_proj.module", "model.model.transformer.visual.attn_pool.attn.out_proj.module",
+              "model.model.transformer.visual.proj_fc", "model.transformer.h.0.attn.c_proj.module",
+              "model.transformer.h.1.mlp.w2.module"}
+    assert expect <= set(quantizers), sorted(quantizers)
+    assert len(quantizers) == len(wrappers)
+    for name, w in wrappers.items():
+        assert "module" in w.weight_quantizers and _on_grid(w.module.weight.data, w.weight_quantizers["module"]), name
+    out = vlm.generate(0, "toy")
+    assert torch.isfinite(out).all() and float((out - ref_out).norm() / ref_out.norm()) < 0.5
+
+
+def test_minicpmv_driver_walks_the_expected_modules():
+    """No MiniCPM-V toy forward: a module tree with the right names, identity-like blocks."""
+    import torch.nn as nn
+    from fake_quant import quant_utils as qu
+    from fake_quant.gptq import minicpmv_gptq_plus
+
+    class Attn(nn.Module):
+        def __init__(self, d, out_name):
+            super().__init__()
+            self.q_proj, self.k_proj, self.v_proj = nn.Linear(d, d), nn.Linear(d, d), nn.Linear(d, d)
+            setattr(self, out_name, nn.Linear(d, d))
+            self.out_name = out_name
+
+        def forward(self, x):
+            return getattr(self, self.out_name)(torch.tanh(self.q_proj(x) + self.k_proj(x)) * self.v_proj(x))
+
+    class VisLayer(nn.Module):
+        def __init__(self, d):
+            super().__init__()
+            self.self_attn, self.mlp = Attn(d, "out_proj"), nn.Module()
+            self.mlp.fc1, self.mlp.fc2 = nn.Linear(d, 2 * d), nn.Linear(2 * d, d)
+
+        def forward(self, x):
+            x = x + self.self_attn(x)
+            return (x + self.mlp.fc2(torch.relu(self.mlp.fc1(x))),)        # HF layers return tuples
+
+    class LlmLayer(nn.Module):
+        def __init__(self, d):
+            super().__init__()
+            self.self_attn, self.mlp = Attn(d, "o_proj"), nn.Module()
+            self.mlp.gate_proj, self.mlp.up_proj, self.mlp.down_proj = nn.Linear(d, 2 * d), nn.Linear(d, 2 * d), nn.Linear(2 * d, d)
+
+        def forward(self, x, position_ids=None):
+            x = x + self.self_attn(x)
+            return (x + self.mlp.down_proj(torch.sigmoid(self.mlp.gate_proj(x)) * self.mlp.up_proj(x)),)
+
+    class Resampler(nn.Module):
+        def __init__(self, d):
+            super().__init__()
+            self.kv_proj, self.attn, self.proj_fc = nn.Linear(d, d), Attn(d, "out_proj"), nn.Linear(d, d)
+
+        def forward(self, x):
+            return self.proj_fc(self.attn(self.kv_proj(x)))
+
+    class Hf(nn.Module):
+        def __init__(self, d=32):
+            super().__init__()
+            self.vpm, self.llm = nn.Module(), nn.Module()
+            self.vpm.embeddings, self.vpm.encoder, self.llm.model = nn.Module(), nn.Module(), nn.Module()
+            self.vpm.embeddings.patch_embedding = nn.Conv2d(3, d, kernel_size=4, stride=4)
+            self.vpm.encoder.layers = nn.ModuleList(VisLayer(d) for _ in range(2))
+            self.resampler = Resampler(d)
+            self.llm.model.layers = nn.ModuleList(LlmLayer(d) for _ in range(2))
+
+        def forward(self, pixels):
+            x = self.vpm.embeddings.patch_embedding(pixels).flatten(1)
+            for layer in self.vpm.encoder.layers:
+                x = layer(x)[0]
+            x = self.resampler(x)
+            for layer in self.llm.model.layers:
+                x = layer(x, position_ids=None)[0]
+            return x
+
+    class Vlm:
+        def __init__(self):
+            torch.manual_seed(0)
+            self.model = Hf()
+
+        def generate(self, message, dataset):
+            g = torch.Generator().manual_seed(int(message))
+            return self.model(torch.randn(12, 3, 4, 4, generator=g))
+
+    vlm = Vlm()
+    args = gptq_args()
+    qu.minicpmv_add_act_qaunt(vlm.model, args)
+    q = minicpmv_gptq_plus.minicpmv_rtn_gptq_fwrd_plus(vlm, ToyDataset(6), "cpu", args)
+    wrappers = qu.find_qlayers(vlm.model, [qu.ActQuantWrapper])
+    assert len(q) == len(wrappers) == 1 + 2 * 6 + 6 + 2 * 7
+    assert {"model.vpm.embeddings.patch_embedding", "model.vpm.encoder.layers.0.self_attn.out_proj.module",
+            "model.resampler.proj_fc.module", "model.llm.model.layers.1.mlp.down_proj.module"} <= set(q)
+    assert all(_on_grid(w.module.weight.data, w.weight_quantizers["module"]) for w in wrappers.values())
