@@ -134,6 +134,20 @@ int mq_prepack_w8(const int8_t *q, long N, long K, int zero_col0, int8_t *out, v
 size_t mq_prepacked_bytes(long N, long K, int w_bits);
 
 /* ---------------------------------------------------------------------------
+ * RMSN + static quantizer in one pass.  Replaces module_util.RMSN.forward
+ * (module_util.py:55-61) followed by UniformQuantizer.quant (uniform.py:20-33):
+ *   h = fp32(x);  y = cast_to_x_dtype(h * (1/sqrt(sum(h*h)/mean_dim + eps)));
+ *   out[m][k] = clamp(rint(y / scale_sel(m)), -128, 127), zero for K <= k < K_pad
+ * x: [M, ldx] MQ_F16 or MQ_F32 (upstream promotes fp16 only), rows 16-byte aligned, K % 16 == 0,
+ * K <= 16384.  y_out (optional, [M, ldy], x's dtype) receives the normalised activations.
+ * The sum of squares uses the fixed order documented in csrc/rmsn_quant.hip (oracle: orc_rmsn);
+ * torch's own reduction order differs in the last fp32 bit, i.e. <= 1 ulp of y.
+ * ------------------------------------------------------------------------- */
+int mq_rmsn_quantize_i8(const void *x, int x_dtype, long M, long K, long ldx, float mean_dim,
+                        float eps, float scale0, float scale1, const uint8_t *row_sel,
+                        void *y_out, long ldy, int8_t *out, long K_pad, long ldo, void *stream);
+
+/* ---------------------------------------------------------------------------
  * Weight quantizer on the device (offline weight pipeline).
  * Replaces WeightQuantizer.find_params + WeightQuantizer.quantize for the symmetric
  * per-output-channel case, quant_utils.py:446-518 (sym_quant_dequant :46-58):

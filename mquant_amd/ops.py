@@ -72,6 +72,24 @@ def quantize_act_i8(x: torch.Tensor, scale0: float = 1.0, scale1: Optional[float
     return out, x0_out
 
 
+def rmsn_quantize_i8(x: torch.Tensor, mean_dim: float, eps: float, scale0: float,
+                     scale1: Optional[float] = None, *, row_sel: Optional[torch.Tensor] = None,
+                     out: Optional[torch.Tensor] = None, want_y: bool = False):
+    """Weight-less RMS norm (module_util.RMSN) + static int8 quantizer in one pass.
+    Returns (int8 [M, ceil128(K)], normalised activations in x's dtype | None)."""
+    x2 = _rows(x)
+    _need_cuda(x2, row_sel, out)
+    M, K = x2.shape
+    K_pad = ceil_to(K, 128) if out is None else out.shape[1]
+    if out is None:
+        out = torch.empty((M, K_pad), dtype=torch.int8, device=x.device)
+    y = torch.empty((M, K), dtype=x.dtype, device=x.device) if want_y else None
+    call("mq_rmsn_quantize_i8", x2.data_ptr(), dtype_code(x2.dtype), M, K, x2.stride(0), float(mean_dim),
+         float(eps), float(scale0), float(scale0 if scale1 is None else scale1), _ptr(row_sel),
+         _ptr(y), K, out.data_ptr(), K_pad, out.stride(0), _stream())
+    return out, (y.reshape(x.shape) if want_y else None)
+
+
 def fakequant_act(x: torch.Tensor, scale0: float = 1.0, scale1: Optional[float] = None, *,
                   scale_vec0: Optional[torch.Tensor] = None,
                   scale_vec1: Optional[torch.Tensor] = None,

@@ -192,6 +192,16 @@ def linear_fakequant_f32(x, s_x, w_dq, bias=None) -> np.ndarray:
     return out
 
 
+def rmsn(x, mean_dim, eps=1e-5, mode=0):
+    """module_util.py:55-61 (weight-less RMS norm) with the device kernel's summation order."""
+    x = _f32(x)
+    rows, cols = x.shape
+    y = np.empty_like(x)
+    lib().orc_rmsn(_p(x, C.c_float), C.c_long(rows), C.c_long(cols), C.c_float(mean_dim), C.c_float(eps),
+                   C.c_int(mode), _p(y, C.c_float))
+    return y
+
+
 def pow_pos(d, norm):
     lib().orc_pow_pos.restype = C.c_float
     return np.float32(lib().orc_pow_pos(C.c_float(d), C.c_float(norm)))

@@ -106,6 +106,43 @@ void orc_quant_static(const float *x, long rows, long cols,
     }
 }
 
+/* ------------------------------------------------------------------ */
+/* RMSN: weight-less RMS normalisation left behind by the LayerNorm fusion,
+ * module_util.py:42-61:  h = fp32(x);  ms = sum(h*h) / mean_dim;  y = cast(h * rsqrt(ms + eps)).
+ * torch leaves the summation order to its reduction kernels; this restatement fixes the order the
+ * device kernel uses (mquant_amd/csrc/rmsn_quant.hip): 256 workers, worker t owns the 16-element
+ * chunks c with c % 256 == t and adds its squares in ascending k; a 64-wide XOR butterfly
+ * (strides 1,2,..,32) inside each group of 64 workers; the four group sums left to right.
+ * rsqrt is 1/sqrt with both operations correctly rounded (= torch's CPU kernel).          */
+/* ------------------------------------------------------------------ */
+void orc_rmsn(const float *x, long rows, long cols, float mean_dim, float eps, int mode, float *y)
+{
+    for (long r = 0; r < rows; ++r) {
+        const float *h = x + r * cols;
+        float part[256];
+        for (int t = 0; t < 256; ++t) part[t] = 0.0f;
+        for (long k = 0; k < cols; ++k) {
+            const int t = (int)((k / 16) % 256);
+            const float sq = h[k] * h[k];
+            part[t] = part[t] + sq;
+        }
+        float wsum[4];
+        for (int w = 0; w < 4; ++w) {
+            float v[64], n[64];
+            for (int l = 0; l < 64; ++l) v[l] = part[w * 64 + l];
+            for (int st = 1; st < 64; st <<= 1) {
+                for (int l = 0; l < 64; ++l) n[l] = v[l] + v[l ^ st];
+                for (int l = 0; l < 64; ++l) v[l] = n[l];
+            }
+            wsum[w] = v[0];
+        }
+        const float total = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+        const float ms = total / mean_dim;
+        const float inv = 1.0f / sqrtf(ms + eps);
+        for (long k = 0; k < cols; ++k) y[r * cols + k] = round_mid(h[k] * inv, mode);
+    }
+}
+
 /* uniform.py:35-43: x_hat = (q - zp) * s  (fp32) */
 void orc_dequant_static(const int8_t *q, long rows, long cols,
                         const float *scale0, const float *zp0,
