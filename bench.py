@@ -74,35 +74,40 @@ def full_prefill_report(pf, dev, args):
     from mquant_amd import workload
     from mquant_amd.full_prefill import FullPrefill
     try:
-        fp = FullPrefill(pf)
-        fp.calibrate()
-        if args.no_graph:
-            run = fp.step
-        else:
-            fp.step()
-            torch.cuda.synchronize(dev)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+        def measure(fused):
+            fp = FullPrefill(pf, fused_glue=fused)
+            fp.calibrate()
+            if args.no_graph:
+                run = fp.step
+            else:
                 fp.step()
-            run = g.replay
-        for _ in range(20):
-            run()
-        torch.cuda.synchronize(dev)
-        times = []
-        for _ in range(max(args.ttft_iters, 5)):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            run()
-            e1.record()
-            e1.synchronize()
-            times.append(e0.elapsed_time(e1))
-        times.sort()
-        med = times[len(times) // 2]
-        p90 = times[min(len(times) - 1, int(round(0.9 * (len(times) - 1))))]
-        finite = bool(torch.isfinite(fp.logits.float()).all().item())
-        return {"what": "whole synthetic prefill: W4A8 Linears (this repo's kernels) + torch glue "
-                        "(RMS norm, RoPE, SDPA, GELU/SiLU, residuals, fp16 lm_head on the last position)",
-                "ttft_ms_median": round(med, 4), "ttft_ms_p90": round(p90, 4), "iters": len(times),
+                torch.cuda.synchronize(dev)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    fp.step()
+                run = g.replay
+            for _ in range(20):
+                run()
+            torch.cuda.synchronize(dev)
+            times = []
+            for _ in range(max(args.ttft_iters, 5)):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                run()
+                e1.record()
+                e1.synchronize()
+                times.append(e0.elapsed_time(e1))
+            times.sort()
+            med = times[len(times) // 2]
+            p90 = times[min(len(times) - 1, int(round(0.9 * (len(times) - 1))))]
+            return med, p90, len(times), bool(torch.isfinite(fp.logits.float()).all().item())
+        med_u, p90_u, _, _ = measure(False)
+        med, p90, iters, finite = measure(True)
+        return {"what": "whole synthetic prefill: W4A8 Linears (this repo's kernels) + torch glue (RoPE, SDPA, "
+                        "residuals, fp16 lm_head on the last position); RMS norm -> quantize and "
+                        "SiLU*up / QuickGELU -> Hadamard -> quantize run as single fused launches",
+                "ttft_ms_median": round(med, 4), "ttft_ms_p90": round(p90, 4), "iters": iters,
+                "ttft_ms_median_unfused_glue": round(med_u, 4), "ttft_ms_p90_unfused_glue": round(p90_u, 4),
                 "llm_tokens_per_s": round(workload.M_LLM / (med * 1e-3), 1),
                 "all_tokens_per_s": round((workload.M_LLM + workload.M_VIS) / (med * 1e-3), 1),
                 "logits_finite": finite}

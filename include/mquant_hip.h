@@ -109,6 +109,19 @@ int mq_hadamard_quant_i8(const void *x, int x_dtype, long M, long n_in, long ldx
                          int skip_col0, float *x0_out,
                          int8_t *out, long K_pad, long ldo, void *stream);
 
+/* Same with the activation that produces the rotated Linear's input fused in front (SURVEY 8(f3):
+ * "SiLU.up fused into the down_proj Hadamard-quant prologue"): the row fed to the transform is
+ *   act == 1 (MQ_ACT_SILU_MUL):   cast(cast(x / (1 + exp(-x))) * x2)   x = gate, x2 = up (same ldx)
+ *   act == 2 (MQ_ACT_QUICK_GELU): cast(x * cast(1 / (1 + exp(-cast(1.702 x)))))
+ * i.e. torch's F.silu(gate) * up / QuickGELUActivation on tensors of x_dtype (fp32 inside an op,
+ * one rounding per op); exp is evaluated library-free (<= 1 ulp fp32; oracle: orc_silu_mul /
+ * orc_quick_gelu).  Everything after that is mq_hadamard_quant_i8.  Requires n/K >= 8. */
+int mq_act_hadamard_quant_i8(const void *x, const void *x2, int act, int x_dtype, long M,
+                             long n_in, long ldx, long n, int K, const uint32_t *had_words,
+                             int fp32_had, float scale0, float scale1, const uint8_t *row_sel,
+                             int skip_col0, float *x0_out, int8_t *out, long K_pad, long ldo,
+                             void *stream);
+
 /* Tuning hook (process-wide, not part of the drop-in surface): 256 or 512 threads per row. */
 int mq_hadamard_debug_threads(int threads);
 

@@ -34,6 +34,7 @@ SIGNATURES = {
     "mq_pack_i4": (_i, [_vp, _l, _l, _vp, _vp]),
     "mq_unpack_i4": (_i, [_vp, _l, _l, _vp, _vp]),
     "mq_weight_levels": (_i, [_vp, _i, _l, _l, _l, _vp, _i, _i, _vp, _vp]),
+    "mq_act_hadamard_quant_i8": (_i, [_vp, _vp, _i, _i, _l, _l, _l, _l, _i, _vp, _i, _f, _f, _vp, _i, _vp, _vp, _l, _l, _vp]),
     "mq_rmsn_quantize_i8": (_i, [_vp, _i, _l, _l, _l, _f, _f, _f, _f, _vp, _vp, _l, _vp, _l, _l, _vp]),
     "mq_wquant_sym": (_i, [_vp, _i, _l, _l, _l, _i, _i, _f, _i, _f, _vp, _vp, _vp, _vp, _l, _vp]),
     "mq_gptq_block": (_i, [_vp, _l, _i, _l, _vp, _l, _vp, _i, _vp, _l, _vp, _l, _vp]),

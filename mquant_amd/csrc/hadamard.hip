@@ -28,6 +28,8 @@ namespace mq {
 
 struct HadArgs {
     const void *x;
+    const void *x2 = nullptr;   // second operand of a fused activation (up of silu(gate)*up), same ldx
+    int act = MQ_ACT_NONE;      // activation applied to the loaded row before the transform
     long M, n_in, ldx, n;
     int K, m;
     const uint8_t *had_bits;
@@ -114,7 +116,7 @@ __device__ __forceinline__ void had_emit4(const HadArgs &p, long row, long col, 
     }
 }
 
-template <int DT, bool QUANT, bool HALF_LDS, int THREADS>
+template <int DT, bool QUANT, bool HALF_LDS, int THREADS, bool ACT = false>
 __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
 {
     constexpr int HAD_THREADS = THREADS;
@@ -178,6 +180,20 @@ __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
                 } else {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) vb[u][i] = (idx + i < p.n_in) ? Elem<DT>::ld(xr[idx + i]) : 0.0f;
+                }
+                if (ACT && idx < p.n_in) {                            // fused activation prologue (own instantiation)
+                    float ub[8];
+                    if (p.act == MQ_ACT_SILU_MUL) {
+                        const T *ur = reinterpret_cast<const T *>(p.x2) + row * p.ldx;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) ub[i] = (idx + i < p.n_in) ? Elem<DT>::ld(ur[idx + i]) : 0.0f;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        if (idx + i >= p.n_in) continue;
+                        vb[u][i] = (p.act == MQ_ACT_SILU_MUL) ? act_silu_mul<DT>(vb[u][i], ub[i])
+                                                               : act_quick_gelu<DT>(vb[u][i]);
+                    }
                 }
               }
 #pragma unroll
@@ -348,7 +364,7 @@ __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
     }
 }
 
-template <int DT, bool QUANT, bool HALF_LDS, int THREADS>
+template <int DT, bool QUANT, bool HALF_LDS, int THREADS, bool ACT = false>
 static int launch_hadamard_t(HadArgs p, hipStream_t st)
 {
     const int esz = HALF_LDS ? 2 : 4;
@@ -359,7 +375,7 @@ static int launch_hadamard_t(HadArgs p, hipStream_t st)
     const size_t wpr = (p.K + 31) / 32;
     const size_t lds = (size_t)p.y_bytes + (p.K > 1 ? (size_t)p.K * wpr * 4 : 0);
     if (lds > 160 * 1024) return fail(MQ_EUNSUPPORTED, "mq_hadamard: n=%ld needs %zu B of LDS (> 160 KiB)", p.n, lds);
-    auto kern = hadamard_kernel<DT, QUANT, HALF_LDS, THREADS>;
+    auto kern = hadamard_kernel<DT, QUANT, HALF_LDS, THREADS, ACT>;
     static size_t lds_granted = 0;   // per instantiation; raised outside any stream capture (first call)
     if (lds > lds_granted) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -384,6 +400,10 @@ static int launch_hadamard(const HadArgs &p, hipStream_t st)
     // keep them busy (down_proj: 10 x 2 = 20 units; measured 83 -> 76 us), else 4 waves
     const int units = (p.K > 1 && p.m >= 64) ? ((p.K + 15) / 16) * (p.m / 64) : 0;
     const int threads = g_had_threads ? g_had_threads : (units >= 16 ? 512 : 256);
+    if (QUANT && p.act != MQ_ACT_NONE) {
+        if (threads == 512) return launch_hadamard_t<DT, QUANT, HALF_LDS, 512, QUANT>(p, st);
+        return launch_hadamard_t<DT, QUANT, HALF_LDS, 256, QUANT>(p, st);
+    }
     if (threads == 512) return launch_hadamard_t<DT, QUANT, HALF_LDS, 512>(p, st);
     return launch_hadamard_t<DT, QUANT, HALF_LDS, 256>(p, st);
 }
@@ -459,4 +479,23 @@ extern "C" int mq_hadamard_quant_i8(const void *x, int x_dtype, long M, long n_i
     p.fp32_had = fp32_had; p.s0 = scale0; p.s1 = scale1; p.row_sel = row_sel;
     p.skip_col0 = skip_col0; p.x0_out = x0_out; p.qout = out; p.K_pad = K_pad; p.ldq = ldo;
     return mq::hadamard_common(p, x_dtype, true, stream);
+}
+
+extern "C" int mq_act_hadamard_quant_i8(const void *x, const void *x2, int act, int x_dtype, long M,
+                                        long n_in, long ldx, long n, int K, const uint32_t *had_words,
+                                        int fp32_had, float scale0, float scale1, const uint8_t *row_sel,
+                                        int skip_col0, float *x0_out, int8_t *out, long K_pad, long ldo,
+                                        void *stream)
+{
+    using namespace mq;
+    MQ_REQUIRE(act == MQ_ACT_SILU_MUL || act == MQ_ACT_QUICK_GELU, "mq_act_hadamard_quant_i8: unknown activation %d", act);
+    MQ_REQUIRE(act != MQ_ACT_SILU_MUL || x2 != nullptr, "mq_act_hadamard_quant_i8: silu(gate)*up needs the second operand");
+    MQ_REQUIRE(K >= 1 && n % K == 0 && n / K >= 8, "mq_act_hadamard_quant_i8: n/K must be >= 8");
+    HadArgs p;
+    memset(&p, 0, sizeof(p));
+    p.x = x; p.x2 = x2; p.act = act;
+    p.M = M; p.n_in = n_in; p.ldx = ldx; p.n = n; p.K = K; p.had_bits = reinterpret_cast<const uint8_t *>(had_words);
+    p.fp32_had = fp32_had; p.s0 = scale0; p.s1 = scale1; p.row_sel = row_sel;
+    p.skip_col0 = skip_col0; p.x0_out = x0_out; p.qout = out; p.K_pad = K_pad; p.ldq = ldo;
+    return hadamard_common(p, x_dtype, true, stream);
 }

@@ -84,6 +84,78 @@ __device__ __forceinline__ int quant_level(float x, float s, float lo, float hi)
     return (int)v;
 }
 
+// ---- library-free transcendental pieces --------------------------------------------------------
+// log2 / exp2 in double from ordered +,*,/ only (no libm, no contraction): every caller rounds the
+// result once to fp32, which makes device results reproducible bit for bit by the C oracle
+// (orc_log2_pos / orc_exp2) and <= 1 ulp(fp32) from the correctly rounded value.
+__device__ __forceinline__ double log2_pos(double x)
+{
+    int e;
+    double m = frexp(x, &e);
+    if (m < 0.70710678118654752440) { m = m * 2.0; e -= 1; }
+    const double f = (m - 1.0) / (m + 1.0);
+    const double f2 = f * f;
+    double t = 1.0 / 23.0;
+    t = t * f2 + 1.0 / 21.0;
+    t = t * f2 + 1.0 / 19.0;
+    t = t * f2 + 1.0 / 17.0;
+    t = t * f2 + 1.0 / 15.0;
+    t = t * f2 + 1.0 / 13.0;
+    t = t * f2 + 1.0 / 11.0;
+    t = t * f2 + 1.0 / 9.0;
+    t = t * f2 + 1.0 / 7.0;
+    t = t * f2 + 1.0 / 5.0;
+    t = t * f2 + 1.0 / 3.0;
+    t = t * f2 + 1.0;
+    return (double)e + (2.0 * f) * t * 1.44269504088896340736;
+}
+
+__device__ __forceinline__ double exp2_d(double y)
+{
+    const double yi = floor(y + 0.5);
+    const double r = (y - yi) * 0.69314718055994530942;
+    double t = 1.0 / 6227020800.0;
+    t = t * r + 1.0 / 479001600.0;
+    t = t * r + 1.0 / 39916800.0;
+    t = t * r + 1.0 / 3628800.0;
+    t = t * r + 1.0 / 362880.0;
+    t = t * r + 1.0 / 40320.0;
+    t = t * r + 1.0 / 5040.0;
+    t = t * r + 1.0 / 720.0;
+    t = t * r + 1.0 / 120.0;
+    t = t * r + 1.0 / 24.0;
+    t = t * r + 1.0 / 6.0;
+    t = t * r + 0.5;
+    t = t * r + 1.0;
+    t = t * r + 1.0;
+    return ldexp(t, (int)yi);
+}
+
+// exp(-z) in fp32
+__device__ __forceinline__ float exp_neg(float z)
+{
+    return (float)exp2_d((double)(-z) * 1.44269504088896340736);
+}
+
+// Activations that sit in front of a rotated Linear, evaluated the way torch evaluates them on
+// DT tensors: fp32 arithmetic inside one op, one rounding to DT per op.
+enum { MQ_ACT_NONE = 0, MQ_ACT_SILU_MUL = 1, MQ_ACT_QUICK_GELU = 2 };
+
+template <int DT> __device__ __forceinline__ float act_silu_mul(float g, float u)
+{
+    const float den = 1.0f + exp_neg(g);              // F.silu: x / (1 + exp(-x))
+    const float sl = Elem<DT>::rnd(g / den);
+    return Elem<DT>::rnd(sl * u);                      // silu(gate) * up
+}
+
+template <int DT> __device__ __forceinline__ float act_quick_gelu(float x)
+{
+    const float z = Elem<DT>::rnd(1.702f * x);         // QuickGELUActivation: x * sigmoid(1.702 x)
+    const float den = 1.0f + exp_neg(z);
+    const float sg = Elem<DT>::rnd(1.0f / den);
+    return Elem<DT>::rnd(x * sg);
+}
+
 __host__ __device__ inline long ceil_div(long a, long b) { return (a + b - 1) / b; }
 
 }  // namespace mq

@@ -19,49 +19,6 @@
 
 namespace mq {
 
-__device__ __forceinline__ double log2_pos(double x)
-{
-    int e;
-    double m = frexp(x, &e);
-    if (m < 0.70710678118654752440) { m = m * 2.0; e -= 1; }
-    const double f = (m - 1.0) / (m + 1.0);
-    const double f2 = f * f;
-    double t = 1.0 / 23.0;
-    t = t * f2 + 1.0 / 21.0;
-    t = t * f2 + 1.0 / 19.0;
-    t = t * f2 + 1.0 / 17.0;
-    t = t * f2 + 1.0 / 15.0;
-    t = t * f2 + 1.0 / 13.0;
-    t = t * f2 + 1.0 / 11.0;
-    t = t * f2 + 1.0 / 9.0;
-    t = t * f2 + 1.0 / 7.0;
-    t = t * f2 + 1.0 / 5.0;
-    t = t * f2 + 1.0 / 3.0;
-    t = t * f2 + 1.0;
-    return (double)e + (2.0 * f) * t * 1.44269504088896340736;
-}
-
-__device__ __forceinline__ double exp2_d(double y)
-{
-    const double yi = floor(y + 0.5);
-    const double r = (y - yi) * 0.69314718055994530942;
-    double t = 1.0 / 6227020800.0;
-    t = t * r + 1.0 / 479001600.0;
-    t = t * r + 1.0 / 39916800.0;
-    t = t * r + 1.0 / 3628800.0;
-    t = t * r + 1.0 / 362880.0;
-    t = t * r + 1.0 / 40320.0;
-    t = t * r + 1.0 / 5040.0;
-    t = t * r + 1.0 / 720.0;
-    t = t * r + 1.0 / 120.0;
-    t = t * r + 1.0 / 24.0;
-    t = t * r + 1.0 / 6.0;
-    t = t * r + 0.5;
-    t = t * r + 1.0;
-    t = t * r + 1.0;
-    return ldexp(t, (int)yi);
-}
-
 __device__ __forceinline__ float pow_pos(float d, float norm)
 {
     if (d == 0.0f) return 0.0f;

@@ -104,6 +104,27 @@ class W4A8Linear:
                                 out=a, x0_out=x0)
         return a, x0
 
+    def quantize_rmsn(self, x: torch.Tensor, mean_dim: float, eps: float,
+                      row_sel: Optional[torch.Tensor] = None):
+        """Weight-less RMS norm + quantize in one launch (layers without an online Hadamard)."""
+        assert self.had is None and not self.split
+        a = WORKSPACE.act(x.device, x.shape[0], self.K_pad)
+        ops.rmsn_quantize_i8(x, mean_dim, eps, self.s_x0, self.s_x1, row_sel=row_sel, out=a)
+        return a, None
+
+    def quantize_act(self, x: torch.Tensor, x2: Optional[torch.Tensor], act: int,
+                     row_sel: Optional[torch.Tensor] = None):
+        """Activation (silu(x)*x2 / quick_gelu(x)) + Hadamard + quantize in one launch: the input of a
+        rotated Linear straight from the producer's output (needs an online Hadamard on this layer)."""
+        assert self.had is not None, "the fused activation prologue lives in the Hadamard kernel"
+        M = x.shape[0]
+        a = WORKSPACE.act(x.device, M, self.K_pad)
+        x0 = WORKSPACE.x0(x.device, M) if self.split else None
+        ops.act_hadamard_quant_i8(x, x2, act, self.had.n, self.had.K, self.had.bits, self.s_x0, self.s_x1,
+                                  fp32_had=self.had.fp32_had, row_sel=row_sel, skip_col0=self.split,
+                                  out=a, x0_out=x0)
+        return a, x0
+
     def gemm(self, a: torch.Tensor, x0: Optional[torch.Tensor], out_dtype: torch.dtype,
              row_sel: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
         return ops.gemm_w4a8(a, self.w_img, self.w_bits, self.N, self.s_x0, self.s_w,

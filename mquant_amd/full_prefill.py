@@ -38,7 +38,9 @@ def _rope(x, cos, sin):
 
 
 class FullPrefill:
-    def __init__(self, pf: Prefill, seed: int = 7):
+    def __init__(self, pf: Prefill, seed: int = 7, fused_glue: bool = True):
+        #: norm -> quantize and activation -> Hadamard -> quantize as single launches
+        self.fused_glue = fused_glue
         assert pf.share_groups, "the chained prefill uses the fused q/k/v and gate/up GEMMs"
         self.pf, self.dev, self.dtype = pf, pf.device, pf.dtype
         by: Dict[str, List[Layer]] = {}
@@ -64,6 +66,21 @@ class FullPrefill:
                 L.lin.s_x1 = s1
         return L.lin.forward(x, L.row_sel)
 
+    def _norm_lin(self, L: Layer, x: torch.Tensor, dim: int) -> torch.Tensor:
+        """Linear(RMSN(x))."""
+        if self.calibrating or not self.fused_glue:
+            return self._lin(L, F.rms_norm(x, (dim,), eps=1e-6))
+        a, _ = L.lin.quantize_rmsn(x, dim, 1e-6, L.row_sel)
+        return L.lin.gemm(a, None, self.dtype, L.row_sel)
+
+    def _act_lin(self, L: Layer, x: torch.Tensor, x2, act: int) -> torch.Tensor:
+        """Linear(act(x[, x2])) for a layer with an online Hadamard."""
+        if self.calibrating or not self.fused_glue:
+            h = F.silu(x) * x2 if act == ops.ACT_SILU_MUL else x * torch.sigmoid(1.702 * x)
+            return self._lin(L, h)
+        a, x0 = L.lin.quantize_act(x, x2, act, L.row_sel)
+        return L.lin.gemm(a, x0, self.dtype, L.row_sel)
+
     def calibrate(self):
         self.calibrating = True
         self.step()
@@ -76,15 +93,13 @@ class FullPrefill:
         # vision tower
         x = self._lin(by["vis.patch_embed"][0], self.patches)
         for i in range(len(by["vis.attn.qkv"])):
-            h = F.rms_norm(x, (VIS_DIM,), eps=1e-6)
-            q, k, v = self._lin(by["vis.attn.qkv"][i], h).view(M_VIS, 3, VIS_HEADS, -1).unbind(1)
+            q, k, v = self._norm_lin(by["vis.attn.qkv"][i], x, VIS_DIM).view(M_VIS, 3, VIS_HEADS, -1).unbind(1)
             q, k = _rope(q, self.vcos, self.vsin), _rope(k, self.vcos, self.vsin)
             a = F.scaled_dot_product_attention(q.transpose(0, 1)[None], k.transpose(0, 1)[None],
                                                v.transpose(0, 1)[None])[0]
             x = x + self._lin(by["vis.attn.proj"][i], a.transpose(0, 1).reshape(M_VIS, VIS_DIM))
-            h = F.rms_norm(x, (VIS_DIM,), eps=1e-6)
-            f = F.gelu(self._lin(by["vis.mlp.fc1"][i], h), approximate="tanh")
-            x = x + self._lin(by["vis.mlp.fc2"][i], f)
+            f = self._norm_lin(by["vis.mlp.fc1"][i], x, VIS_DIM)
+            x = x + self._act_lin(by["vis.mlp.fc2"][i], f, None, ops.ACT_QUICK_GELU)   # hidden_act = quick_gelu
         m = F.rms_norm(x, (VIS_DIM,), eps=1e-6).view(M_MERGED, 4 * VIS_DIM)
         m = self._lin(by["merger.mlp.2"][0], F.gelu(self._lin(by["merger.mlp.0"][0], m)))
         # language model: [vision tokens | text tokens]
@@ -92,18 +107,16 @@ class FullPrefill:
         T = hdn.shape[0]
         kv = LLM_KV_HEADS * HEAD_DIM
         for i in range(len(by["llm.q_proj"])):
-            h = F.rms_norm(hdn, (LLM_DIM,), eps=1e-6)
-            qkv = self._lin(by["llm.q_proj"][i], h)                      # fused q|k|v GEMM
+            qkv = self._norm_lin(by["llm.q_proj"][i], hdn, LLM_DIM)      # fused q|k|v GEMM
             q = _rope(qkv[:, :LLM_DIM].view(T, LLM_HEADS, HEAD_DIM), self.lcos, self.lsin)
             k = _rope(qkv[:, LLM_DIM:LLM_DIM + kv].view(T, LLM_KV_HEADS, HEAD_DIM), self.lcos, self.lsin)
             v = qkv[:, LLM_DIM + kv:].view(T, LLM_KV_HEADS, HEAD_DIM)
             a = F.scaled_dot_product_attention(q.transpose(0, 1)[None], k.transpose(0, 1)[None],
                                                v.transpose(0, 1)[None], is_causal=True, enable_gqa=True)[0]
             hdn = hdn + self._lin(by["llm.o_proj"][i], a.transpose(0, 1).reshape(T, LLM_DIM))
-            h = F.rms_norm(hdn, (LLM_DIM,), eps=1e-6)
-            gu = self._lin(by["llm.gate_proj"][i], h)                    # fused gate|up GEMM
+            gu = self._norm_lin(by["llm.gate_proj"][i], hdn, LLM_DIM)    # fused gate|up GEMM
             half = gu.shape[1] // 2
-            hdn = hdn + self._lin(by["llm.down_proj"][i], F.silu(gu[:, :half]) * gu[:, half:])
+            hdn = hdn + self._act_lin(by["llm.down_proj"][i], gu[:, :half], gu[:, half:], ops.ACT_SILU_MUL)
         last = F.rms_norm(hdn[-1:], (LLM_DIM,), eps=1e-6)
         self.logits = last @ self.lm_head.t()
         return self.logits

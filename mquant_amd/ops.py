@@ -139,6 +139,33 @@ def hadamard_quant_i8(x: torch.Tensor, n: int, K: int, had_bits: Optional[torch.
     return out, x0_out
 
 
+ACT_SILU_MUL, ACT_QUICK_GELU = 1, 2
+
+
+def act_hadamard_quant_i8(x: torch.Tensor, x2: Optional[torch.Tensor], act: int, n: int, K: int,
+                          had_bits: Optional[torch.Tensor], scale0: float, scale1: Optional[float] = None, *,
+                          fp32_had: bool = False, row_sel: Optional[torch.Tensor] = None,
+                          skip_col0: bool = False, out: Optional[torch.Tensor] = None,
+                          x0_out: Optional[torch.Tensor] = None):
+    """silu(x) * x2 (ACT_SILU_MUL) or quick_gelu(x) (ACT_QUICK_GELU) -> [pad] -> Hadamard -> int8,
+    one launch.  x and x2 may be column slices of one tensor (same row stride)."""
+    a = _rows(x)
+    b = _rows(x2) if x2 is not None else None
+    _need_cuda(a, b, had_bits, row_sel, out)
+    if b is not None:
+        assert b.shape == a.shape and b.stride(0) == a.stride(0) and b.dtype == a.dtype
+    M, n_in = a.shape
+    K_pad = ceil_to(n, 128) if out is None else out.shape[1]
+    if out is None:
+        out = torch.empty((M, K_pad), dtype=torch.int8, device=x.device)
+    if skip_col0 and x0_out is None:
+        x0_out = torch.empty((M,), dtype=torch.float32, device=x.device)
+    call("mq_act_hadamard_quant_i8", a.data_ptr(), _ptr(b), int(act), dtype_code(a.dtype), M, n_in, a.stride(0),
+         n, K, _ptr(had_bits), int(fp32_had), float(scale0), float(scale0 if scale1 is None else scale1),
+         _ptr(row_sel), int(skip_col0), _ptr(x0_out), out.data_ptr(), K_pad, out.stride(0), _stream())
+    return out, x0_out
+
+
 # --------------------------------------------------------------------------- weights
 def pack_i4(q: torch.Tensor) -> torch.Tensor:
     _need_cuda(q)

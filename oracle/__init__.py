@@ -202,6 +202,20 @@ def rmsn(x, mean_dim, eps=1e-5, mode=0):
     return y
 
 
+def silu_mul(g, u, mode=0):
+    g, u = _f32(g), _f32(u)
+    out = np.empty_like(g)
+    lib().orc_silu_mul(_p(g, C.c_float), _p(u, C.c_float), C.c_long(g.size), C.c_int(mode), _p(out, C.c_float))
+    return out
+
+
+def quick_gelu(x, mode=0):
+    x = _f32(x)
+    out = np.empty_like(x)
+    lib().orc_quick_gelu(_p(x, C.c_float), C.c_long(x.size), C.c_int(mode), _p(out, C.c_float))
+    return out
+
+
 def pow_pos(d, norm):
     lib().orc_pow_pos.restype = C.c_float
     return np.float32(lib().orc_pow_pos(C.c_float(d), C.c_float(norm)))

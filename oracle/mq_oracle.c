@@ -397,6 +397,30 @@ float orc_pow_pos(float d, float norm)
     return (float)orc_exp2((double)norm * orc_log2_pos((double)d));
 }
 
+/* Activations in front of a rotated Linear, as torch evaluates them on tensors of the given dtype
+ * (mode 0 fp32, 1 fp16, 2 bf16): F.silu(gate) * up and QuickGELUActivation (x * sigmoid(1.702 x));
+ * these live in the HF model code, not in MQuant.  exp through orc_exp2 (library-free). */
+static inline float orc_exp_neg(float z) { return (float)orc_exp2((double)(-z) * 1.44269504088896340736); }
+
+void orc_silu_mul(const float *g, const float *u, long n, int mode, float *out)
+{
+    for (long i = 0; i < n; ++i) {
+        const float den = 1.0f + orc_exp_neg(g[i]);
+        const float sl = round_mid(g[i] / den, mode);
+        out[i] = round_mid(sl * u[i], mode);
+    }
+}
+
+void orc_quick_gelu(const float *x, long n, int mode, float *out)
+{
+    for (long i = 0; i < n; ++i) {
+        const float z = round_mid(1.702f * x[i], mode);
+        const float den = 1.0f + orc_exp_neg(z);
+        const float sg = round_mid(1.0f / den, mode);
+        out[i] = round_mid(x[i] * sg, mode);
+    }
+}
+
 void orc_wquant_sym(const float *w, long N, long K, int bits, int mse,
                     float norm, int grid, float maxshrink,
                     float *scale, int8_t *levels)
