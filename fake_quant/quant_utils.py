@@ -381,9 +381,12 @@ class ActQuantWrapper(torch.nn.Module):
         qz = self.quantizer
         if getattr(self, "_real_frozen", False) and self._real is not None:
             return self.real_quant
-        if not (self.real_quant and qz.static and qz.quant and not qz.calibrate):
+        if not self.real_quant or self.out_quantizer.bits < 16 or self.online_partial_had:
             return False
-        if qz.bits != 8 or self.out_quantizer.bits < 16 or self.online_partial_had:
+        if qz.static:
+            if not (qz.quant and not qz.calibrate) or qz.bits != 8:
+                return False
+        elif not self._dynamic_real_ok():
             return False
         if x.dtype not in (torch.float16, torch.bfloat16, torch.float32):
             return False
@@ -391,7 +394,7 @@ class ActQuantWrapper(torch.nn.Module):
         wq = self.weight_quantizers.get(name)
         if wq is None or not getattr(wq, "sym", False) or wq.bits not in (4, 8):
             return False
-        if qz.quantizer.scale is None or qz.quantizer.scale.numel() != 1:
+        if qz.static and (qz.quantizer.scale is None or qz.quantizer.scale.numel() != 1):
             return False                                   # channel_wise scales: simulated path
         mod = self.module
         if isinstance(mod, torch.nn.Linear):
@@ -400,6 +403,13 @@ class ActQuantWrapper(torch.nn.Module):
         return (not self.split and not self.online_full_had and x.dim() == mod.weight.dim()
                 and tuple(x.shape[2:]) == tuple(mod.kernel_size)
                 and all(p == 0 for p in mod.padding) and mod.groups == 1)
+
+    def _dynamic_real_ok(self) -> bool:
+        """Dynamic symmetric per-token int8 (the reference's default activation mode,
+        quant_utils.py:205-268) also has a real-integer kernel pair."""
+        qz = self.quantizer
+        return (qz.bits <= 8 and qz.bits >= 2 and getattr(qz, "sym", False) and not qz.act_per_tensor
+                and getattr(qz, "groupsize", -1) <= 0)
 
     def _build_real(self, device):
         from mquant_amd import ops
@@ -423,13 +433,17 @@ class ActQuantWrapper(torch.nn.Module):
             had = HadamardSpec(n, self.K, hadamard_utils._bits_for(self.had_K, self.K, device),
                                bool(self.fp32_had))
         qz = self.quantizer
-        s0 = float(qz.quantizer.scale)
-        s1 = None
-        if qz.msq:
-            s1 = float(qz.quantizer_text.scale) if qz.quantizer_text.scale is not None else s0
+        dynamic = None
+        s0, s1 = 1.0, None
+        if qz.static:
+            s0 = float(qz.quantizer.scale)
+            if qz.msq:
+                s1 = float(qz.quantizer_text.scale) if qz.quantizer_text.scale is not None else s0
+        else:
+            dynamic = dict(bits=int(qz.bits), clip_ratio=float(qz.clip_ratio))
         self._real = W4A8Linear(levels, scale, wq.bits,
                                 None if bias is None else bias.data.to(device), s0, s1,
-                                had=had, w0=w0)
+                                had=had, w0=w0, dynamic=dynamic)
         return self._real
 
     def _forward_real(self, x):
@@ -444,7 +458,7 @@ class ActQuantWrapper(torch.nn.Module):
         else:
             rows = x.reshape(x.shape[0], -1)
             out_shape = (x.shape[0], real.N) + (1,) * (x.dim() - 2)
-        sel = _row_mask(rows.shape[0], x.device) if self.quantizer.msq else None
+        sel = _row_mask(rows.shape[0], x.device) if getattr(self.quantizer, "msq", False) else None
         return real.forward(rows, sel).reshape(out_shape)
 
     # ------------------------------------------------------------------ forward

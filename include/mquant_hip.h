@@ -147,6 +147,20 @@ int mq_prepack_w8(const int8_t *q, long N, long K, int zero_col0, int8_t *out, v
 size_t mq_prepacked_bytes(long N, long K, int w_bits);
 
 /* ---------------------------------------------------------------------------
+ * Dynamic per-token activation quantizer: the reference's DEFAULT mode when --*_static is not
+ * given (ActQuantizer.find_params + forward, quant_utils.py:116-133,205-268; symmetric,
+ * act_per_tensor = False, groupsize = -1).  Per row m, fp32 arithmetic on the converted values:
+ *   xmin = min(min_k x, 0)*clip_ratio; xmax = max(max_k x, 0)*clip_ratio; maxq = 2^(bits-1)-1
+ *   scale_out[m] = max(|xmin|, xmax) / maxq   (1 where that is 0)
+ *   out[m][k]    = clamp(rint(x / scale_out[m]), -(maxq+1), maxq), zero for K <= k < K_pad
+ * skip_col0: column 0 is left out of the range, returned in x0_out and given level 0
+ * (ActQuantWrapper.split, quant_utils.py:367-372).  Pair with mq_gemm_w4a8_rowscale_ws.
+ * ------------------------------------------------------------------------- */
+int mq_quantize_act_dyn_i8(const void *x, int x_dtype, long M, long K, long ldx, int bits,
+                           float clip_ratio, int skip_col0, float *x0_out, float *scale_out,
+                           int8_t *out, long K_pad, long ldo, void *stream);
+
+/* ---------------------------------------------------------------------------
  * RMSN + static quantizer in one pass.  Replaces module_util.RMSN.forward
  * (module_util.py:55-61) followed by UniformQuantizer.quant (uniform.py:20-33):
  *   h = fp32(x);  y = cast_to_x_dtype(h * (1/sqrt(sum(h*h)/mean_dim + eps)));
@@ -211,6 +225,13 @@ int mq_gemm_w4a8(const int8_t *a, long lda, const void *w, int w_bits,
                  const float *s_w, const float *bias,
                  const float *x0, const float *w0,
                  void *out, int out_dtype, long ldo, void *stream);
+
+/* Same GEMM with one activation scale PER ROW (s_x_rows[m], from mq_quantize_act_dyn_i8) instead of
+ * the static scale set(s):  y[m][n] = ((float(acc) * s_x_rows[m]) * s_w[n]) + bias[n] + x0[m]*w0[n]. */
+int mq_gemm_w4a8_rowscale_ws(const int8_t *a, long lda, const void *w, int w_bits, long M, long N,
+                             long K_pad, const float *s_x_rows, const float *s_w, const float *bias,
+                             const float *x0, const float *w0, void *out, int out_dtype, long ldo,
+                             void *workspace, size_t workspace_bytes, void *stream);
 
 int mq_gemm_w4a8_i32(const int8_t *a, long lda, const void *w, int w_bits,
                      long M, long N, long K_pad, int32_t *acc, long ldacc, void *stream);

@@ -1,0 +1,139 @@
+// act_quant_dyn.hip -- the reference's DEFAULT activation quantizer: dynamic, symmetric, per token
+// (ActQuantizer.find_params + forward, fake_quant/quant_utils.py:116-133,205-268 with
+// act_per_tensor = False, groupsize = -1, sym = True), as int8 levels + one fp32 scale per row:
+//     xmin = min(min_k x, 0) * clip;  xmax = max(max_k x, 0) * clip      (fp32: the `tmp` of :239
+//     s    = max(|xmin|, xmax) / maxq,  s = 1 where that is 0              promotes half tensors)
+//     q    = clamp(rint(x / s), -(maxq+1), maxq)
+// One workgroup per row, the row stays in registers between the max pass and the quantize pass.
+// skip_col0 (ActQuantWrapper.split, :367-372): column 0 is excluded from the range, comes back in
+// x0_out as fp32 and gets level 0.
+#include "mq_common.h"
+
+namespace mq {
+
+constexpr int DQ_THREADS = 256;
+constexpr int DQ_MAX_CHUNKS = 8;   // rows up to 32768 elements
+
+struct DqArgs {
+    const void *x;
+    long M, K, ldx;
+    float clip, maxq;
+    int skip_col0;
+    float *x0_out, *scale_out;
+    int8_t *out;
+    long K_pad, ldo;
+    int vec_ok;
+};
+
+template <int DT>
+__global__ __launch_bounds__(DQ_THREADS) void act_quant_dyn_kernel(DqArgs p)
+{
+    typedef typename Elem<DT>::T T;
+    __shared__ float rmin[DQ_THREADS / 64], rmax[DQ_THREADS / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const long row = blockIdx.x;
+    const T *xr = reinterpret_cast<const T *>(p.x) + row * p.ldx;
+    const long chunks = ceil_div(p.K, 16);
+
+    float v[DQ_MAX_CHUNKS][16];
+    float mn = 0.0f, mx = 0.0f;
+#pragma unroll
+    for (int c = 0; c < DQ_MAX_CHUNKS; ++c) {
+        const long ch = t + (long)c * DQ_THREADS;
+        if (ch < chunks) {
+            const long col = ch * 16;
+            const T *src = xr + col;
+            if (col + 16 <= p.K && p.vec_ok) {
+                if (sizeof(T) == 2) {
+                    const v8us a = *reinterpret_cast<const v8us *>(src);
+                    const v8us b = *reinterpret_cast<const v8us *>(src + 8);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        v[c][i] = Elem<DT>::ld((T)a[i]);
+                        v[c][8 + i] = Elem<DT>::ld((T)b[i]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const v4f a = *reinterpret_cast<const v4f *>((const float *)src + 4 * j);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[c][4 * j + i] = a[i];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[c][i] = (col + i < p.K) ? Elem<DT>::ld(src[i]) : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (p.skip_col0 && col + i == 0) continue;
+                mn = fminf(mn, v[c][i]);
+                mx = fmaxf(mx, v[c][i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int st = 1; st < 64; st <<= 1) {
+        mn = fminf(mn, __shfl_xor(mn, st, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, st, 64));
+    }
+    if (lane == 0) { rmin[wave] = mn; rmax[wave] = mx; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < DQ_THREADS / 64; ++w) { mn = fminf(mn, rmin[w]); mx = fmaxf(mx, rmax[w]); }
+    const float xmin = mn * p.clip, xmax0 = mx * p.clip;
+    const float xmax = fmaxf(fabsf(xmin), xmax0);
+    const float s = (xmax == 0.0f) ? 1.0f : xmax / p.maxq;
+    if (t == 0 && p.scale_out) p.scale_out[row] = s;
+    const float lo = -(p.maxq + 1.0f), hi = p.maxq;
+
+#pragma unroll
+    for (int c = 0; c < DQ_MAX_CHUNKS; ++c) {
+        const long ch = t + (long)c * DQ_THREADS;
+        if (ch < chunks) {
+            int q[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) q[i] = (ch * 16 + i < p.K) ? quant_level(v[c][i], s, lo, hi) : 0;
+            if (p.skip_col0 && ch == 0) {
+                if (p.x0_out) p.x0_out[row] = v[c][0];
+                q[0] = 0;
+            }
+            v4i pk;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                pk[j] = (q[4 * j] & 0xff) | ((q[4 * j + 1] & 0xff) << 8) | ((q[4 * j + 2] & 0xff) << 16) |
+                        ((q[4 * j + 3] & 0xff) << 24);
+            *reinterpret_cast<v4i *>(p.out + row * p.ldo + ch * 16) = pk;
+        }
+    }
+    for (long k = chunks * 16 + t * 16L; k < p.K_pad; k += DQ_THREADS * 16L)
+        *reinterpret_cast<v4i *>(p.out + row * p.ldo + k) = v4i{0, 0, 0, 0};
+}
+
+}  // namespace mq
+
+extern "C" int mq_quantize_act_dyn_i8(const void *x, int x_dtype, long M, long K, long ldx, int bits,
+                                      float clip_ratio, int skip_col0, float *x0_out, float *scale_out,
+                                      int8_t *out, long K_pad, long ldo, void *stream)
+{
+    using namespace mq;
+    MQ_REQUIRE(x && out && scale_out && M >= 0 && K > 0 && ldx >= K, "mq_quantize_act_dyn_i8: bad shape");
+    MQ_REQUIRE(bits >= 2 && bits <= 8, "mq_quantize_act_dyn_i8: bits must be 2..8");
+    MQ_REQUIRE(K <= 16L * DQ_THREADS * DQ_MAX_CHUNKS, "mq_quantize_act_dyn_i8: K=%ld too large (max %d)", K, 16 * DQ_THREADS * DQ_MAX_CHUNKS);
+    MQ_REQUIRE(K_pad >= K && K_pad % 16 == 0 && ldo >= K_pad && ldo % 16 == 0 && ((uintptr_t)out) % 16 == 0,
+               "mq_quantize_act_dyn_i8: bad K_pad / ldo / alignment");
+    if (M == 0) return MQ_OK;
+    DqArgs p;
+    p.x = x; p.M = M; p.K = K; p.ldx = ldx; p.clip = clip_ratio; p.maxq = (float)((1 << (bits - 1)) - 1);
+    p.skip_col0 = skip_col0; p.x0_out = x0_out; p.scale_out = scale_out; p.out = out; p.K_pad = K_pad; p.ldo = ldo;
+    const size_t esz = (x_dtype == MQ_F32) ? 4 : 2;
+    p.vec_ok = (((uintptr_t)x) % 16 == 0) && ((ldx * esz) % 16 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    switch (x_dtype) {
+    case MQ_F16: hipLaunchKernelGGL(act_quant_dyn_kernel<MQ_F16>, dim3((unsigned)M), dim3(DQ_THREADS), 0, st, p); break;
+    case MQ_BF16: hipLaunchKernelGGL(act_quant_dyn_kernel<MQ_BF16>, dim3((unsigned)M), dim3(DQ_THREADS), 0, st, p); break;
+    case MQ_F32: hipLaunchKernelGGL(act_quant_dyn_kernel<MQ_F32>, dim3((unsigned)M), dim3(DQ_THREADS), 0, st, p); break;
+    default: return fail(MQ_EINVAL, "mq_quantize_act_dyn_i8: unknown dtype %d", x_dtype);
+    }
+    return check_launch("quantize_act_dyn_i8");
+}

@@ -54,6 +54,7 @@ struct GemmArgs {
     long n_pairs;  // ceil(N / 32): 16-channel tile pairs in the W4 image
     float sx0, sx1;
     const uint8_t *row_sel;
+    const float *sx_vec = nullptr;   // per-row activation scales (dynamic per-token quantizer); overrides sx0/sx1
     const float *s_w, *bias, *x0, *w0;
     void *out;
     long ldo;
@@ -190,7 +191,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][
             const long mr = m0 + (wm * TM + pass * PASS_MT) * 16 + lane;
             float sxl = p.sx0, xzl = 0.0f;
             if (mr < p.M) {
-                if (p.row_sel && p.row_sel[mr]) sxl = p.sx1;
+                if (p.sx_vec) sxl = p.sx_vec[mr];
+                else if (p.row_sel && p.row_sel[mr]) sxl = p.sx1;
                 if (p.x0) xzl = p.x0[mr];
             }
             rowpar[lane * 2] = sxl;
@@ -444,7 +446,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p)
         }
         float sx = p.sx0, xz = 0.0f;
         if (EPI != EPI_I32) {
-            if (p.row_sel && p.row_sel[m]) sx = p.sx1;
+            if (p.sx_vec) sx = p.sx_vec[m];
+            else if (p.row_sel && p.row_sel[m]) sx = p.sx1;
             if (p.x0) xz = p.x0[m];
         }
         store_quad<EPI>(p, m, n, a, sx, xz);
@@ -766,7 +769,7 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
                        long K_pad, float s_x0, float s_x1, const uint8_t *row_sel,
                        const float *s_w, const float *bias, const float *x0, const float *w0,
                        void *out, int epi, long ldo, void *workspace, size_t workspace_bytes,
-                       void *stream)
+                       void *stream, const float *sx_vec = nullptr)
 {
     MQ_REQUIRE(M >= 0 && N >= 0 && K_pad >= 0, "mq_gemm_w4a8: negative shape");
     if (M == 0 || N == 0) return MQ_OK;
@@ -787,6 +790,7 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
     p.n_tiles = ceil_div(N, 16);
     p.n_pairs = ceil_div(N, 32);
     p.sx0 = s_x0; p.sx1 = s_x1; p.row_sel = row_sel; p.s_w = s_w; p.bias = bias; p.x0 = x0; p.w0 = w0;
+    p.sx_vec = sx_vec;
     p.out = out; p.ldo = ldo;
     const Plan pl = make_plan(M, N, K_pad, workspace != nullptr, workspace_bytes, g_force_tile,
                               workspace ? g_force_splits : 0, w_bits == 4);
@@ -841,6 +845,18 @@ extern "C" int mq_gemm_w4a8_ws(const int8_t *a, long lda, const void *w, int w_b
         return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_ws: unknown output dtype %d", out_dtype);
     return mq::gemm_common(a, lda, w, w_bits, M, N, K_pad, s_x0, s_x1, row_sel, s_w, bias, x0, w0,
                            out, out_dtype, ldo, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mq_gemm_w4a8_rowscale_ws(const int8_t *a, long lda, const void *w, int w_bits, long M, long N,
+                                        long K_pad, const float *s_x_rows, const float *s_w, const float *bias,
+                                        const float *x0, const float *w0, void *out, int out_dtype, long ldo,
+                                        void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (out_dtype != MQ_F16 && out_dtype != MQ_BF16 && out_dtype != MQ_F32)
+        return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_rowscale_ws: unknown output dtype %d", out_dtype);
+    if (!s_x_rows) return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_rowscale_ws: s_x_rows is required");
+    return mq::gemm_common(a, lda, w, w_bits, M, N, K_pad, 1.0f, 1.0f, nullptr, s_w, bias, x0, w0,
+                           out, out_dtype, ldo, workspace, workspace_bytes, stream, s_x_rows);
 }
 
 extern "C" int mq_gemm_w4a8_i32(const int8_t *a, long lda, const void *w, int w_bits, long M,

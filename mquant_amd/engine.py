@@ -59,7 +59,7 @@ class W4A8Linear:
     def __init__(self, levels: torch.Tensor, s_w: torch.Tensor, w_bits: int,
                  bias: Optional[torch.Tensor], s_x0: float, s_x1: Optional[float] = None,
                  had: Optional[HadamardSpec] = None, w0: Optional[torch.Tensor] = None,
-                 in_features: Optional[int] = None):
+                 in_features: Optional[int] = None, dynamic: Optional[dict] = None):
         assert levels.is_cuda and levels.dtype == torch.int8 and levels.dim() == 2
         self.N, self.K = levels.shape
         self.K_pad = ops.ceil_to(self.K, 128)
@@ -72,6 +72,8 @@ class W4A8Linear:
         self.s_x0 = float(s_x0)
         self.s_x1 = None if s_x1 is None else float(s_x1)
         self.had = had
+        #: None = static scales; dict(bits=, clip_ratio=) = dynamic symmetric per-token quantizer
+        self.dynamic = dynamic
         self.in_features = self.K if in_features is None else in_features
         if had is not None:
             assert had.n == self.K, "Hadamard size must equal the (padded) reduction dim"
@@ -131,9 +133,22 @@ class W4A8Linear:
                              s_x1=self.s_x1, row_sel=row_sel, bias=self.bias, x0=x0, w0=self.w0,
                              out_dtype=out_dtype, out=out)
 
+    def forward_dynamic(self, x2: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """[Hadamard ->] dynamic per-token quantize -> GEMM with per-row scales.  The row maximum
+        needs the whole rotated row, so the Hadamard runs as its own launch here."""
+        if self.had is not None:
+            x2 = ops.hadamard(x2, self.had.n, self.had.K, self.had.bits, self.had.fp32_had)
+        a = WORKSPACE.act(x2.device, x2.shape[0], self.K_pad)
+        a, s_rows, x0 = ops.quantize_act_dyn_i8(x2, self.dynamic["bits"], self.dynamic["clip_ratio"],
+                                                skip_col0=self.split, out=a)
+        return ops.gemm_w4a8_rowscale(a, self.w_img, self.w_bits, self.N, s_rows, self.s_w, bias=self.bias,
+                                      x0=x0, w0=self.w0, out_dtype=x2.dtype, out=out)
+
     def forward(self, x: torch.Tensor, row_sel: Optional[torch.Tensor] = None,
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
         x2 = x.reshape(-1, x.shape[-1])
+        if self.dynamic is not None:
+            return self.forward_dynamic(x2, out).reshape(*x.shape[:-1], self.N)
         a, x0 = self.quantize(x2, row_sel)
         y = self.gemm(a, x0, x.dtype, row_sel, out)
         return y.reshape(*x.shape[:-1], self.N)

@@ -287,6 +287,41 @@ def gemm_w4a8(a: torch.Tensor, w_img: torch.Tensor, w_bits: int, N: int, s_x0: f
     return out
 
 
+def quantize_act_dyn_i8(x: torch.Tensor, bits: int = 8, clip_ratio: float = 1.0, *, skip_col0: bool = False,
+                        out: Optional[torch.Tensor] = None):
+    """Dynamic symmetric per-token quantizer (the reference's default activation mode).
+    Returns (int8 [M, ceil128(K)], per-row scales fp32 [M], column 0 as fp32 [M] | None)."""
+    x2 = _rows(x)
+    _need_cuda(x2, out)
+    M, K = x2.shape
+    K_pad = ceil_to(K, 128) if out is None else out.shape[1]
+    if out is None:
+        out = torch.empty((M, K_pad), dtype=torch.int8, device=x.device)
+    scale = torch.empty((M,), dtype=torch.float32, device=x.device)
+    x0 = torch.empty((M,), dtype=torch.float32, device=x.device) if skip_col0 else None
+    call("mq_quantize_act_dyn_i8", x2.data_ptr(), dtype_code(x2.dtype), M, K, x2.stride(0), int(bits),
+         float(clip_ratio), int(skip_col0), _ptr(x0), scale.data_ptr(), out.data_ptr(), K_pad, out.stride(0),
+         _stream())
+    return out, scale, x0
+
+
+def gemm_w4a8_rowscale(a: torch.Tensor, w_img: torch.Tensor, w_bits: int, N: int, s_x_rows: torch.Tensor,
+                       s_w: torch.Tensor, *, bias: Optional[torch.Tensor] = None, x0: Optional[torch.Tensor] = None,
+                       w0: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.float16,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _need_cuda(a, w_img, s_x_rows, s_w, bias, x0, w0, out)
+    assert a.dtype == torch.int8 and a.dim() == 2 and a.stride(1) == 1 and s_x_rows.dtype == torch.float32
+    M, K_pad = a.shape
+    assert s_x_rows.numel() == M and s_x_rows.is_contiguous()
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    ws = splitk_workspace(a.device)
+    call("mq_gemm_w4a8_rowscale_ws", a.data_ptr(), a.stride(0), w_img.data_ptr(), w_bits, M, N, K_pad,
+         s_x_rows.data_ptr(), s_w.data_ptr(), _ptr(bias), _ptr(x0), _ptr(w0), out.data_ptr(),
+         dtype_code(out.dtype), out.stride(0), _ptr(ws), 0 if ws is None else ws.numel(), _stream())
+    return out
+
+
 def gemm_w4a8_i32(a: torch.Tensor, w_img: torch.Tensor, w_bits: int, N: int,
                   use_workspace: bool = True) -> torch.Tensor:
     _need_cuda(a, w_img)

@@ -167,6 +167,15 @@ def epilogue(acc, sx0, s_w, bias=None, sx1=None, row_sel=None, x0=None, w0=None)
     acc = np.ascontiguousarray(acc, dtype=np.int32)
     M, N = acc.shape
     s_w = _f32(s_w).reshape(-1)
+    if np.ndim(sx0) == 1:
+        # one activation scale per row (dynamic per-token mode): same operation order, one fp32
+        # rounding per numpy operation
+        y = (acc.astype(np.float32) * _f32(sx0).reshape(-1, 1)) * s_w[None, :]
+        if bias is not None:
+            y = y + _f32(bias)[None, :]
+        if x0 is not None:
+            y = y + _f32(x0).reshape(-1, 1) * _f32(w0)[None, :]
+        return y.astype(np.float32)
     bias = _f32(bias)
     x0 = _f32(x0)
     w0 = _f32(w0)
@@ -200,6 +209,17 @@ def rmsn(x, mean_dim, eps=1e-5, mode=0):
     lib().orc_rmsn(_p(x, C.c_float), C.c_long(rows), C.c_long(cols), C.c_float(mean_dim), C.c_float(eps),
                    C.c_int(mode), _p(y, C.c_float))
     return y
+
+
+def quant_dyn(x, bits=8, clip=1.0, skip_col0=False):
+    """quant_utils.py:205-268: dynamic symmetric per-token -> (int8 levels, fp32 scale per row)."""
+    x = _f32(x)
+    rows, cols = x.shape
+    scale = np.empty(rows, dtype=np.float32)
+    q = np.empty((rows, cols), dtype=np.int8)
+    lib().orc_quant_dyn(_p(x, C.c_float), C.c_long(rows), C.c_long(cols), C.c_int(bits), C.c_float(clip),
+                        C.c_int(int(skip_col0)), _p(scale, C.c_float), _p(q, C.c_int8))
+    return q, scale
 
 
 def silu_mul(g, u, mode=0):

@@ -143,6 +143,29 @@ void orc_rmsn(const float *x, long rows, long cols, float mean_dim, float eps, i
     }
 }
 
+/* Dynamic symmetric per-token quantizer, quant_utils.py:205-268 (act_per_tensor = False,
+ * groupsize = -1) + sym_quant :46-50; fp32 arithmetic (the fp32 `tmp` of :239 promotes). */
+void orc_quant_dyn(const float *x, long rows, long cols, int bits, float clip, int skip_col0,
+                   float *scale, int8_t *q)
+{
+    const float maxq = (float)((1 << (bits - 1)) - 1);
+    for (long r = 0; r < rows; ++r) {
+        const float *h = x + r * cols;
+        float mn = 0.0f, mx = 0.0f;
+        for (long k = skip_col0 ? 1 : 0; k < cols; ++k) { if (h[k] < mn) mn = h[k]; if (h[k] > mx) mx = h[k]; }
+        const float xmin = mn * clip, xmax0 = mx * clip;
+        const float xmax = fmaxf(fabsf(xmin), xmax0);
+        const float s = (xmax == 0.0f) ? 1.0f : xmax / maxq;
+        scale[r] = s;
+        for (long k = 0; k < cols; ++k) {
+            float v = rintf(h[k] / s);
+            if (v < -(maxq + 1.0f)) v = -(maxq + 1.0f);
+            if (v > maxq) v = maxq;
+            q[r * cols + k] = (skip_col0 && k == 0) ? 0 : (int8_t)v;
+        }
+    }
+}
+
 /* uniform.py:35-43: x_hat = (q - zp) * s  (fp32) */
 void orc_dequant_static(const int8_t *q, long rows, long cols,
                         const float *scale0, const float *zp0,

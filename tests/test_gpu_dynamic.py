@@ -1,0 +1,97 @@
+"""Dynamic per-token activation mode on the real-integer path: mq_quantize_act_dyn_i8 +
+mq_gemm_w4a8_rowscale_ws against the oracle (bit-exact) and the wrapper against the reference's
+own forward in that mode (tests/golden/wrapper_dyn_*.npz)."""
+import functools
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from golden_inputs import make_w, make_x
+from test_oracle_golden import DYN_CASES
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+torch.set_grad_enabled(False)
+
+
+@pytest.mark.parametrize("M,K,dtype,bits,clip,skip", [(768, 3584, torch.float16, 8, 1.0, False), (33, 1000, torch.float16, 8, 0.9, True),
+                                                       (5, 19968, torch.bfloat16, 8, 1.0, False), (17, 260, torch.float32, 4, 1.0, False),
+                                                       (3, 32768, torch.float16, 8, 1.0, False)])
+def test_kernel_matches_oracle(M, K, dtype, bits, clip, skip):
+    from mquant_amd import ops
+    x = torch.from_numpy(make_x(M * 3 + K, (M, K))).to(device=DEV, dtype=dtype)
+    x[1] = 0                                                       # all-zero row: scale 1
+    q, s, x0 = ops.quantize_act_dyn_i8(x, bits, clip, skip_col0=skip)
+    q_ref, s_ref = oracle.quant_dyn(x.float().cpu().numpy(), bits=bits, clip=clip, skip_col0=skip)
+    np.testing.assert_array_equal(s.cpu().numpy(), s_ref)
+    np.testing.assert_array_equal(q.cpu().numpy()[:, :K], q_ref)
+    assert not q[:, K:].any() and float(s[1]) == 1.0
+    if skip:
+        np.testing.assert_array_equal(x0.cpu().numpy(), x[:, 0].float().cpu().numpy())
+
+
+def test_rowscale_gemm_matches_oracle_including_splitk():
+    from mquant_amd import ops
+    for M, K, N in ((64, 512, 96), (48, 19968, 256)):
+        x = torch.from_numpy(make_x(K, (M, K))).to(DEV).half()
+        w = torch.from_numpy(make_w(N, (N, K))).to(DEV).half()
+        s_w, levels, _, _ = ops.wquant_sym(w, 4)
+        a, s_rows, _ = ops.quantize_act_dyn_i8(x)
+        bias = torch.linspace(-1, 1, N, device=DEV)
+        y = ops.gemm_w4a8_rowscale(a, ops.prepack(levels, 4), 4, N, s_rows, s_w, bias=bias)
+        acc = oracle.gemm_i32(a.cpu().numpy()[:, :K], levels.cpu().numpy())
+        want = oracle.round_to(oracle.epilogue(acc, s_rows.cpu().numpy(), s_w.cpu().numpy(), bias=bias.cpu().numpy()), 1)
+        np.testing.assert_array_equal(y.float().cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("case", DYN_CASES)
+def test_wrapper_dynamic_mode_matches_reference_forward(golden_dir, case):
+    from fake_quant import hadamard_utils as hu, quant_utils as qu, utils
+    from fake_quant.gptq.rtn import rtn_module
+    from mquant_amd import ops
+    g = np.load(os.path.join(golden_dir, f"wrapper_dyn_{case}.npz"))
+    K_in, K_pad, N, M, seed, had, split, bias, a_bits = [int(v) for v in g["meta"]]
+    lin = torch.nn.Linear(K_pad, N, bias=bool(bias))
+    lin.weight.data = torch.from_numpy(make_w(seed, (N, K_pad)))
+    if bias:
+        lin.bias.data = torch.from_numpy(make_w(seed + 1, (N,), std=0.1))
+    wrap = qu.ActQuantWrapper(lin.to(DEV))
+    if had:
+        hadK, Kh = hu.get_hadK(K_pad)
+        wrap.online_full_had, wrap.had_K, wrap.K = True, hadK, Kh
+    if split:
+        wrap.split = True
+        wrap.split_weights()
+    if K_pad != K_in:
+        wrap.register_forward_pre_hook(functools.partial(utils.revise_down_input, new_size=K_pad))
+    quantizers = {}
+    rtn_module(wrap, "layer", 4, True, False, [], quantizers)
+    wrap.quantizer.configure(bits=a_bits, sym=True, clip_ratio=float(g["clip"]))
+    x = torch.from_numpy(make_x(seed + 20, (M, K_in))).to(DEV)
+    assert wrap._real_ready(x), "the dynamic mode must run the real kernels too"
+    y = wrap(x)
+    assert wrap._real is not None and wrap._real.dynamic is not None
+    np.testing.assert_allclose(y.cpu().numpy(), g["y"], rtol=0, atol=1e-3)
+    # the integers of the kernels that ran
+    real = wrap._real
+    xr = ops.hadamard(x, real.had.n, real.had.K, real.had.bits) if had else x
+    a, s_rows, _ = ops.quantize_act_dyn_i8(xr, a_bits, float(g["clip"]), skip_col0=bool(split))
+    np.testing.assert_array_equal(s_rows.cpu().numpy(), g["s_rows"])
+    np.testing.assert_array_equal(a.cpu().numpy()[:, 1 if split else 0:65 if split else 64], g["qx_head"])
+    np.testing.assert_array_equal(ops.gemm_w4a8_i32(a, real.w_img, 4, N).cpu().numpy(), g["acc"])
+
+
+def test_modes_the_kernels_do_not_cover_stay_on_the_simulated_path():
+    from fake_quant import quant_utils as qu
+    from fake_quant.gptq.rtn import rtn_module
+    lin = torch.nn.Linear(256, 32).to(DEV).half()
+    x = torch.from_numpy(make_x(1, (8, 256))).to(DEV).half()
+    for kw in (dict(bits=8, sym=False), dict(bits=8, sym=True, groupsize=128), dict(bits=16)):
+        wrap = qu.ActQuantWrapper(lin)
+        rtn_module(wrap, "l", 4, True, False, [], {})
+        wrap.quantizer.configure(**kw)
+        assert not wrap._real_ready(x)
+        assert torch.isfinite(wrap(x)).all()

@@ -196,3 +196,42 @@ def test_weight_quantizer_on_every_weight_dtype(golden_dir, case):
     np.testing.assert_array_equal(wq, g["wq"])
     if mse:
         assert (scale < oracle.wquant_sym(w, bits=bits, mse=False)[0]).sum() >= 2      # the search does clip
+
+
+def test_dynamic_per_token_quantizer_against_reference(golden_dir):
+    """quant_utils.py:205-268 (default activation mode): levels and per-row scales."""
+    g = np.load(os.path.join(golden_dir, "act_dynamic.npz"))
+    x = g["x"].reshape(-1, g["x"].shape[-1])
+    for tag, kw in (("tok_sym", dict(bits=8)), ("tok_sym4", dict(bits=4)), ("clip_sym", dict(bits=8, clip=0.9))):
+        q, s = oracle.quant_dyn(x, **kw)
+        np.testing.assert_array_equal((q.astype(np.float32) * s[:, None]).reshape(g["x"].shape), g[f"y_{tag}"], err_msg=tag)
+        np.testing.assert_array_equal(np.broadcast_to(s.reshape(g["x"].shape[:-1] + (1,)), g["x"].shape), g[f"scale_{tag}"])
+
+
+DYN_CASES = ["plain_3584", "clip_1280", "had_5120_split", "down_19968"]
+
+
+@pytest.mark.parametrize("case", DYN_CASES)
+def test_dynamic_wrapper_layer_against_reference(golden_dir, had_table, case):
+    """Whole layer in the dynamic mode: [pad, Hadamard,] per-token quantize, int GEMM, dequant."""
+    from golden_inputs import make_w, make_x
+    g = np.load(os.path.join(golden_dir, f"wrapper_dyn_{case}.npz"))
+    K_in, K_pad, N, M, seed, had, split, bias, a_bits = [int(v) for v in g["meta"]]
+    x = make_x(seed + 20, (M, K_in))
+    if had:
+        K = had_table["n2k"][K_pad]
+        x = oracle.hadamard(x, K_pad, K, had_table["mats"][K], mid_round=0, out_round=0)
+    q, s_rows = oracle.quant_dyn(x, bits=a_bits, clip=float(g["clip"]), skip_col0=bool(split))
+    np.testing.assert_array_equal(s_rows, g["s_rows"])
+    np.testing.assert_array_equal(q[:, 1 if split else 0:65 if split else 64], g["qx_head"])
+    W = make_w(seed, (N, K_pad))
+    Wsrc = W[:, 1:] if split else W
+    s_w, levels = oracle.wquant_sym(np.ascontiguousarray(Wsrc), bits=4)
+    np.testing.assert_array_equal(s_w, g["s_w"])
+    if split:
+        levels = np.concatenate([np.zeros((N, 1), np.int8), levels], axis=1)
+    acc = oracle.gemm_i32(q, levels)
+    np.testing.assert_array_equal(acc, g["acc"])
+    b = make_w(seed + 1, (N,), std=0.1) if bias else None
+    y = oracle.epilogue(acc, s_rows, s_w, bias=b, x0=x[:, 0] if split else None, w0=W[:, 0] if split else None)
+    np.testing.assert_allclose(y, g["y"], rtol=0, atol=1e-3)
