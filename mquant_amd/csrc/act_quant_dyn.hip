@@ -117,6 +117,7 @@ extern "C" int mq_quantize_act_dyn_i8(const void *x, int x_dtype, long M, long K
                                       int8_t *out, long K_pad, long ldo, void *stream)
 {
     using namespace mq;
+    if (M == 0) return MQ_OK;                       // empty input: nothing to do (null pointers allowed)
     MQ_REQUIRE(x && out && scale_out && M >= 0 && K > 0 && ldx >= K, "mq_quantize_act_dyn_i8: bad shape");
     MQ_REQUIRE(bits >= 2 && bits <= 8, "mq_quantize_act_dyn_i8: bits must be 2..8");
     MQ_REQUIRE(K <= 16L * DQ_THREADS * DQ_MAX_CHUNKS, "mq_quantize_act_dyn_i8: K=%ld too large (max %d)", K, 16 * DQ_THREADS * DQ_MAX_CHUNKS);

@@ -854,6 +854,7 @@ extern "C" int mq_gemm_w4a8_rowscale_ws(const int8_t *a, long lda, const void *w
 {
     if (out_dtype != MQ_F16 && out_dtype != MQ_BF16 && out_dtype != MQ_F32)
         return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_rowscale_ws: unknown output dtype %d", out_dtype);
+    if (M == 0 || N == 0) return MQ_OK;
     if (!s_x_rows) return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_rowscale_ws: s_x_rows is required");
     return mq::gemm_common(a, lda, w, w_bits, M, N, K_pad, 1.0f, 1.0f, nullptr, s_w, bias, x0, w0,
                            out, out_dtype, ldo, workspace, workspace_bytes, stream, s_x_rows);

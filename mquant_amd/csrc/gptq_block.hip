@@ -89,6 +89,7 @@ extern "C" int mq_gptq_block(const float *W1, long N, int cols, long ldw, const 
                              void *stream)
 {
     using namespace mq;
+    if (N == 0) return MQ_OK;                       // empty input: nothing to do (null pointers allowed)
     MQ_REQUIRE(W1 && Hinv1 && scale && Q1 && Err1, "mq_gptq_block: null argument");
     MQ_REQUIRE(N >= 0 && cols >= 1 && cols <= GB_COLS, "mq_gptq_block: cols must be 1..%d (got %d)", GB_COLS, cols);
     MQ_REQUIRE(ldw >= cols && ldh >= cols && ldq >= cols && lde >= cols, "mq_gptq_block: leading dimension < cols");

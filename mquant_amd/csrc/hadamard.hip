@@ -488,6 +488,7 @@ extern "C" int mq_act_hadamard_quant_i8(const void *x, const void *x2, int act, 
                                         void *stream)
 {
     using namespace mq;
+    if (M == 0) return MQ_OK;                       // empty input: nothing to do (null pointers allowed)
     MQ_REQUIRE(act == MQ_ACT_SILU_MUL || act == MQ_ACT_QUICK_GELU, "mq_act_hadamard_quant_i8: unknown activation %d", act);
     MQ_REQUIRE(act != MQ_ACT_SILU_MUL || x2 != nullptr, "mq_act_hadamard_quant_i8: silu(gate)*up needs the second operand");
     MQ_REQUIRE(K >= 1 && n % K == 0 && n / K >= 8, "mq_act_hadamard_quant_i8: n/K must be >= 8");

@@ -114,6 +114,7 @@ extern "C" int mq_rmsn_quantize_i8(const void *x, int x_dtype, long M, long K, l
                                    void *y_out, long ldy, int8_t *out, long K_pad, long ldo, void *stream)
 {
     using namespace mq;
+    if (M == 0) return MQ_OK;                       // empty input: nothing to do (null pointers allowed)
     MQ_REQUIRE(x && out && M >= 0 && K > 0 && ldx >= K, "mq_rmsn_quantize_i8: bad shape");
     MQ_REQUIRE(K % 16 == 0 && K <= 16L * RQ_THREADS * RQ_MAX_CHUNKS,
                "mq_rmsn_quantize_i8: K must be a multiple of 16 and <= %d (got %ld)", 16 * RQ_THREADS * RQ_MAX_CHUNKS, K);

@@ -164,6 +164,7 @@ extern "C" int mq_wquant_sym(const void *w, int w_dtype, long N, long K, long ld
                              uint8_t *packed, void *wq, long ldq, void *stream)
 {
     using namespace mq;
+    if (N == 0) return MQ_OK;                       // empty input: nothing to do (null pointers allowed)
     MQ_REQUIRE(w && scale && N >= 0 && K > 0 && ldw >= K, "mq_wquant_sym: bad shape");
     MQ_REQUIRE(bits >= 2 && bits <= 8, "mq_wquant_sym: bits must be 2..8 (got %d)", bits);
     MQ_REQUIRE(!packed || (bits == 4 && K % 2 == 0), "mq_wquant_sym: the int4 wire format needs bits == 4 and an even K");

@@ -206,7 +206,7 @@ def wquant_sym(w: torch.Tensor, bits: int = 4, mse: bool = False, norm: float = 
     """Symmetric per-output-channel weight quantizer in one launch (``mq_wquant_sym``).
     Returns (scale fp32 [N], levels int8 [N, K] | None, packed uint8 [N, K/2] | None, W~ | None)."""
     _need_cuda(w)
-    w2 = w.reshape(w.shape[0], -1)
+    w2 = w.flatten(1) if w.dim() > 1 else w.reshape(1, -1)
     if w2.stride(-1) != 1:
         w2 = w2.contiguous()
     N, K = w2.shape

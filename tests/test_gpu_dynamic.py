@@ -95,3 +95,24 @@ def test_modes_the_kernels_do_not_cover_stay_on_the_simulated_path():
         wrap.quantizer.configure(**kw)
         assert not wrap._real_ready(x)
         assert torch.isfinite(wrap(x)).all()
+
+
+def test_empty_inputs_are_accepted_everywhere():
+    """M == 0 / N == 0: every entry point returns without launching (reference: empty tensors pass)."""
+    from mquant_amd import ops
+    e16 = torch.empty((0, 256), device=DEV, dtype=torch.float16)
+    assert ops.quantize_act_dyn_i8(e16)[0].shape == (0, 256)
+    assert ops.rmsn_quantize_i8(e16, 256, 1e-6, 0.1)[0].shape == (0, 256)
+    assert ops.quantize_act_i8(e16, 0.1)[0].shape == (0, 256)
+    assert ops.hadamard_quant_i8(e16, 256, 1, None, 0.1)[0].shape == (0, 256)
+    assert ops.act_hadamard_quant_i8(e16, e16, ops.ACT_SILU_MUL, 256, 1, None, 0.1)[0].shape == (0, 256)
+    s, lv, pk, _ = ops.wquant_sym(torch.empty((0, 64), device=DEV), 4, want_packed=True)
+    assert s.numel() == 0 and lv.shape == (0, 64) and pk.shape == (0, 32)
+    w_img = ops.prepack(torch.zeros((32, 128), dtype=torch.int8, device=DEV), 4)
+    a = torch.empty((0, 128), dtype=torch.int8, device=DEV)
+    assert ops.gemm_w4a8(a, w_img, 4, 32, 0.1, torch.ones(32, device=DEV)).shape == (0, 32)
+    assert ops.gemm_w4a8_rowscale(a, w_img, 4, 32, torch.empty((0,), device=DEV), torch.ones(32, device=DEV)).shape == (0, 32)
+    W = torch.empty((0, 16), device=DEV)
+    ops.gptq_block(W, 0, 16, torch.eye(16, device=DEV), torch.empty((0,), device=DEV), 4, torch.empty((0, 16), device=DEV),
+                   torch.empty((0, 16), device=DEV))
+    torch.cuda.synchronize()

@@ -1,0 +1,96 @@
+"""The whole MQuant recipe on a toy Qwen2-VL (HF attribute layout) on the GPU, the way
+exam/quant_qwen2vl.py strings it together: LayerNorm fusion -> rotation (online Hadamard, padded
+down_proj) -> wrap -> online-Hadamard flags / split / pad hook -> RTN weight pass -> static
+calibration protocol (MSQ on the LLM) -> quantized forward.  The real W4A8 kernels must reproduce
+the simulated (fake-quant, torch) forward of the same wrappers, and both stay near the fp model."""
+import functools
+import types
+
+import pytest
+import torch
+
+import toy_models
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+torch.set_grad_enabled(False)
+
+
+class Args:
+    skip_names = []
+
+
+def build(inter, llm_split, visual_split, w_bits, msq):
+    from fake_quant import hadamard_utils as hu, quant_utils as qu, qwen2vl_rotation, utils
+    from fake_quant.gptq import qwen2vl_gptq_plus
+    model, pixels, ids = toy_models.build("qwen2vl", seed=21, inter=inter)
+    want = model(pixels, ids)
+    rargs = toy_models.rotation_args()
+    torch.manual_seed(4)
+    vlm = types.SimpleNamespace(model=model)
+    qwen2vl_rotation.fuse_qwen2vl_layer_norms(vlm, rargs)
+    qwen2vl_rotation.rotate_qwen2vl_model(model, rargs)
+    model = model.float().to(DEV)
+    vlm.model = model
+    qargs = types.SimpleNamespace(quant_llm=True, quant_visual_clip=True, quant_cross_attention=True,
+                                  act_per_tensor=False, visual_w_rtn=True, llm_w_rtn=True, visual_w_bits=w_bits,
+                                  llm_w_bits=w_bits, w_asym=False, visual_w_clip=False, llm_w_clip=False,
+                                  skip_names=[])
+    qu.qwen2vl_add_act_qaunt(vlm, qargs)
+    for name, w in qu.find_qlayers(model.model, [qu.ActQuantWrapper]).items():      # exam/quant_qwen2vl.py:107-127
+        if "mlp.down_proj" in name:
+            w.had_K, w.K = hu.get_hadK(model.config.intermediate_size)
+            w.online_full_had = True
+            w.split = llm_split
+            if llm_split:
+                w.split_weights()
+            if model.config.need_pad:
+                w.register_forward_pre_hook(functools.partial(utils.revise_down_input,
+                                                              new_size=model.config.intermediate_size))
+    for name, w in qu.find_qlayers(model.visual, [qu.ActQuantWrapper]).items():     # :129-143
+        if "mlp.fc2" in name:
+            w.had_K, w.K = hu.get_hadK(int(model.visual.blocks[0].mlp.fc2.module.in_features))
+            w.online_full_had = True
+            w.split = visual_split
+            if visual_split:
+                w.split_weights()
+    quantizers = qwen2vl_gptq_plus.qwen2vl_rtn_gptq_fwrd_plus(vlm, None, DEV, "toy", qargs)
+    wrappers = qu.find_qlayers(model, [qu.ActQuantWrapper])
+    assert len(quantizers) >= len(wrappers)            # split wrappers contribute ".module" and ".L2"
+    for name, w in wrappers.items():
+        w.quantizer.configure(bits=8, sym=True, static=True, msq=msq and name.startswith("model."))
+    return model, wrappers, pixels.float().to(DEV), ids.to(DEV), want
+
+
+def calibrate(model, pixels, ids, mask):
+    from fake_quant import quant_utils as qu
+    g = torch.Generator(device="cpu").manual_seed(0)
+    with qu.token_type_mask(mask):
+        qu.model_open_calibrate(model, Args())
+        for i in range(3):
+            if i == 2:
+                qu.model_open_last_calibrate(model, Args())
+            model(pixels + 0.05 * torch.randn(pixels.shape, generator=g).to(DEV), ids)
+        qu.model_close_calibrate(model, Args())
+        qu.model_quant(model, Args())
+
+
+@pytest.mark.parametrize("inter,llm_split,visual_split,w_bits,msq", [(96, False, False, 8, False), (88, True, True, 8, True),
+                                                                     (96, False, True, 4, True)])
+def test_quantized_toy_model_real_kernels_equal_simulation(inter, llm_split, visual_split, w_bits, msq):
+    from fake_quant import quant_utils as qu
+    model, wrappers, pixels, ids, want = build(inter, llm_split, visual_split, w_bits, msq)
+    assert model.config.need_pad == (inter == 88)
+    mask = torch.tensor([0, 0, 1, 1, 1, 1, 1], device=DEV)          # 2 merged vision tokens, 5 text tokens
+    calibrate(model, pixels, ids, mask)
+    with qu.token_type_mask(mask):
+        real = model(pixels, ids)
+        used = [n for n, w in wrappers.items() if w._real is not None]
+        assert len(used) == len(wrappers), sorted(set(wrappers) - set(used))   # every wrapped layer ran the kernels
+        for w in wrappers.values():
+            w.real_quant = False
+        sim = model(pixels, ids)
+    # same integer grids, different evaluation order of the dequantised products
+    torch.testing.assert_close(real, sim, rtol=0, atol=2e-3 * float(sim.abs().max()))
+    err = float((real.double().cpu() - want).norm() / want.norm())
+    assert err < (0.05 if w_bits == 8 else 0.35), err

@@ -1,0 +1,7 @@
+#!/bin/bash
+# per-kernel rocprof durations of tools/had_bench.py (optionally with MQUANT_HIP_LIB set by the caller)
+cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+rm -rf gpurun_out/hp; mkdir -p gpurun_out/hp
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/hp -o t -- python3 tools/had_bench.py > gpurun_out/hp/log 2>&1
+python3 tools/trace_summary.py gpurun_out/hp/t_kernel_trace.csv | grep "hadamard"
+rm -f gpurun_out/hp/t_kernel_trace.csv
