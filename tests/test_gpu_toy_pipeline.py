@@ -94,3 +94,76 @@ def test_quantized_toy_model_real_kernels_equal_simulation(inter, llm_split, vis
     torch.testing.assert_close(real, sim, rtol=0, atol=2e-3 * float(sim.abs().max()))
     err = float((real.double().cpu() - want).norm() / want.norm())
     assert err < (0.05 if w_bits == 8 else 0.35), err
+
+
+# ------------------------------------------------------------------ the other model families
+FAMILIES = {
+    # kind: (fuse, rotate, takes_wrapper_for_fuse, add_actquant, weight pass, LLM out-proj tag, ViT out-proj tag)
+    "internvl": ("internvl_rotation.fuse_internvl_layer_norms", "internvl_rotation.rotate_internvl2_model", True,
+                 "internvl_add_act_qaunt", "internvl_gptq_plus.internvl_rtn_gptq_fwrd_plus", "feed_forward.w2", "mlp.fc2"),
+    "qwenvl": ("rotation_utils.fuse_qwenvl_layer_norms", "rotation_utils.rotate_model", False,
+               "qwenvl_add_act_qaunt", "qwenvl_gptq_plus.qwenvl_rtn_gptq_fwrd_plus", "mlp.c_proj", "mlp.c_proj"),
+}
+
+
+def _resolve(path):
+    import importlib
+    mod, fn = path.rsplit(".", 1)
+    pkg = "fake_quant.gptq." if mod.endswith("_gptq_plus") else "fake_quant."
+    return getattr(importlib.import_module(pkg + mod), fn)
+
+
+@pytest.mark.parametrize("kind,split", [("internvl", False), ("internvl", True), ("qwenvl", False), ("qwenvl", True)])
+def test_other_model_families_run_the_real_kernels(kind, split):
+    from fake_quant import hadamard_utils as hu, quant_utils as qu
+    fuse, rotate, fuse_takes_wrapper, add_act, weight_pass, llm_tag, vit_tag = FAMILIES[kind]
+    model, pixels, ids = toy_models.build(kind, seed=33)
+    rargs = toy_models.rotation_args()
+    torch.manual_seed(5)
+    vlm = types.SimpleNamespace(model=model)
+    _resolve(fuse)(vlm if fuse_takes_wrapper else model, rargs)
+    want = model(pixels, ids)                                  # fused fp model (fusion is approximate upstream)
+    _resolve(rotate)(model, rargs)
+    model = model.float().to(DEV)
+    vlm.model = model
+    qargs = types.SimpleNamespace(quant_llm=True, quant_visual_clip=True, quant_cross_attention=True,
+                                  act_per_tensor=False, visual_w_rtn=True, llm_w_rtn=True, visual_w_bits=8,
+                                  llm_w_bits=8, w_asym=False, visual_w_clip=False, llm_w_clip=False,
+                                  skip_names=[], dataset_name="toy")
+    getattr(qu, add_act)(vlm if kind == "internvl" else model, qargs)
+    wrappers = qu.find_qlayers(model, [qu.ActQuantWrapper])
+    rotated = 0
+    for name, w in wrappers.items():
+        is_llm = name.startswith(("language_model.", "transformer.h."))
+        tag = llm_tag if is_llm else vit_tag
+        if tag in name and "attn" not in name.split(tag)[0].rsplit(".", 2)[-1]:
+            if kind == "qwenvl" and not (("transformer.h" in name) or ("transformer.resblock" in name)):
+                continue
+            w.had_K, w.K = hu.get_hadK(w.module.in_features)
+            w.online_full_had = True
+            w.split = split
+            if split:
+                w.split_weights()
+            rotated += 1
+    assert rotated == 4                                        # 2 ViT blocks + 2 LLM layers
+    if kind == "internvl":
+        _resolve(weight_pass)(vlm, None, DEV, "toy", qargs)
+    else:
+        _resolve(weight_pass)(vlm, None, DEV, qargs)
+    for name, w in wrappers.items():
+        w.quantizer.configure(bits=8, sym=True, static=True)
+    pixels, ids = pixels.float().to(DEV), ids.to(DEV)
+    qu.model_open_calibrate(model, Args())
+    model(pixels, ids)
+    qu.model_open_last_calibrate(model, Args())
+    model(pixels * 1.01, ids)
+    qu.model_close_calibrate(model, Args())
+    qu.model_quant(model, Args())
+    real = model(pixels, ids)
+    missing = [n for n, w in wrappers.items() if w._real is None]
+    assert not missing, missing
+    for w in wrappers.values():
+        w.real_quant = False
+    sim = model(pixels, ids)
+    torch.testing.assert_close(real, sim, rtol=0, atol=2e-3 * float(sim.abs().max()))
+    assert float((real.double().cpu() - want).norm() / want.norm()) < 0.08
