@@ -716,6 +716,8 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
     return pl;
 }
 
+// Shapes that were measured and dropped (no gain): LDS-DMA issue positions, 2x8 / 8x2
+// wave layouts, rings of 4-8 stages, 64x256, 128x64, 128x256.
 template <int W_BITS, int EPI>
 static int dispatch_tile(const GemmArgs &p, int tile, hipStream_t st)
 {
@@ -728,35 +730,13 @@ static int dispatch_tile(const GemmArgs &p, int tile, hipStream_t st)
         if constexpr (W_BITS == 4) return launch_gemm<256, 256, 4, 4, 3, W_BITS, EPI>(p, st);
         else return launch_gemm<256, 128, 4, 2, 3, W_BITS, EPI>(p, st);
     case 4: return launch_gemm<128, 256, 2, 4, 3, W_BITS, EPI>(p, st);
-    case 6: if constexpr (W_BITS == 4) return launch_gemm<256, 256, 4, 4, 3, W_BITS, EPI, 0>(p, st); else break;
-    case 7: if constexpr (W_BITS == 4) return launch_gemm<256, 256, 4, 4, 3, W_BITS, EPI, 2>(p, st); else break;
-    case 8: if constexpr (W_BITS == 4) return launch_gemm<256, 256, 2, 4, 3, W_BITS, EPI, 0>(p, st); else break;
-    case 9: if constexpr (W_BITS == 4) return launch_gemm<256, 256, 2, 4, 3, W_BITS, EPI, 2>(p, st); else break;
     case 5: return launch_gemm<256, 128, 2, 4, 3, W_BITS, EPI>(p, st);
     case 13: if constexpr (W_BITS == 4) return launch_gemm_pipe<EPI>(p, st); else break;
-    case 14: if constexpr (W_BITS == 4) return launch_gemm<256, 256, 2, 8, 3, W_BITS, EPI>(p, st); else break;
-    case 15: if constexpr (W_BITS == 4) return launch_gemm<256, 256, 8, 2, 3, W_BITS, EPI>(p, st); else break;
     case 10: return launch_gemm<64, 128, 2, 2, 3, W_BITS, EPI>(p, st);
     case 11: return launch_gemm<128, 64, 2, 2, 3, W_BITS, EPI>(p, st);
     case 12: return launch_gemm<128, 128, 4, 2, 3, W_BITS, EPI>(p, st);
-    case 16: return launch_gemm<64, 128, 2, 2, 4, W_BITS, EPI>(p, st);
-    case 17: return launch_gemm<64, 128, 2, 2, 5, W_BITS, EPI>(p, st);
-    case 18: return launch_gemm<64, 128, 2, 2, 6, W_BITS, EPI>(p, st);
-    case 19: return launch_gemm<64, 128, 2, 2, 8, W_BITS, EPI>(p, st);
-    case 20: return launch_gemm<128, 128, 4, 2, 4, W_BITS, EPI>(p, st);
-    case 21: return launch_gemm<128, 128, 4, 2, 6, W_BITS, EPI>(p, st);
-    case 22: return launch_gemm<128, 128, 2, 2, 5, W_BITS, EPI>(p, st);
-    case 23: return launch_gemm<64, 64, 2, 2, 8, W_BITS, EPI>(p, st);
-    case 24: return launch_gemm<128, 64, 2, 2, 6, W_BITS, EPI>(p, st);
-    case 25: return launch_gemm<64, 128, 1, 4, 3, W_BITS, EPI>(p, st);
     case 26: return launch_gemm<128, 128, 2, 4, 3, W_BITS, EPI>(p, st);
-    case 27: return launch_gemm<128, 128, 1, 4, 3, W_BITS, EPI>(p, st);
-    case 28: return launch_gemm<128, 64, 2, 2, 3, W_BITS, EPI>(p, st);
-    case 29: return launch_gemm<128, 256, 2, 4, 3, W_BITS, EPI>(p, st);
-    case 30: return launch_gemm<96, 128, 2, 2, 3, W_BITS, EPI>(p, st);
     case 31: return launch_gemm<96, 128, 1, 4, 3, W_BITS, EPI>(p, st);
-    case 33: if constexpr (W_BITS == 4) return launch_gemm<64, 256, 1, 4, 3, W_BITS, EPI>(p, st); else break;
-    case 34: if constexpr (W_BITS == 4) return launch_gemm<64, 256, 2, 4, 3, W_BITS, EPI>(p, st); else break;
     case 35: if constexpr (W_BITS == 4) return launch_gemm<192, 128, 2, 4, 3, W_BITS, EPI>(p, st); else break;
     default: break;
     }

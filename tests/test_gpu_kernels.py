@@ -300,3 +300,32 @@ def test_errors_are_loud():
         ops().gemm_w4a8_i32(a, torch.zeros(4096, dtype=torch.uint8, device=DEV), 4, 16)
     with pytest.raises(MQuantHipError):
         ops().hadamard(torch.zeros((2, 24), dtype=torch.float16, device=DEV), 24, 5, None)
+
+
+@pytest.mark.parametrize("w_bits", [4, 8])
+def test_every_tile_shape_and_split_factor_is_exact(w_bits):
+    """All template instantiations behind dispatch_tile (the plan picks among them by shape), with
+    and without split-K, on a ragged problem: int32 accumulators and the fp16 epilogue."""
+    from mquant_amd import ops
+    M, N, K = 300, 520, 1408
+    rng = np.random.default_rng(7)
+    a = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+    lim = 8 if w_bits == 4 else 128
+    w = rng.integers(-lim, lim, size=(N, K), dtype=np.int8)
+    s_w = rng.uniform(0.001, 0.01, size=N).astype(np.float32)
+    bias = rng.normal(size=N).astype(np.float32)
+    acc_ref = oracle.gemm_i32(a, w)
+    y_ref = oracle.round_to(oracle.epilogue(acc_ref, np.float32(0.02), s_w, bias=bias), 1)
+    at, img = to_dev(a), ops.prepack(to_dev(w), w_bits)
+    swt, bt = to_dev(s_w), to_dev(bias)
+    ops.splitk_workspace(torch.device(DEV), 64 << 20)
+    try:
+        for tile in (0, 1, 2, 3, 4, 5, 10, 11, 12, 13, 26, 31, 35):
+            for splits in (1, 3):
+                ops.gemm_debug_force(tile, splits)
+                acc = ops.gemm_w4a8_i32(at, img, w_bits, N)
+                np.testing.assert_array_equal(acc.cpu().numpy(), acc_ref, err_msg=f"tile {tile} splits {splits}")
+                y = ops.gemm_w4a8(at, img, w_bits, N, 0.02, swt, bias=bt)
+                np.testing.assert_array_equal(y.float().cpu().numpy(), y_ref, err_msg=f"tile {tile} splits {splits}")
+    finally:
+        ops.gemm_debug_force(-1, 0)
