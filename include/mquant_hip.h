@@ -114,8 +114,10 @@ int mq_hadamard_quant_i8(const void *x, int x_dtype, long M, long n_in, long ldx
  *   act == 1 (MQ_ACT_SILU_MUL):   cast(cast(x / (1 + exp(-x))) * x2)   x = gate, x2 = up (same ldx)
  *   act == 2 (MQ_ACT_QUICK_GELU): cast(x * cast(1 / (1 + exp(-cast(1.702 x)))))
  * i.e. torch's F.silu(gate) * up / QuickGELUActivation on tensors of x_dtype (fp32 inside an op,
- * one rounding per op); exp is evaluated library-free (<= 1 ulp fp32; oracle: orc_silu_mul /
- * orc_quick_gelu).  Everything after that is mq_hadamard_quant_i8.  Requires n/K >= 8. */
+ * one rounding per op, the device library's expf): bit-identical to running those torch ops on
+ * this GPU and then mq_hadamard_quant_i8 (checked at full size in fp16, bf16 and fp32).  These
+ * activations are HF model code, not MQuant's; the C oracle restates them with a correctly rounded
+ * exp and agrees up to that last bit.  Requires n/K >= 8. */
 int mq_act_hadamard_quant_i8(const void *x, const void *x2, int act, int x_dtype, long M,
                              long n_in, long ldx, long n, int K, const uint32_t *had_words,
                              int fp32_had, float scale0, float scale1, const uint8_t *row_sel,

@@ -43,6 +43,7 @@ struct HadArgs {
     int8_t *qout;
     long K_pad, ldq;
     int vec_ok;
+    int vec_ok2;       // same for x2
     float inv_sqrt_n;  // 1.0f / sqrtf((float)n), computed on the host in IEEE fp32
     int row_bytes;     // LDS bytes per k-row of the staged copy
     int swz;           // XOR-swizzle odd k-rows by 128 B (row_bytes % 256 == 0)
@@ -160,7 +161,9 @@ __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
         // ---------------- A: butterflies ------------------------------------------------
         if (m >= 8) {
             const long nchunks = ceil_div(n, 512);
-            constexpr int NB = 4;   // chunks whose global loads are in flight together
+            // chunks whose global loads are in flight together; the activation prologue holds two
+            // operands per chunk and must stay within 80 VGPRs (three workgroups per CU)
+            constexpr int NB = ACT ? 2 : 4;
             for (long cb = wave; cb < nchunks; cb += HAD_WAVES * NB) {
               float vb[NB][8];
 #pragma unroll
@@ -185,8 +188,21 @@ __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
                     float ub[8];
                     if (p.act == MQ_ACT_SILU_MUL) {
                         const T *ur = reinterpret_cast<const T *>(p.x2) + row * p.ldx;
+                        if (idx + 8 <= p.n_in && p.vec_ok2) {
+                            if (sizeof(T) == 2) {
+                                const v8us a = *reinterpret_cast<const v8us *>(ur + idx);
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) ub[i] = (idx + i < p.n_in) ? Elem<DT>::ld(ur[idx + i]) : 0.0f;
+                                for (int i = 0; i < 8; ++i) ub[i] = Elem<DT>::ld((T)a[i]);
+                            } else {
+                                const v4f a = *reinterpret_cast<const v4f *>((const float *)ur + idx);
+                                const v4f b = *reinterpret_cast<const v4f *>((const float *)ur + idx + 4);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) { ub[i] = a[i]; ub[4 + i] = b[i]; }
+                            }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) ub[i] = (idx + i < p.n_in) ? Elem<DT>::ld(ur[idx + i]) : 0.0f;
+                        }
                     }
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
@@ -430,6 +446,7 @@ static int hadamard_common(HadArgs p, int x_dtype, bool quant, void *stream)
     MQ_REQUIRE(p.ldx >= p.n_in, "mq_hadamard: ldx < n_in");
     const size_t esz = (x_dtype == MQ_F32) ? 4 : 2;
     p.vec_ok = (((uintptr_t)p.x) % 16 == 0) && ((p.ldx * esz) % 16 == 0);
+    p.vec_ok2 = p.x2 && (((uintptr_t)p.x2) % 16 == 0) && ((p.ldx * esz) % 16 == 0);
     hipStream_t st = (hipStream_t)stream;
     if (quant) {
         MQ_REQUIRE(p.qout && p.K_pad >= p.n && p.ldq >= p.K_pad, "mq_hadamard_quant_i8: bad output geometry");

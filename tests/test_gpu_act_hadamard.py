@@ -1,6 +1,7 @@
 """mq_act_hadamard_quant_i8: silu(gate)*up / quick_gelu fused in front of the online Hadamard +
-quantizer.  Oracle-exact; equal to the torch composition followed by the unfused
-kernel except where torch's own exp differs in the last bit."""
+quantizer.  These activations are torch / HF code, not MQuant's: the bar is the torch
+composition on the same GPU followed by the unfused kernel, bit for bit (the fused kernel calls the
+same device expf).  The C oracle (library-free exp) agrees up to its last-bit freedom."""
 import numpy as np
 import pytest
 import torch
@@ -31,10 +32,12 @@ def test_silu_mul_prologue(had_table, M, n_in, n, K, dtype):
     h = oracle.silu_mul(g.float().cpu().numpy(), u.float().cpu().numpy(), mode).reshape(M, n_in)
     rot = oracle.hadamard(h, n, K, had_table["mats"].get(K), mid_round=mode, out_round=mode)
     want = oracle.quant_static(rot, np.float32(s0), scale1=np.float32(s1), row_sel=sel.cpu().numpy())
-    np.testing.assert_array_equal(q.cpu().numpy()[:, :n], want)
-    # the torch composition (its exp may differ in the last fp32 bit -> rare 1-level flips)
+    # the torch ops this launch replaces: identical
     ref, _ = ops.hadamard_quant_i8((torch.nn.functional.silu(g) * u).contiguous(), n, K, bits, s0, s1, row_sel=sel)
-    assert float((q != ref).float().mean()) < 1e-3 and int((q.int() - ref.int()).abs().max()) <= 1
+    assert torch.equal(q, ref)
+    # the CPU oracle (its exp is correctly rounded, the device library's is not always)
+    got = q.cpu().numpy()[:, :n]
+    assert (got != want).mean() < 1e-3 and np.abs(got.astype(np.int32) - want).max() <= 1
 
 
 def test_quick_gelu_prologue_with_split(had_table):
@@ -47,8 +50,12 @@ def test_quick_gelu_prologue_with_split(had_table):
     rot = oracle.hadamard(h, n, K, had_table["mats"][K], mid_round=1, out_round=1)
     want = oracle.quant_static(rot, np.float32(0.04))
     want[:, 0] = 0
-    np.testing.assert_array_equal(q.cpu().numpy()[:, :n], want)
-    np.testing.assert_array_equal(x0.cpu().numpy(), rot[:, 0])
+    ref, x0_ref = ops.hadamard_quant_i8((x * torch.sigmoid(1.702 * x)).contiguous(), n, K, words(had_table, K), 0.04,
+                                        skip_col0=True)
+    assert torch.equal(q, ref) and torch.equal(x0, x0_ref)
+    got = q.cpu().numpy()[:, :n]
+    assert (got != want).mean() < 1e-3 and np.abs(got.astype(np.int32) - want).max() <= 1
+    np.testing.assert_allclose(x0.cpu().numpy(), rot[:, 0], rtol=0, atol=2e-3)
 
 
 def test_engine_forward_from_the_fused_gate_up_output(had_table):
@@ -60,8 +67,7 @@ def test_engine_forward_from_the_fused_gate_up_output(had_table):
     lin = W4A8Linear.from_float(w, 4, s_x0=0.03, had=HadamardSpec(n, K, words(had_table, K)), in_features=n_in)
     a, x0 = lin.quantize_act(gu[:, :n_in], gu[:, n_in:], ops.ACT_SILU_MUL)
     fused = lin.gemm(a, x0, torch.float16).clone()
-    h = oracle.silu_mul(gu[:, :n_in].float().cpu().numpy(), gu[:, n_in:].float().cpu().numpy(), 1).reshape(M, n_in)
-    unfused = lin(torch.from_numpy(h).to(DEV).half())
+    unfused = lin((torch.nn.functional.silu(gu[:, :n_in]) * gu[:, n_in:]).contiguous())
     torch.testing.assert_close(fused, unfused, rtol=0, atol=0)
 
 
