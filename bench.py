@@ -106,8 +106,8 @@ def full_prefill_report(pf, dev, args):
         med_u, p90_u, _, _ = measure(False)
         med, p90, iters, finite = measure(True)
         return {"what": "whole synthetic prefill: W4A8 Linears (this repo's kernels) + torch glue (RoPE, SDPA, "
-                        "residuals, fp16 lm_head on the last position); RMS norm -> quantize and "
-                        "SiLU*up / QuickGELU -> Hadamard -> quantize run as single fused launches",
+                        "fp16 lm_head on the last position); RMS norm -> quantize, SiLU*up / QuickGELU -> "
+                        "Hadamard -> quantize and the residual adds (GEMM epilogue) run fused",
                 "ttft_ms_median": round(med, 4), "ttft_ms_p90": round(p90, 4), "iters": iters,
                 "ttft_ms_median_unfused_glue": round(med_u, 4), "ttft_ms_p90_unfused_glue": round(p90_u, 4),
                 "llm_tokens_per_s": round(workload.M_LLM / (med * 1e-3), 1),

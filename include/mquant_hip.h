@@ -228,6 +228,17 @@ int mq_gemm_w4a8(const int8_t *a, long lda, const void *w, int w_bits,
                  const float *x0, const float *w0,
                  void *out, int out_dtype, long ldo, void *stream);
 
+/* Same GEMM with the residual add of the surrounding block folded into the epilogue:
+ *   out[m][n] = cast(cast(y[m][n]) + residual[m][n])
+ * i.e. torch's `hidden + linear(x)` on tensors of out_dtype (the Linear's output is rounded to
+ * out_dtype before the add).  residual: [M, ldr] in out_dtype; may alias out (each element is read
+ * and written by the same lane). */
+int mq_gemm_w4a8_residual_ws(const int8_t *a, long lda, const void *w, int w_bits, long M, long N,
+                             long K_pad, float s_x0, float s_x1, const uint8_t *row_sel,
+                             const float *s_w, const float *bias, const float *x0, const float *w0,
+                             const void *residual, long ldr, void *out, int out_dtype, long ldo,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
 /* Same GEMM with one activation scale PER ROW (s_x_rows[m], from mq_quantize_act_dyn_i8) instead of
  * the static scale set(s):  y[m][n] = ((float(acc) * s_x_rows[m]) * s_w[n]) + bias[n] + x0[m]*w0[n]. */
 int mq_gemm_w4a8_rowscale_ws(const int8_t *a, long lda, const void *w, int w_bits, long M, long N,

@@ -55,12 +55,15 @@ struct GemmArgs {
     float sx0, sx1;
     const uint8_t *row_sel;
     const float *sx_vec = nullptr;   // per-row activation scales (dynamic per-token quantizer); overrides sx0/sx1
+    const void *residual = nullptr;  // [M, ldr] in the output dtype: out = cast(cast(y) + residual)
+    long ldr = 0;
     const float *s_w, *bias, *x0, *w0;
     void *out;
     long ldo;
     int splits;        // split-K factor (1 = none)
     int vec_ok;        // N, ldo multiples of 8 and a 16-byte aligned output
     int par_ok;        // s_w / bias / w0 16-byte aligned
+    int res_vec;       // residual rows 16-byte aligned
     int32_t *partial;  // [splits][M][N] when splits > 1
 };
 
@@ -93,6 +96,19 @@ __device__ __forceinline__ void store_quad(const GemmArgs &p, long m, long n, v4
             t = t + pr;
         }
         y[r] = t;
+    }
+    if (p.residual) {   // torch: hidden + linear(x): the Linear's output is rounded first
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (n + r >= p.N) continue;
+            if (EPI == EPI_F32) {
+                y[r] = y[r] + reinterpret_cast<const float *>(p.residual)[m * p.ldr + n + r];
+            } else {
+                const unsigned short rb = reinterpret_cast<const unsigned short *>(p.residual)[m * p.ldr + n + r];
+                y[r] = (EPI == EPI_F16) ? f16_bits_to_f32(f32_to_f16_bits(y[r])) + f16_bits_to_f32(rb)
+                                        : bf16_bits_to_f32(f32_to_bf16_bits(y[r])) + bf16_bits_to_f32(rb);
+            }
+        }
     }
     if (EPI == EPI_F32) {
         float *o = reinterpret_cast<float *>(p.out) + m * p.ldo + n;
@@ -225,6 +241,28 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][
             }
             const float sx = rowpar[row * 2];
             const float xz = rowpar[row * 2 + 1];
+            float res[8];
+            if (p.residual) {   // issued ahead of the arithmetic below
+                if (EPI == EPI_F32) {
+                    const float *rp = reinterpret_cast<const float *>(p.residual) + m * p.ldr + n;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) res[e] = (n + e < p.N) ? rp[e] : 0.0f;
+                } else {
+                    const unsigned short *rp = reinterpret_cast<const unsigned short *>(p.residual) + m * p.ldr + n;
+                    if (n_full && p.res_vec) {
+                        const v8us rv = *reinterpret_cast<const v8us *>(rp);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            res[e] = (EPI == EPI_F16) ? f16_bits_to_f32(rv[e]) : bf16_bits_to_f32(rv[e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const unsigned short rb = (n + e < p.N) ? rp[e] : (unsigned short)0;
+                            res[e] = (EPI == EPI_F16) ? f16_bits_to_f32(rb) : bf16_bits_to_f32(rb);
+                        }
+                    }
+                }
+            }
             float y[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -234,6 +272,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][
                 if (p.x0) {
                     const float pr = xz * wzv[e];
                     t = t + pr;
+                }
+                if (p.residual) {   // torch: hidden + linear(x), the Linear's output rounded first
+                    if (EPI == EPI_F16) t = f16_bits_to_f32(f32_to_f16_bits(t));
+                    if (EPI == EPI_BF16) t = bf16_bits_to_f32(f32_to_bf16_bits(t));
+                    t = t + res[e];
                 }
                 y[e] = t;
             }
@@ -749,7 +792,8 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
                        long K_pad, float s_x0, float s_x1, const uint8_t *row_sel,
                        const float *s_w, const float *bias, const float *x0, const float *w0,
                        void *out, int epi, long ldo, void *workspace, size_t workspace_bytes,
-                       void *stream, const float *sx_vec = nullptr)
+                       void *stream, const float *sx_vec = nullptr, const void *residual = nullptr,
+                       long ldr = 0)
 {
     MQ_REQUIRE(M >= 0 && N >= 0 && K_pad >= 0, "mq_gemm_w4a8: negative shape");
     if (M == 0 || N == 0) return MQ_OK;
@@ -771,6 +815,9 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
     p.n_pairs = ceil_div(N, 32);
     p.sx0 = s_x0; p.sx1 = s_x1; p.row_sel = row_sel; p.s_w = s_w; p.bias = bias; p.x0 = x0; p.w0 = w0;
     p.sx_vec = sx_vec;
+    p.residual = residual; p.ldr = ldr;
+    MQ_REQUIRE(!residual || (epi != EPI_I32 && ldr >= N), "mq_gemm_w4a8: bad residual geometry");
+    p.res_vec = residual && (((uintptr_t)residual) % 16 == 0) && ((ldr * ((epi == EPI_F32) ? 4 : 2)) % 16 == 0);
     p.out = out; p.ldo = ldo;
     const Plan pl = make_plan(M, N, K_pad, workspace != nullptr, workspace_bytes, g_force_tile,
                               workspace ? g_force_splits : 0, w_bits == 4);
@@ -825,6 +872,20 @@ extern "C" int mq_gemm_w4a8_ws(const int8_t *a, long lda, const void *w, int w_b
         return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_ws: unknown output dtype %d", out_dtype);
     return mq::gemm_common(a, lda, w, w_bits, M, N, K_pad, s_x0, s_x1, row_sel, s_w, bias, x0, w0,
                            out, out_dtype, ldo, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mq_gemm_w4a8_residual_ws(const int8_t *a, long lda, const void *w, int w_bits, long M, long N,
+                                        long K_pad, float s_x0, float s_x1, const uint8_t *row_sel,
+                                        const float *s_w, const float *bias, const float *x0, const float *w0,
+                                        const void *residual, long ldr, void *out, int out_dtype, long ldo,
+                                        void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (out_dtype != MQ_F16 && out_dtype != MQ_BF16 && out_dtype != MQ_F32)
+        return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_residual_ws: unknown output dtype %d", out_dtype);
+    if (M == 0 || N == 0) return MQ_OK;
+    if (!residual) return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_residual_ws: residual is required");
+    return mq::gemm_common(a, lda, w, w_bits, M, N, K_pad, s_x0, s_x1, row_sel, s_w, bias, x0, w0,
+                           out, out_dtype, ldo, workspace, workspace_bytes, stream, nullptr, residual, ldr);
 }
 
 extern "C" int mq_gemm_w4a8_rowscale_ws(const int8_t *a, long lda, const void *w, int w_bits, long M, long N,

@@ -133,6 +133,12 @@ class W4A8Linear:
                              s_x1=self.s_x1, row_sel=row_sel, bias=self.bias, x0=x0, w0=self.w0,
                              out_dtype=out_dtype, out=out)
 
+    def gemm_residual(self, a: torch.Tensor, x0: Optional[torch.Tensor], residual: torch.Tensor,
+                      row_sel: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+        """residual + Linear in one launch (same rounding as torch's `hidden + linear(x)`)."""
+        return ops.gemm_w4a8_residual(a, self.w_img, self.w_bits, self.N, self.s_x0, self.s_w, residual,
+                                      s_x1=self.s_x1, row_sel=row_sel, bias=self.bias, x0=x0, w0=self.w0, out=out)
+
     def forward_dynamic(self, x2: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """[Hadamard ->] dynamic per-token quantize -> GEMM with per-row scales.  The row maximum
         needs the whole rotated row, so the Hadamard runs as its own launch here."""

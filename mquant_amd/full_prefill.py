@@ -2,8 +2,9 @@
 Linears of ``workload.Prefill`` chained with the operators that sit between them in the model
 -- weight-less RMS norms (LayerNorms are fused away by the rotation pass), rotary embedding,
 PyTorch-ROCm SDPA, GELU / SiLU-gate, residual adds, fp16 ``lm_head`` on the last position
-(it is not wrapped: reference quant_utils.py:560-564).  Those glue operators are torch; only the
-Linears are this repository's kernels.  Used for the TTFT report in bench.py, never for parity.
+(it is not wrapped: reference quant_utils.py:560-564).  Those glue operators are torch; the Linears
+are this repository's kernels, and with ``fused_glue`` also norm -> quantize, activation ->
+Hadamard -> quantize and the residual adds (GEMM epilogue).  Used for the TTFT report in bench.py, never for parity.
 
 Static activation scales are re-calibrated on the chained activations (min/max observer kernels,
 one calibration pass) so that the int8 grids are the ones this dataflow would get.
@@ -58,13 +59,19 @@ class FullPrefill:
         self.logits = None
 
     # -- one wrapped Linear (or fused group) -----------------------------------------------
-    def _lin(self, L: Layer, x: torch.Tensor) -> torch.Tensor:
+    def _lin(self, L: Layer, x: torch.Tensor, residual: torch.Tensor = None) -> torch.Tensor:
+        """Linear(x) [+ residual, folded into the GEMM epilogue when the glue is fused]."""
         if self.calibrating:
             s0, s1 = self.pf._calibrate(x, L.spec, L.lin.had, L.row_sel)
             L.lin.s_x0 = s0
             if L.lin.s_x1 is not None:
                 L.lin.s_x1 = s1
-        return L.lin.forward(x, L.row_sel)
+        if residual is None:
+            return L.lin.forward(x, L.row_sel)
+        if self.calibrating or not self.fused_glue:
+            return residual + L.lin.forward(x, L.row_sel)
+        a, x0 = L.lin.quantize(x, L.row_sel)
+        return L.lin.gemm_residual(a, x0, residual, L.row_sel)
 
     def _norm_lin(self, L: Layer, x: torch.Tensor, dim: int) -> torch.Tensor:
         """Linear(RMSN(x))."""
@@ -73,13 +80,13 @@ class FullPrefill:
         a, _ = L.lin.quantize_rmsn(x, dim, 1e-6, L.row_sel)
         return L.lin.gemm(a, None, self.dtype, L.row_sel)
 
-    def _act_lin(self, L: Layer, x: torch.Tensor, x2, act: int) -> torch.Tensor:
-        """Linear(act(x[, x2])) for a layer with an online Hadamard."""
+    def _act_lin(self, L: Layer, x: torch.Tensor, x2, act: int, residual: torch.Tensor) -> torch.Tensor:
+        """residual + Linear(act(x[, x2])) for a layer with an online Hadamard."""
         if self.calibrating or not self.fused_glue:
             h = F.silu(x) * x2 if act == ops.ACT_SILU_MUL else x * torch.sigmoid(1.702 * x)
-            return self._lin(L, h)
+            return self._lin(L, h, residual)
         a, x0 = L.lin.quantize_act(x, x2, act, L.row_sel)
-        return L.lin.gemm(a, x0, self.dtype, L.row_sel)
+        return L.lin.gemm_residual(a, x0, residual, L.row_sel)
 
     def calibrate(self):
         self.calibrating = True
@@ -97,9 +104,9 @@ class FullPrefill:
             q, k = _rope(q, self.vcos, self.vsin), _rope(k, self.vcos, self.vsin)
             a = F.scaled_dot_product_attention(q.transpose(0, 1)[None], k.transpose(0, 1)[None],
                                                v.transpose(0, 1)[None])[0]
-            x = x + self._lin(by["vis.attn.proj"][i], a.transpose(0, 1).reshape(M_VIS, VIS_DIM))
+            x = self._lin(by["vis.attn.proj"][i], a.transpose(0, 1).reshape(M_VIS, VIS_DIM), residual=x)
             f = self._norm_lin(by["vis.mlp.fc1"][i], x, VIS_DIM)
-            x = x + self._act_lin(by["vis.mlp.fc2"][i], f, None, ops.ACT_QUICK_GELU)   # hidden_act = quick_gelu
+            x = self._act_lin(by["vis.mlp.fc2"][i], f, None, ops.ACT_QUICK_GELU, residual=x)   # hidden_act = quick_gelu
         m = F.rms_norm(x, (VIS_DIM,), eps=1e-6).view(M_MERGED, 4 * VIS_DIM)
         m = self._lin(by["merger.mlp.2"][0], F.gelu(self._lin(by["merger.mlp.0"][0], m)))
         # language model: [vision tokens | text tokens]
@@ -113,10 +120,10 @@ class FullPrefill:
             v = qkv[:, LLM_DIM + kv:].view(T, LLM_KV_HEADS, HEAD_DIM)
             a = F.scaled_dot_product_attention(q.transpose(0, 1)[None], k.transpose(0, 1)[None],
                                                v.transpose(0, 1)[None], is_causal=True, enable_gqa=True)[0]
-            hdn = hdn + self._lin(by["llm.o_proj"][i], a.transpose(0, 1).reshape(T, LLM_DIM))
+            hdn = self._lin(by["llm.o_proj"][i], a.transpose(0, 1).reshape(T, LLM_DIM), residual=hdn)
             gu = self._norm_lin(by["llm.gate_proj"][i], hdn, LLM_DIM)    # fused gate|up GEMM
             half = gu.shape[1] // 2
-            hdn = hdn + self._act_lin(by["llm.down_proj"][i], gu[:, :half], gu[:, half:], ops.ACT_SILU_MUL)
+            hdn = self._act_lin(by["llm.down_proj"][i], gu[:, :half], gu[:, half:], ops.ACT_SILU_MUL, residual=hdn)
         last = F.rms_norm(hdn[-1:], (LLM_DIM,), eps=1e-6)
         self.logits = last @ self.lm_head.t()
         return self.logits

@@ -322,6 +322,26 @@ def gemm_w4a8_rowscale(a: torch.Tensor, w_img: torch.Tensor, w_bits: int, N: int
     return out
 
 
+def gemm_w4a8_residual(a: torch.Tensor, w_img: torch.Tensor, w_bits: int, N: int, s_x0: float, s_w: torch.Tensor,
+                       residual: torch.Tensor, *, s_x1: Optional[float] = None, row_sel: Optional[torch.Tensor] = None,
+                       bias: Optional[torch.Tensor] = None, x0: Optional[torch.Tensor] = None,
+                       w0: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """residual + Linear(x) in one launch; the output has the residual's dtype (may alias it)."""
+    _need_cuda(a, w_img, s_w, residual, row_sel, bias, x0, w0, out)
+    assert a.dtype == torch.int8 and a.dim() == 2 and a.stride(1) == 1
+    M, K_pad = a.shape
+    assert residual.shape == (M, N) and residual.stride(1) == 1
+    if out is None:
+        out = torch.empty((M, N), dtype=residual.dtype, device=a.device)
+    assert out.dtype == residual.dtype
+    ws = splitk_workspace(a.device)
+    call("mq_gemm_w4a8_residual_ws", a.data_ptr(), a.stride(0), w_img.data_ptr(), w_bits, M, N, K_pad,
+         float(s_x0), float(s_x0 if s_x1 is None else s_x1), _ptr(row_sel), s_w.data_ptr(), _ptr(bias), _ptr(x0),
+         _ptr(w0), residual.data_ptr(), residual.stride(0), out.data_ptr(), dtype_code(out.dtype), out.stride(0),
+         _ptr(ws), 0 if ws is None else ws.numel(), _stream())
+    return out
+
+
 def gemm_w4a8_i32(a: torch.Tensor, w_img: torch.Tensor, w_bits: int, N: int,
                   use_workspace: bool = True) -> torch.Tensor:
     _need_cuda(a, w_img)

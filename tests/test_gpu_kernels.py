@@ -329,3 +329,30 @@ def test_every_tile_shape_and_split_factor_is_exact(w_bits):
                 np.testing.assert_array_equal(y.float().cpu().numpy(), y_ref, err_msg=f"tile {tile} splits {splits}")
     finally:
         ops.gemm_debug_force(-1, 0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,splits", [(130, 200, 640, 1), (768, 256, 19968, 0), (64, 96, 256, 3)])
+def test_gemm_residual_epilogue_equals_torch_add(dtype, M, N, K, splits):
+    """hidden + linear(x) in one launch == the GEMM followed by torch's add (same roundings), also
+    in place and through the split-K reduce."""
+    from mquant_amd import ops
+    rng = np.random.default_rng(M + N)
+    a = to_dev(rng.integers(-128, 128, size=(M, K), dtype=np.int8))
+    w = to_dev(rng.integers(-8, 8, size=(N, K), dtype=np.int8))
+    img = ops.prepack(w, 4)
+    s_w = to_dev(rng.uniform(0.001, 0.01, size=N).astype(np.float32))
+    bias = to_dev(rng.normal(size=N).astype(np.float32))
+    res = to_dev(rng.normal(size=(M, N)).astype(np.float32) * 3).to(dtype)
+    sel = to_dev((np.arange(M) % 2).astype(np.uint8))
+    try:
+        ops.gemm_debug_force(-1 if splits == 0 else 10, splits)
+        y = ops.gemm_w4a8(a, img, 4, N, 0.02, s_w, s_x1=0.03, row_sel=sel, bias=bias, out_dtype=dtype)
+        want = res + y
+        got = ops.gemm_w4a8_residual(a, img, 4, N, 0.02, s_w, res, s_x1=0.03, row_sel=sel, bias=bias)
+        assert got.dtype == dtype and torch.equal(got, want)
+        inplace = res.clone()
+        ops.gemm_w4a8_residual(a, img, 4, N, 0.02, s_w, inplace, s_x1=0.03, row_sel=sel, bias=bias, out=inplace)
+        assert torch.equal(inplace, want)
+    finally:
+        ops.gemm_debug_force(-1, 0)
