@@ -196,6 +196,16 @@ int mq_wquant_sym(const void *w, int w_dtype, long N, long K, long ldw, int bits
                   uint8_t *packed, void *wq, long ldq, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * Rotary embedding (rotate-half), in place on `heads` consecutive head_dim-wide column blocks of
+ * x [T, ldx] -- e.g. the q and k parts of a fused q|k|v GEMM output.  Not an MQuant function (the
+ * reference never touches RoPE): glue of the whole-prefill TTFT harness, bit-identical to the HF
+ * formula evaluated with torch ops on x_dtype tensors:
+ *   out = cast(cast(x*cos) + cast(rotate_half(x)*sin)),  cos/sin: [T, head_dim] in x_dtype.
+ * ------------------------------------------------------------------------- */
+int mq_rope_inplace(void *x, int x_dtype, long T, int heads, int head_dim, long ldx,
+                    const void *cos, const void *sin, void *stream);
+
+/* ---------------------------------------------------------------------------
  * GPTQ: the column loop of one lazy-batch block, gptq/gptq_utils.py:258-279 (symmetric
  * per-channel quantizer, no groups).  For i = 0..cols-1, per output row n:
  *   q = scale[n]*clamp(rint(w_i/scale[n]), -2^(bits-1), 2^(bits-1)-1);  err = (w_i - q)/Hinv1[i][i];

@@ -55,6 +55,8 @@ class FullPrefill:
         self.lm_head = rnd(VOCAB, LLM_DIM, std=0.02)
         self.vcos, self.vsin = _rope_tables(M_VIS, VIS_DIM // VIS_HEADS, self.dev, self.dtype)
         self.lcos, self.lsin = _rope_tables(M_MERGED + M_TXT, HEAD_DIM, self.dev, self.dtype, 1e6)
+        self.vcos2, self.vsin2 = self.vcos[:, 0].contiguous(), self.vsin[:, 0].contiguous()     # [T, d] for the kernel
+        self.lcos2, self.lsin2 = self.lcos[:, 0].contiguous(), self.lsin[:, 0].contiguous()
         self.calibrating = False
         self.logits = None
 
@@ -100,8 +102,13 @@ class FullPrefill:
         # vision tower
         x = self._lin(by["vis.patch_embed"][0], self.patches)
         for i in range(len(by["vis.attn.qkv"])):
-            q, k, v = self._norm_lin(by["vis.attn.qkv"][i], x, VIS_DIM).view(M_VIS, 3, VIS_HEADS, -1).unbind(1)
-            q, k = _rope(q, self.vcos, self.vsin), _rope(k, self.vcos, self.vsin)
+            qkv = self._norm_lin(by["vis.attn.qkv"][i], x, VIS_DIM)
+            if self.fused_glue:                               # q and k rotated in place, one launch
+                ops.rope_inplace(qkv[:, :2 * VIS_DIM], 2 * VIS_HEADS, VIS_DIM // VIS_HEADS, self.vcos2, self.vsin2)
+                q, k, v = qkv.view(M_VIS, 3, VIS_HEADS, -1).unbind(1)
+            else:
+                q, k, v = qkv.view(M_VIS, 3, VIS_HEADS, -1).unbind(1)
+                q, k = _rope(q, self.vcos, self.vsin), _rope(k, self.vcos, self.vsin)
             a = F.scaled_dot_product_attention(q.transpose(0, 1)[None], k.transpose(0, 1)[None],
                                                v.transpose(0, 1)[None])[0]
             x = self._lin(by["vis.attn.proj"][i], a.transpose(0, 1).reshape(M_VIS, VIS_DIM), residual=x)
@@ -115,8 +122,13 @@ class FullPrefill:
         kv = LLM_KV_HEADS * HEAD_DIM
         for i in range(len(by["llm.q_proj"])):
             qkv = self._norm_lin(by["llm.q_proj"][i], hdn, LLM_DIM)      # fused q|k|v GEMM
-            q = _rope(qkv[:, :LLM_DIM].view(T, LLM_HEADS, HEAD_DIM), self.lcos, self.lsin)
-            k = _rope(qkv[:, LLM_DIM:LLM_DIM + kv].view(T, LLM_KV_HEADS, HEAD_DIM), self.lcos, self.lsin)
+            if self.fused_glue:
+                ops.rope_inplace(qkv[:, :LLM_DIM + kv], LLM_HEADS + LLM_KV_HEADS, HEAD_DIM, self.lcos2, self.lsin2)
+                q = qkv[:, :LLM_DIM].view(T, LLM_HEADS, HEAD_DIM)
+                k = qkv[:, LLM_DIM:LLM_DIM + kv].view(T, LLM_KV_HEADS, HEAD_DIM)
+            else:
+                q = _rope(qkv[:, :LLM_DIM].view(T, LLM_HEADS, HEAD_DIM), self.lcos, self.lsin)
+                k = _rope(qkv[:, LLM_DIM:LLM_DIM + kv].view(T, LLM_KV_HEADS, HEAD_DIM), self.lcos, self.lsin)
             v = qkv[:, LLM_DIM + kv:].view(T, LLM_KV_HEADS, HEAD_DIM)
             a = F.scaled_dot_product_attention(q.transpose(0, 1)[None], k.transpose(0, 1)[None],
                                                v.transpose(0, 1)[None], is_causal=True, enable_gqa=True)[0]

@@ -139,6 +139,17 @@ def hadamard_quant_i8(x: torch.Tensor, n: int, K: int, had_bits: Optional[torch.
     return out, x0_out
 
 
+def rope_inplace(x: torch.Tensor, heads: int, head_dim: int, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    """Rotate-half RoPE in place on the first heads*head_dim columns of x [T, >= heads*head_dim]
+    (x may be a column slice of a wider tensor).  cos / sin: [T, head_dim], x's dtype."""
+    _need_cuda(x, cos, sin)
+    assert x.dim() == 2 and x.stride(1) == 1 and cos.dtype == x.dtype == sin.dtype
+    assert cos.is_contiguous() and sin.is_contiguous() and cos.shape == (x.shape[0], head_dim) == sin.shape
+    call("mq_rope_inplace", x.data_ptr(), dtype_code(x.dtype), x.shape[0], heads, head_dim, x.stride(0),
+         cos.data_ptr(), sin.data_ptr(), _stream())
+    return x
+
+
 ACT_SILU_MUL, ACT_QUICK_GELU = 1, 2
 
 

@@ -79,3 +79,20 @@ def test_argument_checks():
         ops.act_hadamard_quant_i8(x, None, ops.ACT_SILU_MUL, 64, 1, None, 0.1)       # no second operand
     with pytest.raises(MQuantHipError):
         ops.act_hadamard_quant_i8(x, x, 7, 64, 1, None, 0.1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+def test_rope_inplace_equals_the_torch_formula(dtype):
+    """Harness glue (not MQuant): rotate-half RoPE on the q|k part of a fused q|k|v output."""
+    from mquant_amd import ops
+    from mquant_amd.full_prefill import _rope, _rope_tables
+    T, heads, kvh, d = 77, 6, 2, 64
+    qkv = torch.from_numpy(make_x(3, (T, (heads + 2 * kvh) * d))).to(device=DEV, dtype=dtype)
+    cos, sin = _rope_tables(T, d, torch.device(DEV), dtype)
+    want_q = _rope(qkv[:, :heads * d].view(T, heads, d), cos, sin)
+    want_k = _rope(qkv[:, heads * d:(heads + kvh) * d].view(T, kvh, d), cos, sin)
+    v_before = qkv[:, (heads + kvh) * d:].clone()
+    ops.rope_inplace(qkv[:, :(heads + kvh) * d], heads + kvh, d, cos[:, 0].contiguous(), sin[:, 0].contiguous())
+    assert torch.equal(qkv[:, :heads * d].view(T, heads, d), want_q)
+    assert torch.equal(qkv[:, heads * d:(heads + kvh) * d].view(T, kvh, d), want_k)
+    assert torch.equal(qkv[:, (heads + kvh) * d:], v_before)
