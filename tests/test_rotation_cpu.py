@@ -14,7 +14,7 @@ import torch
 
 import toy_models
 from fake_quant import hadamard_utils as hu
-from fake_quant import internvl_rotation, module_util, qwen2vl_rotation, rotation_utils
+from fake_quant import internvl_rotation, minicpmv_rotation, module_util, qwen2vl_rotation, rotation_utils
 
 torch.set_grad_enabled(False)
 
@@ -28,14 +28,21 @@ torch.set_grad_enabled(False)
 APPROXIMATE_FUSION = ("internvl", "qwenvl")
 
 
-def _run_passes(kind, model, args, seed=123, probe=None):
+def _run_passes(kind, model, args, seed=123, probe=None, as_upstream=False):
     """fuse, (probe the fused model), rotate.  Returns the probe's logits after fusion only."""
     torch.manual_seed(seed)
     wrapper = types.SimpleNamespace(model=model)
     fuse, rotate = {"qwen2vl": (qwen2vl_rotation.fuse_qwen2vl_layer_norms, qwen2vl_rotation.rotate_qwen2vl_model),
                     "internvl": (internvl_rotation.fuse_internvl_layer_norms, internvl_rotation.rotate_internvl2_model),
-                    "qwenvl": (rotation_utils.fuse_qwenvl_layer_norms, rotation_utils.rotate_model)}[kind]
-    fuse(model if kind == "qwenvl" else wrapper, args)       # the Qwen-VL pass takes the HF module itself
+                    "qwenvl": (rotation_utils.fuse_qwenvl_layer_norms, rotation_utils.rotate_model),
+                    "minicpmv": (minicpmv_rotation.fuse_minicpmv_layer_norms, minicpmv_rotation.rotate_minicpmv_model)}[kind]
+    fuse(model if kind in ("qwenvl", "minicpmv") else wrapper, args)       # these passes take the HF module itself
+    if kind == "minicpmv" and not args.no_fuse_visual_clip and not as_upstream:
+        # upstream folds vpm.post_layernorm's affine into resampler.kv_proj but leaves the module a
+        # LayerNorm (minicpmv_rotation.py:54-60 replaces the encoder's norms only); its mean
+        # subtraction is not rotation invariant.  With the equivalent RMSN (the stream is zero-mean
+        # at that point) the rotation is exact, which is what this test pins down.
+        model.vpm.post_layernorm = module_util.RMSN(model.vpm.embed_dim, eps=1e-6)
     fused = model(*probe) if probe is not None else None
     rotate(model, args)
     model.online_visual = bool(args.rotate_visual_clip and args.online_visual_hadamard)
@@ -43,7 +50,7 @@ def _run_passes(kind, model, args, seed=123, probe=None):
     return fused
 
 
-@pytest.mark.parametrize("kind", ["qwen2vl", "internvl", "qwenvl"])
+@pytest.mark.parametrize("kind", ["qwen2vl", "internvl", "qwenvl", "minicpmv"])
 @pytest.mark.parametrize("mode", ["hadamard", "random"])
 def test_network_function_is_invariant(kind, mode):
     model, pixels, ids = toy_models.build(kind, seed=7)
@@ -62,7 +69,7 @@ def test_network_function_is_invariant(kind, mode):
     assert any(isinstance(m, module_util.RMSN) for m in model.modules())
 
 
-@pytest.mark.parametrize("kind", ["qwen2vl", "internvl", "qwenvl"])
+@pytest.mark.parametrize("kind", ["qwen2vl", "internvl", "qwenvl", "minicpmv"])
 def test_partial_passes_are_invariant_too(kind):
     for over in (dict(rotate_visual_clip=False, rotate_visual_cross_attn=False, no_fuse_visual_clip=True,
                       no_fuse_visual_cross_attn=True),
@@ -117,11 +124,11 @@ def test_orthogonal_matrices():
         rotation_utils.get_orthogonal_matrix(8, "dct")
 
 
-@pytest.mark.parametrize("kind", ["qwen2vl", "internvl", "qwenvl"])
+@pytest.mark.parametrize("kind", ["qwen2vl", "internvl", "qwenvl", "minicpmv"])
 def test_weights_match_reference_passes(golden_dir, kind):
     g = np.load(os.path.join(golden_dir, f"rotation_{kind}.npz"))
     model, pixels, ids = toy_models.build(kind, seed=int(g["seed"]))
-    _run_passes(kind, model, toy_models.rotation_args(), seed=int(g["rot_seed"]))
+    _run_passes(kind, model, toy_models.rotation_args(), seed=int(g["rot_seed"]), as_upstream=True)
     sd = model.state_dict()
     keys = [k for k in g.files if k not in ("seed", "rot_seed", "logits")]
     assert sorted(keys) == sorted(sd.keys())

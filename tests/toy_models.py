@@ -404,6 +404,99 @@ class ToyQwenVL(nn.Module):
         return self.lm_head(self.transformer.ln_f(h))
 
 
+# ------------------------------------------------------------------------------------ MiniCPM-V
+class SiglipLayer(nn.Module):
+    def __init__(self, dim, heads, hidden, owner):
+        super().__init__()
+        self.layer_norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.layer_norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.self_attn = MHA(dim, heads)
+        self.self_attn.num_heads, self.self_attn.head_dim = heads, dim // heads
+        self.mlp = nn.Module()
+        self.mlp.fc1 = nn.Linear(dim, hidden)
+        self.mlp.fc2 = nn.Linear(hidden, dim)
+        self.owner = owner
+
+    def forward(self, x):
+        y = self.layer_norm1(x)
+        x = x + self.self_attn(y, y, y)
+        h = F.gelu(self.mlp.fc1(self.layer_norm2(x)))
+        if self.owner[0].online_visual:
+            h = _had(h, self.mlp.fc2.in_features)
+        return x + self.mlp.fc2(h)
+
+
+class MiniCpmResampler(nn.Module):
+    def __init__(self, width, dim, heads, queries, patches):
+        super().__init__()
+        self.embed_dim, self.num_heads = dim, heads
+        self.kv_proj = nn.Linear(width, dim, bias=False)
+        self.ln_kv, self.ln_q, self.ln_post = nn.LayerNorm(dim, eps=1e-6), nn.LayerNorm(dim, eps=1e-6), nn.LayerNorm(dim, eps=1e-6)
+        self.query = nn.Parameter(torch.randn(queries, dim))
+        self.pos_embed = nn.Parameter(torch.randn(patches, dim))
+        self.attn = MHA(dim, heads)
+        self.proj_fc = nn.Linear(dim, dim, bias=True)
+
+    def forward(self, x):
+        kv = self.ln_kv(self.kv_proj(x))
+        out = self.attn(self.ln_q(self.query), kv + self.pos_embed, kv)
+        return self.proj_fc(self.ln_post(out))
+
+
+class MiniCpmLlmLayer(nn.Module):
+    def __init__(self, dim, heads, inter, owner):
+        super().__init__()
+        self.input_layernorm, self.post_attention_layernorm = RMSNorm(dim), RMSNorm(dim)
+        self.self_attn = MHA(dim, heads, out_name="o_proj", bias=False, out_bias=False)
+        self.mlp = QwenLlmMlp(dim, inter, owner)
+
+    def forward(self, x):
+        y = self.input_layernorm(x)
+        x = x + self.self_attn(y, y, y)
+        return x + self.mlp(self.post_attention_layernorm(x))
+
+
+class ToyMiniCPMV(nn.Module):
+    def __init__(self, width=32, vheads=2, vhidden=48, vdepth=2, dim=64, heads=4, inter=96, depth=2, vocab=50,
+                 patches=8, queries=4):
+        super().__init__()
+        self.online_visual = self.online_llm = False
+        owner = [self]
+        self.vpm = nn.Module()
+        self.vpm.embed_dim = width
+        self.vpm.embeddings = nn.Module()
+        self.vpm.embeddings.embed_dim = width
+        self.vpm.embeddings.patch_embedding = nn.Conv2d(3, width, kernel_size=4, stride=4, bias=True)
+        self.vpm.embeddings.position_embedding = nn.Embedding(patches, width)
+        self.vpm.encoder = nn.Module()
+        self.vpm.encoder.layers = nn.ModuleList(SiglipLayer(width, vheads, vhidden, owner) for _ in range(vdepth))
+        self.vpm.post_layernorm = nn.LayerNorm(width, eps=1e-6)
+        self.resampler = MiniCpmResampler(width, dim, heads, queries, patches)
+        self.llm = nn.Module()
+        self.llm.model = nn.Module()
+        self.llm.model.embed_tokens = nn.Embedding(vocab, dim)
+        self.llm.model.layers = nn.ModuleList(MiniCpmLlmLayer(dim, heads, inter, owner) for _ in range(depth))
+        self.llm.model.norm = RMSNorm(dim)
+        self.llm.lm_head = nn.Linear(dim, vocab, bias=False)
+        self.config = types.SimpleNamespace(hidden_size=dim, num_attention_heads=heads, intermediate_size=inter,
+                                            vision_config=types.SimpleNamespace(intermediate_size=vhidden))
+        for p in self.parameters():
+            if p.dim() == 1:
+                p.data = torch.randn_like(p) * 0.3 + (1.0 if p.numel() in (width, dim) else 0.0)
+
+    def forward(self, pixels, ids):
+        """pixels [patches, 3, 4, 4], ids [S] -> logits [queries + S, vocab]"""
+        e = self.vpm.embeddings
+        x = e.patch_embedding(pixels).flatten(1) + e.position_embedding.weight
+        for layer in self.vpm.encoder.layers:
+            x = layer(x)
+        x = self.resampler(self.vpm.post_layernorm(x))
+        h = torch.cat([x, self.llm.model.embed_tokens(ids)], 0)
+        for layer in self.llm.model.layers:
+            h = layer(h)
+        return self.llm.lm_head(self.llm.model.norm(h))
+
+
 def rotation_args(**over):
     base = dict(no_fuse_visual_clip=False, no_fuse_visual_cross_attn=False, no_fuse_llm=False,
                 rotate_visual_clip=True, rotate_visual_cross_attn=True, rotate_llm=True,
@@ -414,12 +507,15 @@ def rotation_args(**over):
 
 def build(kind, seed, **kw):
     torch.manual_seed(seed)
-    model = {"qwen2vl": ToyQwen2VL, "internvl": ToyInternVL, "qwenvl": ToyQwenVL}[kind](**kw).double().eval()
+    model = {"qwen2vl": ToyQwen2VL, "internvl": ToyInternVL, "qwenvl": ToyQwenVL,
+             "minicpmv": ToyMiniCPMV}[kind](**kw).double().eval()
     g = torch.Generator().manual_seed(seed + 1)
     if kind == "qwen2vl":
         pixels = torch.randn(8, *model.patch, generator=g, dtype=torch.float64)
     elif kind == "qwenvl":
         pixels = torch.randn(8, 24, generator=g, dtype=torch.float64)
+    elif kind == "minicpmv":
+        pixels = torch.randn(8, 3, 4, 4, generator=g, dtype=torch.float64)
     else:
         pixels = torch.randn(8, 3, 4, 4, generator=g, dtype=torch.float64)
     ids = torch.randint(0, 50, (5,), generator=g)

@@ -2,7 +2,7 @@
 """Golden weights for the LayerNorm-fusion + rotation passes: runs the REFERENCE's
 fuse_*_layer_norms / rotate_*_model (read-only at /root/reference) on the toy models of
 tests/toy_models.py and stores the resulting state_dict and logits in
-tests/golden/rotation_{qwen2vl,internvl,qwenvl}.npz.  Build-container only.
+tests/golden/rotation_{qwen2vl,internvl,qwenvl,minicpmv}.npz.  Build-container only.
 
 Two things the reference needs that this box lacks are bridged for the run, nothing else:
 the `fast_hadamard_transform` import (same stand-in as tools/gen_golden.py) and a CUDA device
@@ -37,15 +37,16 @@ def main():
         internvl_rotation.utils = ref_utils
     import toy_models                      # its forward imports fake_quant.hadamard_utils lazily -> reference's
 
-    from fake_quant import rotation_utils
+    from fake_quant import minicpmv_rotation, rotation_utils
     for kind, fuse, rotate in (
+            ("minicpmv", minicpmv_rotation.fuse_minicpmv_layer_norms, minicpmv_rotation.rotate_minicpmv_model),
             ("qwen2vl", qwen2vl_rotation.fuse_qwen2vl_layer_norms, qwen2vl_rotation.rotate_qwen2vl_model),
             ("internvl", internvl_rotation.fuse_internvl_layer_norms, internvl_rotation.rotate_internvl2_model),
             ("qwenvl", rotation_utils.fuse_qwenvl_layer_norms, rotation_utils.rotate_model)):
         model, pixels, ids = toy_models.build(kind, SEED)
         args = toy_models.rotation_args()
         torch.manual_seed(ROT_SEED)
-        fuse(model if kind == "qwenvl" else types.SimpleNamespace(model=model), args)
+        fuse(model if kind in ("qwenvl", "minicpmv") else types.SimpleNamespace(model=model), args)
         rotate(model, args)
         model.online_visual = model.online_llm = True
         logits = model(pixels, ids)
