@@ -103,6 +103,8 @@ FAMILIES = {
                  "internvl_add_act_qaunt", "internvl_gptq_plus.internvl_rtn_gptq_fwrd_plus", "feed_forward.w2", "mlp.fc2"),
     "qwenvl": ("rotation_utils.fuse_qwenvl_layer_norms", "rotation_utils.rotate_model", False,
                "qwenvl_add_act_qaunt", "qwenvl_gptq_plus.qwenvl_rtn_gptq_fwrd_plus", "mlp.c_proj", "mlp.c_proj"),
+    "minicpmv": ("minicpmv_rotation.fuse_minicpmv_layer_norms", "minicpmv_rotation.rotate_minicpmv_model", False,
+                 "minicpmv_add_act_qaunt", "minicpmv_gptq_plus.minicpmv_rtn_gptq_fwrd_plus", "mlp.down_proj", "mlp.fc2"),
 }
 
 
@@ -113,7 +115,8 @@ def _resolve(path):
     return getattr(importlib.import_module(pkg + mod), fn)
 
 
-@pytest.mark.parametrize("kind,split", [("internvl", False), ("internvl", True), ("qwenvl", False), ("qwenvl", True)])
+@pytest.mark.parametrize("kind,split", [("internvl", False), ("internvl", True), ("qwenvl", False), ("qwenvl", True),
+                                        ("minicpmv", False), ("minicpmv", True)])
 def test_other_model_families_run_the_real_kernels(kind, split):
     from fake_quant import hadamard_utils as hu, quant_utils as qu
     fuse, rotate, fuse_takes_wrapper, add_act, weight_pass, llm_tag, vit_tag = FAMILIES[kind]
@@ -122,6 +125,9 @@ def test_other_model_families_run_the_real_kernels(kind, split):
     torch.manual_seed(5)
     vlm = types.SimpleNamespace(model=model)
     _resolve(fuse)(vlm if fuse_takes_wrapper else model, rargs)
+    if kind == "minicpmv":      # upstream leaves this one a LayerNorm; see tests/test_rotation_cpu.py
+        from fake_quant import module_util
+        model.vpm.post_layernorm = module_util.RMSN(model.vpm.embed_dim, eps=1e-6)
     want = model(pixels, ids)                                  # fused fp model (fusion is approximate upstream)
     _resolve(rotate)(model, rargs)
     model = model.float().to(DEV)
@@ -134,7 +140,7 @@ def test_other_model_families_run_the_real_kernels(kind, split):
     wrappers = qu.find_qlayers(model, [qu.ActQuantWrapper])
     rotated = 0
     for name, w in wrappers.items():
-        is_llm = name.startswith(("language_model.", "transformer.h."))
+        is_llm = name.startswith(("language_model.", "transformer.h.", "llm."))
         tag = llm_tag if is_llm else vit_tag
         if tag in name and "attn" not in name.split(tag)[0].rsplit(".", 2)[-1]:
             if kind == "qwenvl" and not (("transformer.h" in name) or ("transformer.resblock" in name)):
