@@ -20,7 +20,7 @@ without touching (or needing) floating-point weights.
 """
 from __future__ import annotations
 
-from typing import Dict, Optional
+from typing import Dict
 
 import torch
 
