@@ -20,7 +20,16 @@ class Args:
     skip_names = []
 
 
-def build(inter, llm_split, visual_split, w_bits, msq):
+class _Dataset:
+    def __init__(self, n):
+        import pandas as pd
+        self.data = pd.DataFrame({"v": list(range(n))})
+
+    def build_prompt(self, record):
+        return int(record["v"])
+
+
+def build(inter, llm_split, visual_split, w_bits, msq, gptq=False):
     from fake_quant import hadamard_utils as hu, quant_utils as qu, qwen2vl_rotation, utils
     from fake_quant.gptq import qwen2vl_gptq_plus
     model, pixels, ids = toy_models.build("qwen2vl", seed=21, inter=inter)
@@ -32,10 +41,19 @@ def build(inter, llm_split, visual_split, w_bits, msq):
     qwen2vl_rotation.rotate_qwen2vl_model(model, rargs)
     model = model.float().to(DEV)
     vlm.model = model
+    # gptq=True: the flags of the documented command lines (docs/qwen2vl.md): GPTQ with --act_order and
+    # the MSE clip search on both towers, --visual_split
     qargs = types.SimpleNamespace(quant_llm=True, quant_visual_clip=True, quant_cross_attention=True,
-                                  act_per_tensor=False, visual_w_rtn=True, llm_w_rtn=True, visual_w_bits=w_bits,
-                                  llm_w_bits=w_bits, w_asym=False, visual_w_clip=False, llm_w_clip=False,
-                                  skip_names=[])
+                                  act_per_tensor=False, visual_w_rtn=not gptq, llm_w_rtn=not gptq, visual_w_bits=w_bits,
+                                  llm_w_bits=w_bits, w_asym=False, visual_w_clip=gptq, llm_w_clip=gptq,
+                                  skip_names=[], nsamples=4, percdamp=0.01, w_groupsize=-1, act_order=gptq,
+                                  dataset_name="toy", visual_split=visual_split, llm_split=llm_split)
+    pix_dev, ids_dev = pixels.float().to(DEV), ids.to(DEV)
+
+    def generate(message, dataset):
+        g = torch.Generator().manual_seed(int(message))
+        return model(pix_dev + 0.1 * torch.randn(pix_dev.shape, generator=g).to(DEV), ids_dev)
+    vlm.generate = generate
     qu.qwen2vl_add_act_qaunt(vlm, qargs)
     for name, w in qu.find_qlayers(model.model, [qu.ActQuantWrapper]).items():      # exam/quant_qwen2vl.py:107-127
         if "mlp.down_proj" in name:
@@ -54,7 +72,7 @@ def build(inter, llm_split, visual_split, w_bits, msq):
             w.split = visual_split
             if visual_split:
                 w.split_weights()
-    quantizers = qwen2vl_gptq_plus.qwen2vl_rtn_gptq_fwrd_plus(vlm, None, DEV, "toy", qargs)
+    quantizers = qwen2vl_gptq_plus.qwen2vl_rtn_gptq_fwrd_plus(vlm, _Dataset(8), DEV, "toy", qargs)
     wrappers = qu.find_qlayers(model, [qu.ActQuantWrapper])
     assert len(quantizers) >= len(wrappers)            # split wrappers contribute ".module" and ".L2"
     for name, w in wrappers.items():
@@ -75,11 +93,12 @@ def calibrate(model, pixels, ids, mask):
         qu.model_quant(model, Args())
 
 
-@pytest.mark.parametrize("inter,llm_split,visual_split,w_bits,msq", [(96, False, False, 8, False), (88, True, True, 8, True),
-                                                                     (96, False, True, 4, True)])
-def test_quantized_toy_model_real_kernels_equal_simulation(inter, llm_split, visual_split, w_bits, msq):
+@pytest.mark.parametrize("inter,llm_split,visual_split,w_bits,msq,gptq", [
+    (96, False, False, 8, False, False), (88, True, True, 8, True, False), (96, False, True, 4, True, False),
+    (96, False, True, 8, False, True), (88, False, True, 4, True, True)])
+def test_quantized_toy_model_real_kernels_equal_simulation(inter, llm_split, visual_split, w_bits, msq, gptq):
     from fake_quant import quant_utils as qu
-    model, wrappers, pixels, ids, want = build(inter, llm_split, visual_split, w_bits, msq)
+    model, wrappers, pixels, ids, want = build(inter, llm_split, visual_split, w_bits, msq, gptq)
     assert model.config.need_pad == (inter == 88)
     mask = torch.tensor([0, 0, 1, 1, 1, 1, 1], device=DEV)          # 2 merged vision tokens, 5 text tokens
     calibrate(model, pixels, ids, mask)
