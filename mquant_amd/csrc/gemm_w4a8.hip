@@ -734,13 +734,13 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
     // Small GEMMs are bound by the L2 -> L1 -> LDS path (~22 B/clk/CU measured, tools/probes/
     // l1_to_lds_rate.hip), i.e. by the bytes the busiest CU has to pull: ceil(tiles/256) x (BM + BN/2)
     // per unit of K.  Pick the shape that minimises that (measured ranking agrees).
-    static const int cand[][3] = {{10, 64, 128}, {31, 96, 128}, {26, 128, 128}, {35, 192, 128}};
+    static const int cand[][3] = {{10, 64, 128}, {31, 96, 128}, {26, 128, 128}, {35, 192, 128}, {2, 256, 128}};
     Plan pl = {10, 1};
     long best = -1;
     for (const auto &c : cand) {
         if (c[0] == 35 && !w4) continue;
         const long tiles = ceil_div(M, c[1]) * ceil_div(N, c[2]);
-        const long cost = ceil_div(tiles, 256) * (c[1] + c[2] / 2);
+        const long cost = ceil_div(tiles, 256) * (c[1] + (w4 ? c[2] / 2 : c[2]));   // int8 weights: one byte each
         if (best < 0 || cost < best) { best = cost; pl.tile = c[0]; }
     }
     (void)t128;

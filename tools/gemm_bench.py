@@ -37,6 +37,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="-1:0,0:1,2:1,1:1")
     ap.add_argument("--only", default="")
+    ap.add_argument("--bits", type=int, default=4)
     args = ap.parse_args()
     cfgs = [tuple(int(v) for v in c.split(":")) for c in args.configs.split(",")]
     dev = torch.device("cuda:0")
@@ -46,19 +47,20 @@ def main():
         if args.only and args.only not in name:
             continue
         a = torch.randint(-128, 128, (M, K), dtype=torch.int8, device=dev)
-        q = torch.randint(-8, 8, (N, K), dtype=torch.int8, device=dev)
-        img = ops.prepack(q, 4)
+        lim = 1 << (args.bits - 1)
+        q = torch.randint(-lim, lim, (N, K), dtype=torch.int8, device=dev)
+        img = ops.prepack(q, args.bits)
         s_w = torch.full((N,), 0.01, device=dev)
         out = torch.empty((M, N), dtype=torch.float16, device=dev)
         ref = None
         cols = []
         for tile, splits in cfgs:
             ops.gemm_debug_force(tile, splits)
-            acc = ops.gemm_w4a8_i32(a, img, 4, N)
+            acc = ops.gemm_w4a8_i32(a, img, args.bits, N)
             if ref is None:
                 ref = acc
             ok = bool(torch.equal(acc, ref))
-            us = bench(lambda: ops.gemm_w4a8(a, img, 4, N, 0.02, s_w, out=out))
+            us = bench(lambda: ops.gemm_w4a8(a, img, args.bits, N, 0.02, s_w, out=out))
             cols.append(f"{us:8.1f} {2.0 * M * N * K / us / 1e6:7.0f}{'' if ok else ' MISMATCH'}")
         print(f"{name:14s} {M:5d} {N:6d} {K:6d} | " + " | ".join(cols))
     ops.gemm_debug_force(-1, 0)
