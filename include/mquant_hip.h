@@ -167,7 +167,8 @@ int mq_quantize_act_dyn_i8(const void *x, int x_dtype, long M, long K, long ldx,
  * (module_util.py:55-61) followed by UniformQuantizer.quant (uniform.py:20-33):
  *   h = fp32(x);  y = cast_to_x_dtype(h * (1/sqrt(sum(h*h)/mean_dim + eps)));
  *   out[m][k] = clamp(rint(y / scale_sel(m)), -128, 127), zero for K <= k < K_pad
- * x: [M, ldx] MQ_F16 or MQ_F32 (upstream promotes fp16 only), rows 16-byte aligned, K % 16 == 0,
+ * x: [M, ldx], rows 16-byte aligned, K % 16 == 0 (MQ_BF16 rows are normalised in bf16 arithmetic, one
+ * rounding per torch op, because upstream promotes fp16 only),
  * K <= 16384.  y_out (optional, [M, ldy], x's dtype) receives the normalised activations.
  * The sum of squares uses the fixed order documented in csrc/rmsn_quant.hip (oracle: orc_rmsn);
  * torch's own reduction order differs in the last fp32 bit, i.e. <= 1 ulp of y.

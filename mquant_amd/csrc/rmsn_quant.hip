@@ -8,7 +8,8 @@
 //
 // One workgroup per row, the row stays in registers between the two passes (one HBM read, one
 // int8 write; optionally the normalised row in the input dtype as well).  The sum of squares uses
-// a FIXED order that the oracle restates (orc_rmsn): thread t adds the squares of its 16-element
+// (bf16 rows are not promoted upstream -- only fp16 is, module_util.py:56-57 -- so every step of the
+// bf16 path rounds to bf16 like the torch ops do) a FIXED order that the oracle restates (orc_rmsn): thread t adds the squares of its 16-element
 // chunks c = t, t + 256, ... in ascending k; XOR butterfly (1..32) inside each wave; the four wave
 // sums left to right.  1/sqrt with correctly rounded sqrt and divide (torch's CPU rsqrt).
 #include "mq_common.h"
@@ -64,7 +65,8 @@ __global__ __launch_bounds__(RQ_THREADS) void rmsn_quant_kernel(RqArgs p)
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float sq = v[c][i] * v[c][i];
+                float sq = v[c][i] * v[c][i];
+                if (DT == MQ_BF16) sq = Elem<DT>::rnd(sq);      // bf16 rows are NOT promoted upstream: x.pow(2) is bf16
                 part = part + sq;
             }
         }
@@ -74,8 +76,16 @@ __global__ __launch_bounds__(RQ_THREADS) void rmsn_quant_kernel(RqArgs p)
     if (lane == 0) wsum[wave] = part;
     __syncthreads();
     const float total = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
-    const float ms = total / p.mean_dim;
-    const float inv = 1.0f / sqrtf(ms + p.eps);
+    float inv;
+    if (DT == MQ_BF16) {
+        // module_util.py:58-60 on a bf16 tensor: every torch op rounds its fp32 result to bf16
+        const float var = Elem<DT>::rnd(Elem<DT>::rnd(total) / p.mean_dim);
+        const float ve = Elem<DT>::rnd(var + p.eps);
+        inv = Elem<DT>::rnd(1.0f / sqrtf(ve));
+    } else {
+        const float ms = total / p.mean_dim;
+        inv = 1.0f / sqrtf(ms + p.eps);
+    }
     const float s = (p.row_sel && p.row_sel[row]) ? p.scale1 : p.scale0;
 
 #pragma unroll
@@ -132,9 +142,8 @@ extern "C" int mq_rmsn_quantize_i8(const void *x, int x_dtype, long M, long K, l
     switch (x_dtype) {
     case MQ_F16: hipLaunchKernelGGL(rmsn_quant_kernel<MQ_F16>, dim3((unsigned)M), dim3(RQ_THREADS), 0, st, p); break;
     case MQ_F32: hipLaunchKernelGGL(rmsn_quant_kernel<MQ_F32>, dim3((unsigned)M), dim3(RQ_THREADS), 0, st, p); break;
-    default:
-        return fail(MQ_EINVAL, "mq_rmsn_quantize_i8: dtype %d not supported (RMSN promotes fp16 only; "
-                               "bf16 rows are normalised in bf16 arithmetic upstream -- use the unfused pair)", x_dtype);
+    case MQ_BF16: hipLaunchKernelGGL(rmsn_quant_kernel<MQ_BF16>, dim3((unsigned)M), dim3(RQ_THREADS), 0, st, p); break;
+    default: return fail(MQ_EINVAL, "mq_rmsn_quantize_i8: unknown dtype %d", x_dtype);
     }
     return check_launch("rmsn_quantize_i8");
 }

@@ -123,7 +123,8 @@ void orc_rmsn(const float *x, long rows, long cols, float mean_dim, float eps, i
         for (int t = 0; t < 256; ++t) part[t] = 0.0f;
         for (long k = 0; k < cols; ++k) {
             const int t = (int)((k / 16) % 256);
-            const float sq = h[k] * h[k];
+            float sq = h[k] * h[k];
+            if (mode == 2) sq = round_mid(sq, 2);          /* bf16: x.pow(2) is a bf16 tensor */
             part[t] = part[t] + sq;
         }
         float wsum[4];
@@ -137,8 +138,15 @@ void orc_rmsn(const float *x, long rows, long cols, float mean_dim, float eps, i
             wsum[w] = v[0];
         }
         const float total = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
-        const float ms = total / mean_dim;
-        const float inv = 1.0f / sqrtf(ms + eps);
+        float inv;
+        if (mode == 2) {                                   /* no promotion for bf16: one rounding per torch op */
+            const float var = round_mid(round_mid(total, 2) / mean_dim, 2);
+            const float ve = round_mid(var + eps, 2);
+            inv = round_mid(1.0f / sqrtf(ve), 2);
+        } else {
+            const float ms = total / mean_dim;
+            inv = 1.0f / sqrtf(ms + eps);
+        }
         for (long k = 0; k < cols; ++k) y[r * cols + k] = round_mid(h[k] * inv, mode);
     }
 }

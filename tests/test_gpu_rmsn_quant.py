@@ -14,11 +14,12 @@ torch.set_grad_enabled(False)
 
 
 @pytest.mark.parametrize("M,K,dtype", [(768, 3584, torch.float16), (1024, 1280, torch.float16), (5, 16, torch.float16),
-                                       (33, 5120, torch.float32), (3, 16384, torch.float16), (64, 4112, torch.float16)])
+                                       (33, 5120, torch.float32), (3, 16384, torch.float16), (64, 4112, torch.float16),
+                                       (768, 3584, torch.bfloat16), (9, 1280, torch.bfloat16)])
 def test_matches_oracle_bit_for_bit(M, K, dtype):
     from mquant_amd import ops
     x = torch.from_numpy(make_x(M + K, (M, K))).to(device=DEV, dtype=dtype)
-    mode = 1 if dtype == torch.float16 else 0
+    mode = {torch.float16: 1, torch.float32: 0, torch.bfloat16: 2}[dtype]
     sel = (torch.arange(M, device=DEV) % 3 == 0).to(torch.uint8)
     q, y = ops.rmsn_quantize_i8(x, K, 1e-6, 0.031, 0.017, row_sel=sel, want_y=True)
     y_ref = oracle.rmsn(x.float().cpu().numpy(), K, 1e-6, mode)
@@ -55,10 +56,20 @@ def test_feeds_the_gemm_like_the_unfused_pair():
     torch.testing.assert_close(fused, lin(y), rtol=0, atol=0)
 
 
-def test_rejects_what_upstream_does_not_promote():
+def test_bf16_rows_follow_the_unpromoted_torch_ops():
+    """Qwen2-VL's native dtype: RMSN leaves bf16 tensors in bf16 (module_util.py:56-57 promotes fp16 only)."""
+    from fake_quant.module_util import RMSN
+    from mquant_amd import ops
+    x = torch.from_numpy(make_x(21, (768, 3584))).to(DEV).bfloat16()
+    want = RMSN(3584, eps=1e-6)(x)
+    q, y = ops.rmsn_quantize_i8(x, 3584, 1e-6, 0.02, want_y=True)
+    assert float((y != want).float().mean()) < 1e-3                 # the row sum's order is torch's own
+    q_ref, _ = ops.quantize_act_i8(want, 0.02)
+    assert float((q != q_ref).float().mean()) < 1e-3
+
+
+def test_rejects_unaligned_rows():
     from mquant_amd import ops
     from mquant_amd._lib import MQuantHipError
-    with pytest.raises(MQuantHipError):
-        ops.rmsn_quantize_i8(torch.zeros((4, 64), device=DEV, dtype=torch.bfloat16), 64, 1e-6, 0.1)
     with pytest.raises(MQuantHipError):
         ops.rmsn_quantize_i8(torch.zeros((4, 40), device=DEV, dtype=torch.float16), 40, 1e-6, 0.1)
