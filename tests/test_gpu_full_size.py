@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 torch.set_grad_enabled(False)
 
-FULL = [("gate_up", 768, 37888, 3584), ("down_proj split-K", 768, 3584, 19968), ("vit fc1", 1024, 5120, 1280)]
+FULL = [("gate_up", 768, 37888, 3584), ("down_proj split-K", 768, 3584, 19968), ("vit fc1", 1024, 5120, 1280),
+        ("72B gate_up", 768, 59136, 8192), ("72B down_proj", 768, 8192, 30720)]          # BASELINE config 5 shapes
 
 
 def _levels(N, K, bits, seed):
@@ -61,7 +62,7 @@ def test_weight_image_decodes_through_the_gemm(name, M, N, K):
     assert torch.equal(ops.unpack_i4(ops.pack_i4(w)), w)
 
 
-@pytest.mark.parametrize("n_in,n", [(18944, 19968), (5120, 5120)])
+@pytest.mark.parametrize("n_in,n", [(18944, 19968), (5120, 5120), (29568, 30720)])
 def test_hadamard_round_trip_and_norm(n_in, n):
     from fake_quant import hadamard_utils as hu
     from mquant_amd import ops

@@ -200,7 +200,7 @@ def _rand_levels(seed, shape, bits):
 
 
 GEMM_SHAPES = [(16, 16, 128), (128, 128, 256), (37, 50, 384), (256, 384, 1280), (130, 132, 640),
-               (768, 512, 3584), (1, 3584, 128), (300, 48, 19968)]
+               (768, 512, 3584), (1, 3584, 128), (300, 48, 19968), (64, 96, 30720)]
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
