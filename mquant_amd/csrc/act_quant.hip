@@ -20,8 +20,15 @@ __global__ __launch_bounds__(256) void act_quant_kernel(
     const long total = M * chunks_per_row;
     for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < total;
          c += (long)gridDim.x * blockDim.x) {
-        const long row = c / chunks_per_row;
-        const long col = (c - row * chunks_per_row) * 16;
+        long row, col;
+        if (total < (1L << 31)) {                // 32-bit divide: a 64-bit one costs ~100 cycles per thread
+            const unsigned r32 = (unsigned)c / (unsigned)chunks_per_row;
+            row = r32;
+            col = (long)((unsigned)c - r32 * (unsigned)chunks_per_row) * 16;
+        } else {
+            row = c / chunks_per_row;
+            col = (c - row * chunks_per_row) * 16;
+        }
         const int sel = row_sel ? (row_sel[row] != 0) : 0;
         const float s_t = sel ? scale1 : scale0;
         const float *sv = sel ? svec1 : svec0;
