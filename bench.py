@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--no-full-prefill", action="store_true",
                     help="skip the secondary report: whole synthetic prefill incl. attention/norms (torch glue)")
     ap.add_argument("--ttft-iters", type=int, default=100)
+    ap.add_argument("--batch", type=int, default=1,
+                    help="image+prompt samples per GPU and step (the benchmark configuration is 1; >1 is a scaling study)")
     args = ap.parse_args()
 
     import torch
@@ -147,9 +149,9 @@ def main():
 
     from mquant_amd import workload
 
-    specs = workload.tiny_specs() if args.tiny else workload.qwen2vl_7b_specs(msq=True)
+    specs = workload.tiny_specs() if args.tiny else workload.qwen2vl_7b_specs(msq=True, batch=args.batch)
     pf = workload.Prefill(specs, device=dev, dtype=torch.float16, share_groups=not args.no_fuse)
-    tokens_per_step = workload.M_LLM if not args.tiny else specs[-1].M
+    tokens_per_step = workload.M_LLM * args.batch if not args.tiny else specs[-1].M
 
     logits_local = torch.zeros((1, VOCAB), dtype=torch.float16, device=dev)
     logits_all = torch.zeros((world, VOCAB), dtype=torch.float16, device=dev) if distributed else None
@@ -214,7 +216,7 @@ def main():
     launches = pf.gemm_launches()
     traffic, traffic_note = None, "no profiles/r1_traffic.json"
     tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_traffic.json")
-    if os.path.exists(tpath) and not args.tiny:
+    if os.path.exists(tpath) and not args.tiny and args.batch == 1:
         # HBM bytes per GEMM launch from the PMC passes (tools/pmc_traffic.py); counters cannot be
         # read inside the timed run, so this is the committed measurement of the same command
         with open(tpath) as fh:
@@ -241,7 +243,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "int8",
             "data": "synthetic (random weights with the real shapes, random activations with outlier channels)",
             "config": {"workload": "Qwen2-VL-7B W4A8 MSQ prefill, 1x448^2 image (1024 vision tokens) + "
-                                   "512 text tokens, 327 wrapped Linears, M_llm=768" + ("" if args.no_fuse else " (q/k/v and gate/up share one quantization and one GEMM)") if not args.tiny
+                                   "512 text tokens, 327 wrapped Linears, M_llm=768" + ("" if args.batch == 1 else f", x{args.batch} samples per step (scaling study, not the benchmark configuration)") + ("" if args.no_fuse else " (q/k/v and gate/up share one quantization and one GEMM)") if not args.tiny
                        else "tiny debug shapes",
                        "tokens_per_step_per_gpu": tokens_per_step, "parallelism": f"batch-shard x{world}",
                        "ttft_hot_path_ms": round(ms_per_step, 4),
@@ -249,7 +251,7 @@ def main():
                        "hip_graph": not args.no_graph,
                        "weights_GB": round(pf.weight_bytes() / 1e9, 3)},
             "roofline": roofline}
-    if not (args.tiny or args.no_full_prefill or args.no_fuse):
+    if not (args.tiny or args.no_full_prefill or args.no_fuse or args.batch != 1):
         line["full_prefill"] = full_prefill_report(pf, dev, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

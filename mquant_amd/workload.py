@@ -36,8 +36,17 @@ M_VIS, M_MERGED, M_TXT = 1024, 256, 512
 M_LLM = M_MERGED + M_TXT
 
 
-def qwen2vl_7b_specs(msq: bool = True) -> List[LinearSpec]:
+def qwen2vl_7b_specs(msq: bool = True, batch: int = 1) -> List[LinearSpec]:
+    """``batch`` image+prompt samples stacked along the row dimension of every Linear (the
+    benchmark configuration is batch = 1; larger values show how the GEMMs scale with M)."""
     v, l = 32, 28
+    specs = _qwen2vl_7b_specs(msq, v, l)
+    for sp in specs:
+        sp.M *= batch
+    return specs
+
+
+def _qwen2vl_7b_specs(msq: bool, v: int, l: int) -> List[LinearSpec]:
     return [
         LinearSpec("vis.patch_embed", M_VIS, 1176, 1176, 1280, 1),
         LinearSpec("vis.attn.qkv", M_VIS, 1280, 1280, 3840, v, bias=True),
