@@ -77,7 +77,7 @@ def gptq_minicpmv_fwrd_llm(model, dataset, dev, args, quantizers):
 
 
 @torch.no_grad()
-def minicpmv_rtn_gptq_fwrd_plus(model, dataset, dev, args):
+def minicpmv_rtn_gptq_fwrd_plus(model, dataset, dev, dataset_name, args):
     logging.info("-----RTN Or GPTQ Quantization-----")
     quantizers = {}
     if args.quant_visual_clip:

@@ -265,7 +265,7 @@ def test_minicpmv_driver_walks_the_expected_modules():
     vlm = Vlm()
     args = gptq_args()
     qu.minicpmv_add_act_qaunt(vlm.model, args)
-    q = minicpmv_gptq_plus.minicpmv_rtn_gptq_fwrd_plus(vlm, ToyDataset(6), "cpu", args)
+    q = minicpmv_gptq_plus.minicpmv_rtn_gptq_fwrd_plus(vlm, ToyDataset(6), "cpu", "toy", args)
     wrappers = qu.find_qlayers(vlm.model, [qu.ActQuantWrapper])
     assert len(q) == len(wrappers) == 1 + 2 * 6 + 6 + 2 * 7
     assert {"model.vpm.embeddings.patch_embedding", "model.vpm.encoder.layers.0.self_attn.out_proj.module",
