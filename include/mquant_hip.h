@@ -38,6 +38,20 @@ extern "C" {
 #define MQ_EINVAL (-1)      /* bad argument (shape / alignment / dtype)          */
 #define MQ_EUNSUPPORTED (-2) /* valid request this build does not implement       */
 
+/* Layout of the int8 activation matrix handed from the quantizers to the GEMM.  Every entry point
+ * that takes (int8 matrix, K_pad, leading dimension) accepts either
+ *   ld >= K_pad      row-major [M, K_pad], ld bytes per row; or
+ *   ld == MQ_LD_TILED  the TILED layout: [ceil(M/16)][K_pad/64] pieces of 1 KiB; inside a piece the
+ *                    16-byte chunk holding k = 64 kt + 16 c .. +15 of row 16 mt + r sits at byte
+ *                    (16 c + r) * 16, i.e. byte offset of element (m, k) =
+ *                      ((m/16) * (K_pad/64) + k/64) * 1024 + (((k/16)%4) * 16 + m%16) * 16 + k%16.
+ *                    K_pad % 64 == 0; the buffer holds ceil16(M) * K_pad bytes (rows >= M are never
+ *                    read into a result).  One piece is one MFMA operand fragment in lane order, so
+ *                    the GEMM fetches it with a single contiguous 1 KiB LDS-DMA: a CU gathers rows
+ *                    of a row-major matrix at ~14.5 B/clk but streams contiguous KiB at 40-50 B/clk
+ *                    (DESIGN.md 4.1). */
+#define MQ_LD_TILED 0L
+
 /* Geometry of the pre-tiled weight image consumed by mq_gemm_w4a8. */
 #define MQ_W_TILE_N 16   /* output channels per MFMA fragment                     */
 #define MQ_W_TILE_K 128  /* reduction elements per fragment pair (2 x K=64 MFMAs) */
@@ -227,7 +241,8 @@ int mq_gptq_block(const float *W1, long N, int cols, long ldw, const float *Hinv
  *   acc[m][n] = sum_k a[m][k] * w[n][k]                      (int32, exact)
  *   y[m][n]   = ((float(acc) * s_x[row_sel[m]]) * s_w[n]) + bias[n] + x0[m]*w0[n]
  * each fp32 operation rounded once, in that order, then cast to out_dtype.
- * a: [M, K_pad] int8, leading dimension lda (bytes, multiple of 16), K_pad % 128 == 0.
+ * a: [M, K_pad] int8, leading dimension lda (bytes, multiple of 16) or lda = MQ_LD_TILED (the
+ *    layout the quantizers write on request, fastest), K_pad % 128 == 0.
  * w: image produced by mq_prepack_w4 / _w8 for (N, K) with the same K_pad.
  * bias, x0, w0, row_sel may be NULL.  out: [M, N], leading dimension ldo (elements).
  * mq_gemm_w4a8_i32 stores the raw accumulators (parity interface).
@@ -279,7 +294,7 @@ int mq_gemm_w4a8_i32_ws(const int8_t *a, long lda, const void *w, int w_bits,
                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* Tuning / test hook (process-wide, not part of the drop-in surface): force the tile shape
- * (-1 heuristic, 0: 128x128, 1: 256x256, 2: 256x128) and the split-K factor (0 heuristic). */
+ * (-1 heuristic; ids as in csrc/gemm_w4a8.hip dispatch_tile) and the split-K factor (0 heuristic). */
 int mq_gemm_debug_force(int tile, int splits);
 
 /* ---------------------------------------------------------------------------

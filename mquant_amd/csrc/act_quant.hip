@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void act_quant_kernel(
         }
 
         if (!DEQUANT) {
-            int8_t *out = reinterpret_cast<int8_t *>(out_) + row * ldo + col;
+            int8_t *out = reinterpret_cast<int8_t *>(out_) + act_offset(row, col, K_pad, ldo);
             v4i p;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -121,8 +121,8 @@ extern "C" int mq_quantize_act_i8(const void *x, int x_dtype, long M, long K, lo
     if (M == 0 || K == 0) return MQ_OK;
     MQ_REQUIRE(x && out, "mq_quantize_act_i8: null buffer");
     MQ_REQUIRE(K_pad >= K && K_pad % 16 == 0, "mq_quantize_act_i8: K_pad=%ld must be >= K=%ld and a multiple of 16", K_pad, K);
-    MQ_REQUIRE(ldo >= K_pad && ldo % 16 == 0 && ((uintptr_t)out) % 16 == 0,
-               "mq_quantize_act_i8: out must be 16-byte aligned with ldo %% 16 == 0 (ldo=%ld)", ldo);
+    MQ_REQUIRE(((uintptr_t)out) % 16 == 0 && (ldo == MQ_LD_TILED ? K_pad % 64 == 0 : (ldo >= K_pad && ldo % 16 == 0)),
+               "mq_quantize_act_i8: out must be 16-byte aligned with ldo %% 16 == 0, or ldo = MQ_LD_TILED with K_pad %% 64 == 0 (ldo=%ld)", ldo);
     MQ_REQUIRE(ldx >= K, "mq_quantize_act_i8: ldx < K");
     MQ_REQUIRE(!row_sel || !scale_vec0 || scale_vec1, "mq_quantize_act_i8: row_sel with per-channel scales needs scale_vec1");
     if (!scale_vec1) scale_vec1 = scale_vec0;

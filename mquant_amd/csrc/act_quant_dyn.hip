@@ -103,11 +103,11 @@ __global__ __launch_bounds__(DQ_THREADS) void act_quant_dyn_kernel(DqArgs p)
             for (int j = 0; j < 4; ++j)
                 pk[j] = (q[4 * j] & 0xff) | ((q[4 * j + 1] & 0xff) << 8) | ((q[4 * j + 2] & 0xff) << 16) |
                         ((q[4 * j + 3] & 0xff) << 24);
-            *reinterpret_cast<v4i *>(p.out + row * p.ldo + ch * 16) = pk;
+            *reinterpret_cast<v4i *>(p.out + act_offset(row, ch * 16, p.K_pad, p.ldo)) = pk;
         }
     }
     for (long k = chunks * 16 + t * 16L; k < p.K_pad; k += DQ_THREADS * 16L)
-        *reinterpret_cast<v4i *>(p.out + row * p.ldo + k) = v4i{0, 0, 0, 0};
+        *reinterpret_cast<v4i *>(p.out + act_offset(row, k, p.K_pad, p.ldo)) = v4i{0, 0, 0, 0};
 }
 
 }  // namespace mq
@@ -121,7 +121,8 @@ extern "C" int mq_quantize_act_dyn_i8(const void *x, int x_dtype, long M, long K
     MQ_REQUIRE(x && out && scale_out && M >= 0 && K > 0 && ldx >= K, "mq_quantize_act_dyn_i8: bad shape");
     MQ_REQUIRE(bits >= 2 && bits <= 8, "mq_quantize_act_dyn_i8: bits must be 2..8");
     MQ_REQUIRE(K <= 16L * DQ_THREADS * DQ_MAX_CHUNKS, "mq_quantize_act_dyn_i8: K=%ld too large (max %d)", K, 16 * DQ_THREADS * DQ_MAX_CHUNKS);
-    MQ_REQUIRE(K_pad >= K && K_pad % 16 == 0 && ldo >= K_pad && ldo % 16 == 0 && ((uintptr_t)out) % 16 == 0,
+    MQ_REQUIRE(K_pad >= K && K_pad % 16 == 0 && ((uintptr_t)out) % 16 == 0 &&
+                   (ldo == MQ_LD_TILED ? K_pad % 64 == 0 : (ldo >= K_pad && ldo % 16 == 0)),
                "mq_quantize_act_dyn_i8: bad K_pad / ldo / alignment");
     if (M == 0) return MQ_OK;
     DqArgs p;

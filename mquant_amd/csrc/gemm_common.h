@@ -1,0 +1,324 @@
+// gemm_common.h -- pieces shared by the W4A8 GEMM kernels (gemm_w4a8.hip, gemm_ws.hip):
+// argument block, LDS-DMA helper, dequantisation epilogue.
+#pragma once
+#include "mq_common.h"
+
+namespace mq {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ void dma16(const void *g, void *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((gbl_void *)g, (lds_void *)lds_wave_base, 16, 0, 0);
+}
+
+enum { EPI_F16 = MQ_F16, EPI_BF16 = MQ_BF16, EPI_F32 = MQ_F32, EPI_I32 = 3 };
+
+// Experiment switch for bottleneck hunting (never set in the shipped build): 1 = no DMA inside the
+// k-loop (compute side alone), 2 = no LDS reads / MFMA (DMA side alone).
+#ifndef MQ_EXP
+#define MQ_EXP 0
+#endif
+
+struct GemmArgs {
+    const int8_t *a;
+    long lda;
+    int a_tiled = 0;   // activations in the tiled layout (MQ_LD_TILED): [ceil(M/16)][K_pad/64] pieces of 1 KiB
+    const uint8_t *w;
+    long M, N, K_pad;
+    long n_tiles;  // ceil(N / 16)
+    long n_pairs;  // ceil(N / 32): 16-channel tile pairs in the W4 image
+    float sx0, sx1;
+    const uint8_t *row_sel;
+    const float *sx_vec = nullptr;   // per-row activation scales (dynamic per-token quantizer); overrides sx0/sx1
+    const void *residual = nullptr;  // [M, ldr] in the output dtype: out = cast(cast(y) + residual)
+    long ldr = 0;
+    const float *s_w, *bias, *x0, *w0;
+    void *out;
+    long ldo;
+    int splits;        // split-K factor (1 = none)
+    int vec_ok;        // N, ldo multiples of 8 and a 16-byte aligned output
+    int par_ok;        // s_w / bias / w0 16-byte aligned
+    int res_vec;       // residual rows 16-byte aligned
+    int32_t *partial;  // [splits][M][N] when splits > 1
+    // Launch geometry, filled on the host by set_geometry(): the kernels do no integer division (the
+    // five runtime divisions of the round-1 prologue, two of them 64-bit, cost ~1.5 us per launch).
+    unsigned m_blocks = 1, n_blocks = 1;
+    unsigned mag_m = 0, mag_n = 0;   // ceil(2^32 / d): n / d == umulhi(n, mag) for n, d < 2^16
+    int kq = 0, kr = 0;              // k units per split: split s owns kq (+1 if s < kr) units from s*kq + min(s, kr)
+};
+
+inline void set_geometry(GemmArgs &p, int BM, int BN, int k_unit)
+{
+    p.m_blocks = (unsigned)ceil_div(p.M, BM);
+    p.n_blocks = (unsigned)ceil_div(p.n_tiles * 16, BN);
+    p.mag_m = (unsigned)(((1ULL << 32) + p.m_blocks - 1) / p.m_blocks);
+    p.mag_n = (unsigned)(((1ULL << 32) + p.n_blocks - 1) / p.n_blocks);
+    const long units = p.K_pad / k_unit;
+    p.kq = (int)(units / p.splits);
+    p.kr = (int)(units % p.splits);
+}
+
+// workgroup -> (bm, bn, split): XCD-aware and bijective.  Block b runs on XCD b % 8; the remap makes
+// the m-blocks that share a weight panel (and, under split-K, the tiles of one k-slice) consecutive
+// on ONE XCD, so a panel is fetched into one L2 once.
+__device__ __forceinline__ void tile_of_block(const GemmArgs &p, int &bm, int &bn, int &split)
+{
+    const unsigned total = gridDim.x, b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const unsigned q = total >> 3, r = total & 7;
+    const unsigned wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const unsigned rest = p.m_blocks == 1 ? wid : __umulhi(wid, p.mag_m);
+    bm = (int)(wid - rest * p.m_blocks);
+    const unsigned sp = p.n_blocks == 1 ? rest : __umulhi(rest, p.mag_n);
+    split = (int)sp;
+    bn = (int)(rest - sp * p.n_blocks);
+}
+
+__device__ __forceinline__ void k_range_of_split(const GemmArgs &p, int split, int &k_begin, int &nk)
+{
+    const int extra = split < p.kr ? split : p.kr;
+    k_begin = split * p.kq + extra;
+    nk = p.kq + (split < p.kr ? 1 : 0);
+}
+
+// y = ((float(acc) * sx) * s_w[n]) + bias[n] + x0 * w0[n]; one rounding per operation.
+template <int EPI>
+__device__ __forceinline__ void store_quad(const GemmArgs &p, long m, long n, v4i a, float sx,
+                                           float xz)
+{
+    const bool full = (n + 4 <= p.N) && (p.ldo % 4 == 0);
+    if (EPI == EPI_I32) {
+        int *o = reinterpret_cast<int *>(p.out) + m * p.ldo + n;
+        if (full) {
+            *reinterpret_cast<v4i *>(o) = a;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < p.N) o[r] = a[r];
+        }
+        return;
+    }
+    float y[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long nn = (n + r < p.N) ? n + r : p.N - 1;
+        float t = (float)a[r] * sx;
+        t = t * p.s_w[nn];
+        if (p.bias) t = t + p.bias[nn];
+        if (p.x0) {
+            const float pr = xz * p.w0[nn];
+            t = t + pr;
+        }
+        y[r] = t;
+    }
+    if (p.residual) {   // torch: hidden + linear(x): the Linear's output is rounded first
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (n + r >= p.N) continue;
+            if (EPI == EPI_F32) {
+                y[r] = y[r] + reinterpret_cast<const float *>(p.residual)[m * p.ldr + n + r];
+            } else {
+                const unsigned short rb = reinterpret_cast<const unsigned short *>(p.residual)[m * p.ldr + n + r];
+                y[r] = (EPI == EPI_F16) ? f16_bits_to_f32(f32_to_f16_bits(y[r])) + f16_bits_to_f32(rb)
+                                        : bf16_bits_to_f32(f32_to_bf16_bits(y[r])) + bf16_bits_to_f32(rb);
+            }
+        }
+    }
+    if (EPI == EPI_F32) {
+        float *o = reinterpret_cast<float *>(p.out) + m * p.ldo + n;
+        if (full) {
+            *reinterpret_cast<v4f *>(o) = v4f{y[0], y[1], y[2], y[3]};
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < p.N) o[r] = y[r];
+        }
+    } else {
+        unsigned short h[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            h[r] = (EPI == EPI_F16) ? f32_to_f16_bits(y[r]) : f32_to_bf16_bits(y[r]);
+        unsigned short *o = reinterpret_cast<unsigned short *>(p.out) + m * p.ldo + n;
+        if (full) {
+            *reinterpret_cast<v4us *>(o) = v4us{h[0], h[1], h[2], h[3]};
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < p.N) o[r] = h[r];
+        }
+    }
+}
+
+// ---- epilogue -------------------------------------------------------------------------------
+// Code executed once per workgroup is instruction-fetch bound (cold I-cache), so the epilogue is
+// kept SMALL: each wave parks its raw int32 accumulators in a private LDS slab with a handful of
+// unrolled ds_write_b128, then a ROLLED loop re-reads them row-contiguously, dequantises and
+// stores 16 B (fp16) / 32 B per lane: whole 128-byte row segments, edges in the same loop.
+template <int TM, int TN, int NWAVES, int RING_BYTES, int W_BITS, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][TM], char *smem,
+                                              int wave, int lane, int wm, int wn, long m0, long nt0,
+                                              int split)
+{
+    // D layout: col = lane & 15 -> m, row = (lane >> 4) * 4 + r -> n
+    constexpr int WN_COLS = TN * 16;                 // columns of the wave's sub-tile
+    constexpr int SLAB_LD = WN_COLS * 4 + 16;        // bytes per slab row (+16: conflict-free)
+    constexpr int PASS_MT =                          // m-tiles parked per pass (slab must fit)
+        (TM % 4 == 0 && NWAVES * 64 * (SLAB_LD + 8) <= RING_BYTES) ? 4
+        : (TM % 2 == 0 && NWAVES * 32 * (SLAB_LD + 8) <= RING_BYTES) ? 2 : 1;
+    constexpr int PASS_ROWS = PASS_MT * 16;
+    constexpr int SLAB_BYTES = PASS_ROWS * SLAB_LD + PASS_ROWS * 8;
+    constexpr int LANES_PER_ROW = WN_COLS / 8;       // 8 outputs per lane
+    constexpr int ROWS_PER_IT = 64 / LANES_PER_ROW;
+    static_assert(NWAVES * SLAB_BYTES <= RING_BYTES, "epilogue slab must fit the ring");
+    static_assert(TM % PASS_MT == 0 && 64 % LANES_PER_ROW == 0 && PASS_ROWS % ROWS_PER_IT == 0, "epilogue geometry");
+
+    __syncthreads();                                 // every wave has left the operand ring
+    char *slab = smem + wave * SLAB_BYTES;
+    const int ml = lane & 15, nq = (lane >> 4) * 4;
+    const bool to_partial = p.splits > 1;
+    const int lrow = lane / LANES_PER_ROW;
+    const int c8 = (lane % LANES_PER_ROW) * 8;
+    const long n = nt0 * 16 + wn * WN_COLS + c8;     // first of this lane's 8 output channels
+    const bool n_full = (n + 8 <= p.N) && p.vec_ok;
+
+    // per-channel parameters of this lane's 8 outputs: two 16-byte loads each when aligned
+    float swv[8], bsv[8], wzv[8];
+    if (EPI != EPI_I32 && !to_partial) {
+        if (n_full && p.par_ok) {
+            const v4f s0 = *reinterpret_cast<const v4f *>(p.s_w + n), s1 = *reinterpret_cast<const v4f *>(p.s_w + n + 4);
+            v4f b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0, z0 = b0, z1 = b0;
+            if (p.bias) { b0 = *reinterpret_cast<const v4f *>(p.bias + n); b1 = *reinterpret_cast<const v4f *>(p.bias + n + 4); }
+            if (p.w0) { z0 = *reinterpret_cast<const v4f *>(p.w0 + n); z1 = *reinterpret_cast<const v4f *>(p.w0 + n + 4); }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                swv[e] = s0[e]; swv[4 + e] = s1[e];
+                bsv[e] = b0[e]; bsv[4 + e] = b1[e];
+                wzv[e] = z0[e]; wzv[4 + e] = z1[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const long nn = (n + e < p.N) ? n + e : p.N - 1;
+                swv[e] = (n < p.N) ? p.s_w[nn] : 0.0f;
+                bsv[e] = (p.bias && n < p.N) ? p.bias[nn] : 0.0f;
+                wzv[e] = (p.w0 && n < p.N) ? p.w0[nn] : 0.0f;
+            }
+        }
+    }
+    // per-row parameters (activation scale set, split term) are fetched once per pass, one row
+    // per lane, and parked behind the slab so the store loop never waits on global memory
+    float *rowpar = reinterpret_cast<float *>(slab + PASS_ROWS * SLAB_LD);   // [PASS_ROWS][2]
+
+#pragma unroll
+    for (int pass = 0; pass < TM / PASS_MT; ++pass) {
+#pragma unroll
+        for (int jj = 0; jj < PASS_MT; ++jj)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+                *reinterpret_cast<v4i *>(slab + (jj * 16 + ml) * SLAB_LD + (i * 16 + nq) * 4) =
+                    acc[i][pass * PASS_MT + jj];
+        if (EPI != EPI_I32 && !to_partial && lane < PASS_ROWS) {
+            const long mr = m0 + (wm * TM + pass * PASS_MT) * 16 + lane;
+            float sxl = p.sx0, xzl = 0.0f;
+            if (mr < p.M) {
+                if (p.sx_vec) sxl = p.sx_vec[mr];
+                else if (p.row_sel && p.row_sel[mr]) sxl = p.sx1;
+                if (p.x0) xzl = p.x0[mr];
+            }
+            rowpar[lane * 2] = sxl;
+            rowpar[lane * 2 + 1] = xzl;
+        }
+        // the slab is wave-private: LDS operations of one wave complete in order
+#pragma unroll 1
+        for (int r0 = 0; r0 < PASS_ROWS; r0 += ROWS_PER_IT) {
+            const int row = r0 + lrow;
+            const long m = m0 + (wm * TM + pass * PASS_MT) * 16 + row;
+            v4i q0 = *reinterpret_cast<const v4i *>(slab + row * SLAB_LD + c8 * 4);
+            v4i q1 = *reinterpret_cast<const v4i *>(slab + row * SLAB_LD + c8 * 4 + 16);
+            if (m >= p.M || n >= p.N) continue;
+            int a[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+            if (W_BITS == 4) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] >>= 4;
+            }
+            if (to_partial || EPI == EPI_I32) {
+                int *o = to_partial ? p.partial + ((long)split * p.M + m) * p.N + n
+                                    : reinterpret_cast<int *>(p.out) + m * p.ldo + n;
+                if (n_full) {
+                    *reinterpret_cast<v4i *>(o) = v4i{a[0], a[1], a[2], a[3]};
+                    *reinterpret_cast<v4i *>(o + 4) = v4i{a[4], a[5], a[6], a[7]};
+                } else {
+                    for (int e = 0; e < 8; ++e)
+                        if (n + e < p.N) o[e] = a[e];
+                }
+                continue;
+            }
+            const float sx = rowpar[row * 2];
+            const float xz = rowpar[row * 2 + 1];
+            float res[8];
+            if (p.residual) {   // issued ahead of the arithmetic below
+                if (EPI == EPI_F32) {
+                    const float *rp = reinterpret_cast<const float *>(p.residual) + m * p.ldr + n;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) res[e] = (n + e < p.N) ? rp[e] : 0.0f;
+                } else {
+                    const unsigned short *rp = reinterpret_cast<const unsigned short *>(p.residual) + m * p.ldr + n;
+                    if (n_full && p.res_vec) {
+                        const v8us rv = *reinterpret_cast<const v8us *>(rp);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            res[e] = (EPI == EPI_F16) ? f16_bits_to_f32(rv[e]) : bf16_bits_to_f32(rv[e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const unsigned short rb = (n + e < p.N) ? rp[e] : (unsigned short)0;
+                            res[e] = (EPI == EPI_F16) ? f16_bits_to_f32(rb) : bf16_bits_to_f32(rb);
+                        }
+                    }
+                }
+            }
+            float y[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = (float)a[e] * sx;
+                t = t * swv[e];
+                if (p.bias) t = t + bsv[e];
+                if (p.x0) {
+                    const float pr = xz * wzv[e];
+                    t = t + pr;
+                }
+                if (p.residual) {   // torch: hidden + linear(x), the Linear's output rounded first
+                    if (EPI == EPI_F16) t = f16_bits_to_f32(f32_to_f16_bits(t));
+                    if (EPI == EPI_BF16) t = bf16_bits_to_f32(f32_to_bf16_bits(t));
+                    t = t + res[e];
+                }
+                y[e] = t;
+            }
+            if (EPI == EPI_F32) {
+                float *o = reinterpret_cast<float *>(p.out) + m * p.ldo + n;
+                if (n_full) {
+                    *reinterpret_cast<v4f *>(o) = v4f{y[0], y[1], y[2], y[3]};
+                    *reinterpret_cast<v4f *>(o + 4) = v4f{y[4], y[5], y[6], y[7]};
+                } else {
+                    for (int e = 0; e < 8; ++e)
+                        if (n + e < p.N) o[e] = y[e];
+                }
+            } else {
+                v8us h;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    h[e] = (EPI == EPI_F16) ? f32_to_f16_bits(y[e]) : f32_to_bf16_bits(y[e]);
+                unsigned short *o = reinterpret_cast<unsigned short *>(p.out) + m * p.ldo + n;
+                if (n_full) {
+                    *reinterpret_cast<v8us *>(o) = h;
+                } else {
+                    for (int e = 0; e < 8; ++e)
+                        if (n + e < p.N) o[e] = h[e];
+                }
+            }
+        }
+    }
+}
+
+}  // namespace mq

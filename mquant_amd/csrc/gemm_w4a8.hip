@@ -26,285 +26,12 @@
 // Reference semantics: fake_quant/quant_utils.py:384 (F.linear on fake-quant tensors) and
 // :367-376 (split: channel 0 through L1 in fp32).
 #include "mq_common.h"
+#include "gemm_common.h"
 
 namespace mq {
 
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void gbl_void;
-
-__device__ __forceinline__ void dma16(const void *g, void *lds_wave_base)
-{
-    __builtin_amdgcn_global_load_lds((gbl_void *)g, (lds_void *)lds_wave_base, 16, 0, 0);
-}
-
-enum { EPI_F16 = MQ_F16, EPI_BF16 = MQ_BF16, EPI_F32 = MQ_F32, EPI_I32 = 3 };
-
-// Experiment switch for bottleneck hunting (never set in the shipped build): 1 = no DMA inside the
-// k-loop (compute side alone), 2 = no LDS reads / MFMA (DMA side alone).
-#ifndef MQ_EXP
-#define MQ_EXP 0
-#endif
-
-struct GemmArgs {
-    const int8_t *a;
-    long lda;
-    const uint8_t *w;
-    long M, N, K_pad;
-    long n_tiles;  // ceil(N / 16)
-    long n_pairs;  // ceil(N / 32): 16-channel tile pairs in the W4 image
-    float sx0, sx1;
-    const uint8_t *row_sel;
-    const float *sx_vec = nullptr;   // per-row activation scales (dynamic per-token quantizer); overrides sx0/sx1
-    const void *residual = nullptr;  // [M, ldr] in the output dtype: out = cast(cast(y) + residual)
-    long ldr = 0;
-    const float *s_w, *bias, *x0, *w0;
-    void *out;
-    long ldo;
-    int splits;        // split-K factor (1 = none)
-    int vec_ok;        // N, ldo multiples of 8 and a 16-byte aligned output
-    int par_ok;        // s_w / bias / w0 16-byte aligned
-    int res_vec;       // residual rows 16-byte aligned
-    int32_t *partial;  // [splits][M][N] when splits > 1
-};
-
-// y = ((float(acc) * sx) * s_w[n]) + bias[n] + x0 * w0[n]; one rounding per operation.
-template <int EPI>
-__device__ __forceinline__ void store_quad(const GemmArgs &p, long m, long n, v4i a, float sx,
-                                           float xz)
-{
-    const bool full = (n + 4 <= p.N) && (p.ldo % 4 == 0);
-    if (EPI == EPI_I32) {
-        int *o = reinterpret_cast<int *>(p.out) + m * p.ldo + n;
-        if (full) {
-            *reinterpret_cast<v4i *>(o) = a;
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (n + r < p.N) o[r] = a[r];
-        }
-        return;
-    }
-    float y[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const long nn = (n + r < p.N) ? n + r : p.N - 1;
-        float t = (float)a[r] * sx;
-        t = t * p.s_w[nn];
-        if (p.bias) t = t + p.bias[nn];
-        if (p.x0) {
-            const float pr = xz * p.w0[nn];
-            t = t + pr;
-        }
-        y[r] = t;
-    }
-    if (p.residual) {   // torch: hidden + linear(x): the Linear's output is rounded first
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (n + r >= p.N) continue;
-            if (EPI == EPI_F32) {
-                y[r] = y[r] + reinterpret_cast<const float *>(p.residual)[m * p.ldr + n + r];
-            } else {
-                const unsigned short rb = reinterpret_cast<const unsigned short *>(p.residual)[m * p.ldr + n + r];
-                y[r] = (EPI == EPI_F16) ? f16_bits_to_f32(f32_to_f16_bits(y[r])) + f16_bits_to_f32(rb)
-                                        : bf16_bits_to_f32(f32_to_bf16_bits(y[r])) + bf16_bits_to_f32(rb);
-            }
-        }
-    }
-    if (EPI == EPI_F32) {
-        float *o = reinterpret_cast<float *>(p.out) + m * p.ldo + n;
-        if (full) {
-            *reinterpret_cast<v4f *>(o) = v4f{y[0], y[1], y[2], y[3]};
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (n + r < p.N) o[r] = y[r];
-        }
-    } else {
-        unsigned short h[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            h[r] = (EPI == EPI_F16) ? f32_to_f16_bits(y[r]) : f32_to_bf16_bits(y[r]);
-        unsigned short *o = reinterpret_cast<unsigned short *>(p.out) + m * p.ldo + n;
-        if (full) {
-            *reinterpret_cast<v4us *>(o) = v4us{h[0], h[1], h[2], h[3]};
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (n + r < p.N) o[r] = h[r];
-        }
-    }
-}
-
-// ---- epilogue -------------------------------------------------------------------------------
-// Code executed once per workgroup is instruction-fetch bound (cold I-cache), so the epilogue is
-// kept SMALL: each wave parks its raw int32 accumulators in a private LDS slab with a handful of
-// unrolled ds_write_b128, then a ROLLED loop re-reads them row-contiguously, dequantises and
-// stores 16 B (fp16) / 32 B per lane: whole 128-byte row segments, edges in the same loop.
-template <int TM, int TN, int NWAVES, int RING_BYTES, int W_BITS, int EPI>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][TM], char *smem,
-                                              int wave, int lane, int wm, int wn, long m0, long nt0,
-                                              int split)
-{
-    // D layout: col = lane & 15 -> m, row = (lane >> 4) * 4 + r -> n
-    constexpr int WN_COLS = TN * 16;                 // columns of the wave's sub-tile
-    constexpr int SLAB_LD = WN_COLS * 4 + 16;        // bytes per slab row (+16: conflict-free)
-    constexpr int PASS_MT =                          // m-tiles parked per pass (slab must fit)
-        (TM % 4 == 0 && NWAVES * 64 * (SLAB_LD + 8) <= RING_BYTES) ? 4
-        : (TM % 2 == 0 && NWAVES * 32 * (SLAB_LD + 8) <= RING_BYTES) ? 2 : 1;
-    constexpr int PASS_ROWS = PASS_MT * 16;
-    constexpr int SLAB_BYTES = PASS_ROWS * SLAB_LD + PASS_ROWS * 8;
-    constexpr int LANES_PER_ROW = WN_COLS / 8;       // 8 outputs per lane
-    constexpr int ROWS_PER_IT = 64 / LANES_PER_ROW;
-    static_assert(NWAVES * SLAB_BYTES <= RING_BYTES, "epilogue slab must fit the ring");
-    static_assert(TM % PASS_MT == 0 && 64 % LANES_PER_ROW == 0 && PASS_ROWS % ROWS_PER_IT == 0, "epilogue geometry");
-
-    __syncthreads();                                 // every wave has left the operand ring
-    char *slab = smem + wave * SLAB_BYTES;
-    const int ml = lane & 15, nq = (lane >> 4) * 4;
-    const bool to_partial = p.splits > 1;
-    const int lrow = lane / LANES_PER_ROW;
-    const int c8 = (lane % LANES_PER_ROW) * 8;
-    const long n = nt0 * 16 + wn * WN_COLS + c8;     // first of this lane's 8 output channels
-    const bool n_full = (n + 8 <= p.N) && p.vec_ok;
-
-    // per-channel parameters of this lane's 8 outputs: two 16-byte loads each when aligned
-    float swv[8], bsv[8], wzv[8];
-    if (EPI != EPI_I32 && !to_partial) {
-        if (n_full && p.par_ok) {
-            const v4f s0 = *reinterpret_cast<const v4f *>(p.s_w + n), s1 = *reinterpret_cast<const v4f *>(p.s_w + n + 4);
-            v4f b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0, z0 = b0, z1 = b0;
-            if (p.bias) { b0 = *reinterpret_cast<const v4f *>(p.bias + n); b1 = *reinterpret_cast<const v4f *>(p.bias + n + 4); }
-            if (p.w0) { z0 = *reinterpret_cast<const v4f *>(p.w0 + n); z1 = *reinterpret_cast<const v4f *>(p.w0 + n + 4); }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                swv[e] = s0[e]; swv[4 + e] = s1[e];
-                bsv[e] = b0[e]; bsv[4 + e] = b1[e];
-                wzv[e] = z0[e]; wzv[4 + e] = z1[e];
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const long nn = (n + e < p.N) ? n + e : p.N - 1;
-                swv[e] = (n < p.N) ? p.s_w[nn] : 0.0f;
-                bsv[e] = (p.bias && n < p.N) ? p.bias[nn] : 0.0f;
-                wzv[e] = (p.w0 && n < p.N) ? p.w0[nn] : 0.0f;
-            }
-        }
-    }
-    // per-row parameters (activation scale set, split term) are fetched once per pass, one row
-    // per lane, and parked behind the slab so the store loop never waits on global memory
-    float *rowpar = reinterpret_cast<float *>(slab + PASS_ROWS * SLAB_LD);   // [PASS_ROWS][2]
-
-#pragma unroll
-    for (int pass = 0; pass < TM / PASS_MT; ++pass) {
-#pragma unroll
-        for (int jj = 0; jj < PASS_MT; ++jj)
-#pragma unroll
-            for (int i = 0; i < TN; ++i)
-                *reinterpret_cast<v4i *>(slab + (jj * 16 + ml) * SLAB_LD + (i * 16 + nq) * 4) =
-                    acc[i][pass * PASS_MT + jj];
-        if (EPI != EPI_I32 && !to_partial && lane < PASS_ROWS) {
-            const long mr = m0 + (wm * TM + pass * PASS_MT) * 16 + lane;
-            float sxl = p.sx0, xzl = 0.0f;
-            if (mr < p.M) {
-                if (p.sx_vec) sxl = p.sx_vec[mr];
-                else if (p.row_sel && p.row_sel[mr]) sxl = p.sx1;
-                if (p.x0) xzl = p.x0[mr];
-            }
-            rowpar[lane * 2] = sxl;
-            rowpar[lane * 2 + 1] = xzl;
-        }
-        // the slab is wave-private: LDS operations of one wave complete in order
-#pragma unroll 1
-        for (int r0 = 0; r0 < PASS_ROWS; r0 += ROWS_PER_IT) {
-            const int row = r0 + lrow;
-            const long m = m0 + (wm * TM + pass * PASS_MT) * 16 + row;
-            v4i q0 = *reinterpret_cast<const v4i *>(slab + row * SLAB_LD + c8 * 4);
-            v4i q1 = *reinterpret_cast<const v4i *>(slab + row * SLAB_LD + c8 * 4 + 16);
-            if (m >= p.M || n >= p.N) continue;
-            int a[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
-            if (W_BITS == 4) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) a[e] >>= 4;
-            }
-            if (to_partial || EPI == EPI_I32) {
-                int *o = to_partial ? p.partial + ((long)split * p.M + m) * p.N + n
-                                    : reinterpret_cast<int *>(p.out) + m * p.ldo + n;
-                if (n_full) {
-                    *reinterpret_cast<v4i *>(o) = v4i{a[0], a[1], a[2], a[3]};
-                    *reinterpret_cast<v4i *>(o + 4) = v4i{a[4], a[5], a[6], a[7]};
-                } else {
-                    for (int e = 0; e < 8; ++e)
-                        if (n + e < p.N) o[e] = a[e];
-                }
-                continue;
-            }
-            const float sx = rowpar[row * 2];
-            const float xz = rowpar[row * 2 + 1];
-            float res[8];
-            if (p.residual) {   // issued ahead of the arithmetic below
-                if (EPI == EPI_F32) {
-                    const float *rp = reinterpret_cast<const float *>(p.residual) + m * p.ldr + n;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) res[e] = (n + e < p.N) ? rp[e] : 0.0f;
-                } else {
-                    const unsigned short *rp = reinterpret_cast<const unsigned short *>(p.residual) + m * p.ldr + n;
-                    if (n_full && p.res_vec) {
-                        const v8us rv = *reinterpret_cast<const v8us *>(rp);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            res[e] = (EPI == EPI_F16) ? f16_bits_to_f32(rv[e]) : bf16_bits_to_f32(rv[e]);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const unsigned short rb = (n + e < p.N) ? rp[e] : (unsigned short)0;
-                            res[e] = (EPI == EPI_F16) ? f16_bits_to_f32(rb) : bf16_bits_to_f32(rb);
-                        }
-                    }
-                }
-            }
-            float y[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float t = (float)a[e] * sx;
-                t = t * swv[e];
-                if (p.bias) t = t + bsv[e];
-                if (p.x0) {
-                    const float pr = xz * wzv[e];
-                    t = t + pr;
-                }
-                if (p.residual) {   // torch: hidden + linear(x), the Linear's output rounded first
-                    if (EPI == EPI_F16) t = f16_bits_to_f32(f32_to_f16_bits(t));
-                    if (EPI == EPI_BF16) t = bf16_bits_to_f32(f32_to_bf16_bits(t));
-                    t = t + res[e];
-                }
-                y[e] = t;
-            }
-            if (EPI == EPI_F32) {
-                float *o = reinterpret_cast<float *>(p.out) + m * p.ldo + n;
-                if (n_full) {
-                    *reinterpret_cast<v4f *>(o) = v4f{y[0], y[1], y[2], y[3]};
-                    *reinterpret_cast<v4f *>(o + 4) = v4f{y[4], y[5], y[6], y[7]};
-                } else {
-                    for (int e = 0; e < 8; ++e)
-                        if (n + e < p.N) o[e] = y[e];
-                }
-            } else {
-                v8us h;
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    h[e] = (EPI == EPI_F16) ? f32_to_f16_bits(y[e]) : f32_to_bf16_bits(y[e]);
-                unsigned short *o = reinterpret_cast<unsigned short *>(p.out) + m * p.ldo + n;
-                if (n_full) {
-                    *reinterpret_cast<v8us *>(o) = h;
-                } else {
-                    for (int e = 0; e < 8; ++e)
-                        if (n + e < p.N) o[e] = h[e];
-                }
-            }
-        }
-    }
-}
+template <int W_BITS, int EPI>
+int dispatch_ws(const GemmArgs &p, int tile, hipStream_t st);   // gemm_ws.hip (tiled activations only)
 
 template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int W_BITS, int EPI, int DMA_POS>
 __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmArgs p)
@@ -329,27 +56,14 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WARPS_N, wn = wave % WARPS_N;
 
-    // ---- workgroup -> (split, bn, bm), XCD-aware and bijective ------------------------
-    const int m_blocks = (int)ceil_div(p.M, BM);
-    const int total = gridDim.x;
-    int wid;
-    {
-        const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
-        const int q = total >> 3, r = total & 7;
-        wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int bm = wid % m_blocks;
-    const int rest = wid / m_blocks;
-    const int n_blocks = total / (m_blocks * p.splits);
-    const int bn = rest % n_blocks;                // split-K: one XCD works on ONE k-slice, so its
-    const int split = rest / n_blocks;             // L2 holds that slice of A once for all its tiles
+    // ---- workgroup -> (split, bn, bm), XCD-aware and bijective (gemm_common.h) ---------
+    int bm, bn, split, kb, nk;
+    tile_of_block(p, bm, bn, split);               // split-K: one XCD works on ONE k-slice, so its L2
+    k_range_of_split(p, split, kb, nk);            // holds that slice of A once for all its tiles
     const long m0 = (long)bm * BM;
     const long nt0 = (long)bn * (BN / 16);
-
-    const long kps = p.K_pad / 128;  // k-steps in the whole reduction
-    const long k_begin = kps * split / p.splits;
-    const long k_end = kps * (split + 1) / p.splits;
-    const int nk = (int)(k_end - k_begin);
+    const long kps = p.K_pad >> 7;                 // k-steps in the whole reduction
+    const long k_begin = kb;
 
     // ---- per-lane DMA source addresses (piece f = wave + i*NWAVES) ----------------------
     const char *src[LPW];
@@ -364,6 +78,13 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
             src[i] = reinterpret_cast<const char *>(p.a) + row * p.lda + kt * 64 + (lane >> 4) * 16 +
                      k_begin * 128;
             step_bytes[i] = 128;
+            if (p.a_tiled) {   // one contiguous KiB per (16-row tile, k-tile): 3x the L2 rate of the row gather
+                long mtg = m0 / 16 + mt;
+                const long MT = (p.M + 15) >> 4;
+                if (mtg >= MT) mtg = MT - 1;
+                src[i] = reinterpret_cast<const char *>(p.a) + ((mtg * (p.K_pad >> 6) + k_begin * 2 + kt) * 64 + lane) * 16;
+                step_bytes[i] = 2048;
+            }
         } else if (W_BITS == 4) {
             // piece g = (n-tile pair, k-tile of the step): image [ntp][kt][lane][16 B]
             const int g = f - X_FRAGS;
@@ -400,10 +121,10 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
     // ---- main loop ------------------------------------------------------------------------
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
-        if (s < nk) issue_stage(s, s);
+        if (MQ_EXP != 5 && s < nk) issue_stage(s, s);
 
     int cur = 0;
-    for (int it = 0; it < nk; ++it) {
+    for (int it = 0; it < (MQ_EXP == 5 ? 0 : nk); ++it) {
         // stage `it` has landed when at most the (STAGES-2) younger stages are outstanding
         const int younger = nk - 1 - it;
         if (younger >= STAGES - 2) {
@@ -460,6 +181,15 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
         if (++cur == STAGES) cur = 0;
     }
 
+    if (MQ_EXP == 4) {   // timing experiment: everything but the epilogue
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) t ^= acc[i][j][0] ^ acc[i][j][1] ^ acc[i][j][2] ^ acc[i][j][3];
+        if (t == 0x12345678) reinterpret_cast<int *>(p.out)[0] = t;
+        return;
+    }
     gemm_epilogue<TM, TN, NWAVES, STAGES * STAGE_BYTES, W_BITS, EPI>(p, acc, smem, wave, lane, wm, wn, m0, nt0, split);
 }
 
@@ -526,26 +256,13 @@ __global__ __launch_bounds__(512) void gemm_w4a8_pipe_kernel(GemmArgs p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WARPS_N, wn = wave % WARPS_N;
 
-    const int m_blocks = (int)ceil_div(p.M, BM);
-    const int total = gridDim.x;
-    int wid;
-    {
-        const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
-        const int q = total >> 3, r = total & 7;
-        wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int bm = wid % m_blocks;
-    const int rest = wid / m_blocks;
-    const int n_blocks = total / (m_blocks * p.splits);
-    const int bn = rest % n_blocks;                // split-K: one XCD works on ONE k-slice, so its
-    const int split = rest / n_blocks;             // L2 holds that slice of A once for all its tiles
+    int bm, bn, split, ktb, nt;
+    tile_of_block(p, bm, bn, split);
+    k_range_of_split(p, split, ktb, nt);                     // in 64-wide k-tiles for this kernel
     const long m0 = (long)bm * BM;
     const long nt0 = (long)bn * (BN / 16);
-
-    const long kts = p.K_pad / 64;
-    const long kt_begin = kts * split / p.splits;
-    const long kt_end = kts * (split + 1) / p.splits;
-    const int nt = (int)(kt_end - kt_begin);                // k-tiles of this workgroup
+    const long kts = p.K_pad >> 6;
+    const long kt_begin = ktb;
 
     const char *src[LPW];
     int step_bytes[LPW];
@@ -557,6 +274,13 @@ __global__ __launch_bounds__(512) void gemm_w4a8_pipe_kernel(GemmArgs p)
             if (row >= p.M) row = p.M - 1;
             src[i] = reinterpret_cast<const char *>(p.a) + row * p.lda + (lane >> 4) * 16 + kt_begin * 64;
             step_bytes[i] = 64;
+            if (p.a_tiled) {
+                long mtg = m0 / 16 + f;
+                const long MT = (p.M + 15) >> 4;
+                if (mtg >= MT) mtg = MT - 1;
+                src[i] = reinterpret_cast<const char *>(p.a) + ((mtg * kts + kt_begin) * 64 + lane) * 16;
+                step_bytes[i] = 1024;
+            }
         } else {
             long ntp = nt0 / 2 + (f - X_PIECES);
             if (ntp >= p.n_pairs) ntp = p.n_pairs - 1;
@@ -671,15 +395,13 @@ static int launch_gemm_pipe(const GemmArgs &p, hipStream_t st)
 {
     constexpr int SMEM = 6 * 24 * 1024;
     auto kern = gemm_w4a8_pipe_kernel<EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        if (e != hipSuccess) return fail((int)e, "gemm: set smem attr: %s", hipGetErrorString(e));
-        attr_set = true;
+    {
+        const int rc = ensure_dynamic_lds((const void *)kern, SMEM);
+        if (rc != MQ_OK) return rc;
     }
-    const long m_blocks = ceil_div(p.M, 256);
-    const long n_blocks = ceil_div(p.n_tiles * 16, 256);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(m_blocks * n_blocks * p.splits)), dim3(512), SMEM, st, p);
+    GemmArgs g = p;
+    set_geometry(g, 256, 256, 64);
+    hipLaunchKernelGGL(kern, dim3(g.m_blocks * g.n_blocks * (unsigned)g.splits), dim3(512), SMEM, st, g);
     int rc = check_launch("gemm_w4a8_pipe");
     if (rc != MQ_OK || p.splits == 1) return rc;
     long blocks = ceil_div(p.M * ceil_div(p.N, 4), 256);
@@ -694,17 +416,14 @@ static int launch_gemm(const GemmArgs &p, hipStream_t st)
     constexpr int PIECES = (BM / 16) * 2 + ((W_BITS == 4) ? (BN / 16) : (BN / 16) * 2);
     constexpr int SMEM = STAGES * PIECES * 1024;
     auto kern = gemm_w4a8_kernel<BM, BN, WARPS_M, WARPS_N, STAGES, W_BITS, EPI, DMA_POS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        if (e != hipSuccess) return fail((int)e, "gemm: set smem attr: %s", hipGetErrorString(e));
-        attr_set = true;
+    {
+        const int rc = ensure_dynamic_lds((const void *)kern, SMEM);
+        if (rc != MQ_OK) return rc;
     }
-    const long m_blocks = ceil_div(p.M, BM);
-    const long n_blocks = ceil_div(p.n_tiles * 16, BN);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(m_blocks * n_blocks * p.splits)),
-                       dim3(WARPS_M * WARPS_N * 64), SMEM, st, p);
+    GemmArgs g = p;
+    set_geometry(g, BM, BN, 128);
+    hipLaunchKernelGGL(kern, dim3(g.m_blocks * g.n_blocks * (unsigned)g.splits),
+                       dim3(WARPS_M * WARPS_N * 64), SMEM, st, g);
     int rc = check_launch("gemm_w4a8");
     if (rc != MQ_OK || p.splits == 1) return rc;
     long blocks = ceil_div(p.M * ceil_div(p.N, 4), 256);
@@ -726,26 +445,38 @@ struct Plan {
 };
 
 static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes, int force_tile,
-                      int force_splits, bool w4 = true)
+                      int force_splits, bool w4 = true, bool a_tiled = false)
 {
     const long kps = K_pad / 128;
     const long t256 = ceil_div(M, 256) * ceil_div(N, 256);
-    const long t128 = ceil_div(M, 128) * ceil_div(N, 128);
-    // Small GEMMs are bound by the L2 -> L1 -> LDS path (~22 B/clk/CU measured, tools/probes/
-    // l1_to_lds_rate.hip), i.e. by the bytes the busiest CU has to pull: ceil(tiles/256) x (BM + BN/2)
-    // per unit of K.  Pick the shape that minimises that (measured ranking agrees).
-    static const int cand[][3] = {{10, 64, 128}, {31, 96, 128}, {26, 128, 128}, {35, 192, 128}, {2, 256, 128}};
     Plan pl = {10, 1};
     long best = -1;
-    for (const auto &c : cand) {
-        if (c[0] == 35 && !w4) continue;
-        const long tiles = ceil_div(M, c[1]) * ceil_div(N, c[2]);
-        const long cost = ceil_div(tiles, 256) * (c[1] + (w4 ? c[2] / 2 : c[2]));   // int8 weights: one byte each
-        if (best < 0 || cost < best) { best = cost; pl.tile = c[0]; }
+    if (a_tiled) {
+        // wave-specialised kernels (gemm_ws.hip), every operand byte arrives as contiguous KiB pieces:
+        // the bytes the busiest CU has to pull decide, ceil(tiles/256) x (BM + BN/2) per unit of K
+        static const int cand[][3] = {{43, 64, 128}, {40, 96, 128}, {41, 128, 128}, {42, 192, 128}};
+        for (const auto &c : cand) {
+            if (c[0] == 42 && !w4) continue;
+            const long tiles = ceil_div(M, c[1]) * ceil_div(N, c[2]);
+            const long cost = ceil_div(tiles, 256) * (c[1] + (w4 ? c[2] / 2 : c[2]));
+            if (best < 0 || cost < best) { best = cost; pl.tile = c[0]; }
+        }
+    } else {
+        // Row-major activations: small GEMMs are bound by the row gather (~14.5 B/clk/CU out of L2,
+        // tools/probes/l2_row_stride.hip); same cost model over the symmetric kernels.
+        static const int cand[][3] = {{10, 64, 128}, {31, 96, 128}, {26, 128, 128}, {35, 192, 128}, {2, 256, 128}};
+        for (const auto &c : cand) {
+            if (c[0] == 35 && !w4) continue;
+            const long tiles = ceil_div(M, c[1]) * ceil_div(N, c[2]);
+            const long cost = ceil_div(tiles, 256) * (c[1] + (w4 ? c[2] / 2 : c[2]));   // int8 weights: one byte each
+            if (best < 0 || cost < best) { best = cost; pl.tile = c[0]; }
+        }
     }
-    (void)t128;
     if (t256 >= 192) {
         pl.tile = 3;
+    } else if (a_tiled && best >= 0 && ceil_div(M, 96) * ceil_div(N, 128) >= 128) {
+        // enough 96..192 x 128 tiles for most CUs: the wave-specialised kernel walks the whole reduction
+        // (down_proj, K = 19968: 64 us against 60 + 14 us for split-K partials plus the reduce kernel)
     } else if (have_ws && kps >= 64 && t256 >= 8) {
         long s = (252 + t256 - 1) / t256;
         if (s > 8) s = 8;
@@ -764,6 +495,15 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
 template <int W_BITS, int EPI>
 static int dispatch_tile(const GemmArgs &p, int tile, hipStream_t st)
 {
+    if (tile >= 40 && tile < 60) {
+        if (!p.a_tiled) return fail(MQ_EINVAL, "mq_gemm_w4a8: tile %d needs activations in the tiled layout (lda = MQ_LD_TILED)", tile);
+        const int rc = dispatch_ws<W_BITS, EPI>(p, tile, st);
+        if (rc != MQ_OK || p.splits == 1) return rc;
+        long blocks = ceil_div(p.M * ceil_div(p.N, 4), 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel<EPI>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+        return check_launch("splitk_reduce");
+    }
     switch (tile) {
     case 1:
         if constexpr (W_BITS == 4) return launch_gemm<256, 256, 2, 4, 3, W_BITS, EPI>(p, st);
@@ -799,8 +539,9 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
     if (M == 0 || N == 0) return MQ_OK;
     MQ_REQUIRE(a && w && out, "mq_gemm_w4a8: null buffer");
     MQ_REQUIRE(K_pad > 0 && K_pad % 128 == 0, "mq_gemm_w4a8: K_pad=%ld must be a positive multiple of 128", K_pad);
-    MQ_REQUIRE(lda >= K_pad && lda % 16 == 0 && ((uintptr_t)a) % 16 == 0,
-               "mq_gemm_w4a8: activations must be 16-byte aligned with lda %% 16 == 0 and lda >= K_pad");
+    const bool a_tiled = (lda == MQ_LD_TILED);
+    MQ_REQUIRE(((uintptr_t)a) % 16 == 0 && (a_tiled || (lda >= K_pad && lda % 16 == 0)),
+               "mq_gemm_w4a8: activations must be 16-byte aligned with lda %% 16 == 0 and lda >= K_pad (or lda = MQ_LD_TILED)");
     MQ_REQUIRE(((uintptr_t)w) % 16 == 0, "mq_gemm_w4a8: weight image must be 16-byte aligned");
     MQ_REQUIRE(w_bits == 4 || w_bits == 8, "mq_gemm_w4a8: w_bits must be 4 or 8");
     MQ_REQUIRE(ldo >= N, "mq_gemm_w4a8: ldo < N");
@@ -810,7 +551,7 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
     MQ_REQUIRE(K_pad <= 131072L, "mq_gemm_w4a8: K too large for int32 accumulation");
     MQ_REQUIRE(!workspace || ((uintptr_t)workspace) % 16 == 0, "mq_gemm_w4a8: workspace must be 16-byte aligned");
     GemmArgs p;
-    p.a = a; p.lda = lda; p.w = (const uint8_t *)w; p.M = M; p.N = N; p.K_pad = K_pad;
+    p.a = a; p.lda = lda; p.a_tiled = a_tiled; p.w = (const uint8_t *)w; p.M = M; p.N = N; p.K_pad = K_pad;
     p.n_tiles = ceil_div(N, 16);
     p.n_pairs = ceil_div(N, 32);
     p.sx0 = s_x0; p.sx1 = s_x1; p.row_sel = row_sel; p.s_w = s_w; p.bias = bias; p.x0 = x0; p.w0 = w0;
@@ -820,7 +561,7 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
     p.res_vec = residual && (((uintptr_t)residual) % 16 == 0) && ((ldr * ((epi == EPI_F32) ? 4 : 2)) % 16 == 0);
     p.out = out; p.ldo = ldo;
     const Plan pl = make_plan(M, N, K_pad, workspace != nullptr, workspace_bytes, g_force_tile,
-                              workspace ? g_force_splits : 0, w_bits == 4);
+                              workspace ? g_force_splits : 0, w_bits == 4, a_tiled);
     p.splits = pl.splits;
     p.partial = (int32_t *)workspace;
     auto al16 = [](const void *q) { return q == nullptr || ((uintptr_t)q) % 16 == 0; };
@@ -917,8 +658,8 @@ extern "C" int mq_gemm_w4a8_i32_ws(const int8_t *a, long lda, const void *w, int
                            stream);
 }
 
-// Tuning / test hook: force a tile shape (-1 = heuristic; 0: 128x128, 1: 256x256, 2: 256x128)
-// and a split-K factor (0 = heuristic).  Process-wide; not part of the drop-in surface.
+// Tuning / test hook: force a tile shape (-1 = heuristic; the ids are the cases of dispatch_tile /
+// dispatch_ws) and a split-K factor (0 = heuristic).  Process-wide; not part of the drop-in surface.
 extern "C" int mq_gemm_debug_force(int tile, int splits)
 {
     mq::g_force_tile = tile;

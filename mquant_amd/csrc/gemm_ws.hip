@@ -1,0 +1,554 @@
+// gemm_ws.hip -- wave-specialised W4A8 GEMM for the shapes whose M x N output cannot feed 256 CUs
+// with 256 x 256 tiles (every Linear of the prefill except gate_up / down_proj).
+//
+// Measurements that shaped it (tools/probes/l2_read_rate.hip, l2_row_stride.hip):
+//   * a CU pulls 40-50 B/clk out of its XCD's L2 when every wave instruction fetches 1 KiB of
+//     CONTIGUOUS bytes, but only ~14.5 B/clk when the instruction gathers rows of a row-major
+//     matrix (8 x 128 B, 16 x 64 B, 4 x 256 B alike).  The activation operand therefore arrives
+//     in the TILED layout ([M/16][K/64] pieces of 1 KiB in MFMA-fragment order, written that way
+//     by the quantizer kernels): every LDS-DMA of this kernel is one contiguous KiB;
+//   * with one wave per SIMD nothing overlaps: LDS-DMA issue (60-180 cycles each), ds_read
+//     latency and the MFMA chain of a k-step add up (0.45 us per 128-byte k-step for a 96 x 128
+//     tile whose MFMAs need 0.16 us).  Here the roles are split: NL LOADER waves issue every
+//     LDS-DMA and own the vmcnt bookkeeping, the MATH waves only read fragments and issue MFMAs,
+//     with the fragments of the next half k-step already on their way while the current ones
+//     feed the matrix core.  A SIMD hosts one wave of each kind;
+//   * ~4 us of every launch used to be epilogue latency (parameter fetches in front of the
+//     stores).  The math waves fetch the per-channel / per-row parameters into LDS while the
+//     loaders fill the first stage; after the k-loop ALL waves dequantise and store.
+//
+// Synchronisation: one s_barrier per k-step, B(0), B(1), ... B(nk):
+//   B(0):     stage 0 has landed (loaders waited with a counted vmcnt); parameters are in LDS
+//   B(it+1):  stage it+1 has landed; every math wave has finished step it-1, so the slot of stage
+//             it-1 is free and the loaders refill it with stage it-1+S
+//   math, step it:  B(it+1) | read (it, kt1) | MFMA (it, kt0) | read (it+1, kt0) | MFMA (it, kt1)
+#include "gemm_common.h"
+
+// Debug build only (-DMQ_STAMP): cycle stamps of workgroup 0 (math wave 0: slots 0-7, loader wave 0:
+// slots 8-15) into the split-K workspace, read back by tools/gemm_stamps.py.
+#ifdef MQ_STAMP
+#define MQ_STAMP_AT(i) do { if (blockIdx.x == MQ_STAMP && lane == 0 && (wave == 0 || wave == NM) && p.partial) \
+    reinterpret_cast<long long *>(p.partial)[(wave >= NM ? 8 : 0) + (i)] = (long long)clock64(); } while (0)
+#define MQ_STAMP_T() ((long long)clock64())
+#define MQ_STAMP_ACC(v, t0) do { const long long t1_ = MQ_STAMP_T(); (v) += t1_ - (t0); (t0) = t1_; } while (0)
+#define MQ_STAMP_PUT(i, v) do { if (blockIdx.x == MQ_STAMP && lane == 0 && (wave == 0 || wave == NM) && p.partial) \
+    reinterpret_cast<long long *>(p.partial)[i] = (v); } while (0)
+#else
+#define MQ_STAMP_AT(i) do { } while (0)
+#define MQ_STAMP_T() 0LL
+#define MQ_STAMP_ACC(v, t0) do { } while (0)
+#define MQ_STAMP_PUT(i, v) do { } while (0)
+#endif
+
+namespace mq {
+
+template <int BM, int BN, int MW_M, int MW_N, int KS, int NL, int S, int W_BITS, int EPI>
+__global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(GemmArgs p)
+{
+    // Math waves: MW_M x MW_N wave tiles, times KS "k groups".  A single wave cannot overlap its own
+    // VALU / LDS instructions with its MFMAs (12 MFMAs alone: 0.19 us per k-step, with the 24 unpack
+    // VALU between them: 0.30 us, tools/probes/math_loop.hip), a second wave on the SIMD can.  Small
+    // tiles offer only four 32-wide wave tiles, so with KS = 2 two groups of four waves share them:
+    // group g takes the K = 32 sub-steps of parity g into its own accumulators, the epilogue adds
+    // the two partial sums (integers: exact and order-free).
+    constexpr int NMT = MW_M * MW_N;                // wave tiles
+    constexpr int NM = NMT * KS;                    // math waves
+    constexpr int NT = (NM + NL) * 64;              // threads
+    constexpr int TM = BM / MW_M / 32;              // 32-row activation fragments per math wave
+    constexpr int TN = BN / MW_N / 32;              // 32-channel weight fragments per math wave
+    constexpr int A_PIECES = (BM / 16) * 2;         // 1 KiB pieces per stage (two k-tiles)
+    constexpr int W_PIECES = (W_BITS == 4) ? (BN / 32) * 2 : (BN / 16) * 2;
+    constexpr int PIECES = A_PIECES + W_PIECES;
+    constexpr int LPW = PIECES / NL;                // LDS-DMA instructions per loader wave per stage
+    constexpr int A_BYTES = A_PIECES * 1024;
+    constexpr int STAGE = PIECES * 1024;
+    constexpr int RING = S * STAGE;
+    constexpr int PITCH = BN * 4 + 16;              // epilogue slab row pitch (bytes)
+    static_assert(BM % (MW_M * 32) == 0 && BN % (MW_N * 32) == 0, "tile shape");
+    static_assert(PIECES % NL == 0, "pieces must divide over the loader waves");
+    static_assert(S >= 4 && S <= 8 && (S - 3) * LPW < 64, "ring depth (vmcnt is 6 bits)");
+    static_assert(KS == 1 || KS == 2, "k groups");
+    static_assert(KS * BM * PITCH <= RING, "epilogue slab(s) must fit the ring");
+    static_assert(NM * 64 >= BN && NM * 64 >= BM, "parameter prefetch: one thread per channel / row");
+    static_assert(KS == 1 || (W_BITS == 4 ? true : true), "k groups");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *par_sw = reinterpret_cast<float *>(smem + RING);      // [BN] weight scales
+    float *par_bs = par_sw + BN;                                  // [BN] bias
+    float *par_wz = par_bs + BN;                                  // [BN] w0 (split term)
+    float *par_sx = par_wz + BN;                                  // [BM] activation scale of the row
+    float *par_xz = par_sx + BM;                                  // [BM] x0 of the row
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    MQ_STAMP_AT(0);
+
+    // ---- workgroup -> (split, bn, bm), XCD-aware and bijective (gemm_common.h) ---------------------
+    int bm, bn, split, kb, nk;
+    tile_of_block(p, bm, bn, split);
+    k_range_of_split(p, split, kb, nk);
+    const long m0 = (long)bm * BM;
+    const long nt0 = (long)bn * (BN / 16);
+    const long n0 = nt0 * 16;
+    const long kps = p.K_pad >> 7;
+    const long k_begin = kb;
+
+    // Accumulators: with fewer than six 32x32 tiles per wave consecutive K = 32 sub-steps would form
+    // a dependent MFMA chain only three or four instructions long and every VALU / LDS instruction
+    // between two sub-steps would add to it (tools/probes/math_loop.hip: 520 -> 760 cycles per k-step);
+    // even and odd sub-steps therefore accumulate into separate sets, added at the end (integers: exact).
+    constexpr int NACC = (KS == 1 && TM * TN < 6) ? 2 : 1;
+    v16i acc[NACC][TN][TM];
+
+    if (wave >= NM) {
+        // =========================== loader waves ===========================================
+        const int lw = wave - NM;
+        __builtin_amdgcn_s_setprio(2);               // a loader's few instructions go ahead of the math waves' streams
+        const long KT = p.K_pad >> 6, MT = (p.M + 15) >> 4;
+        const char *src[LPW];
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const int f = lw + i * NL;
+            if (f < A_PIECES) {
+                long mt = m0 / 16 + (f >> 1);
+                if (mt >= MT) mt = MT - 1;
+                src[i] = reinterpret_cast<const char *>(p.a) + ((mt * KT + k_begin * 2 + (f & 1)) * 64 + lane) * 16;
+            } else if (W_BITS == 4) {
+                const int g = f - A_PIECES;
+                long ntp = nt0 / 2 + (g >> 1);
+                if (ntp >= p.n_pairs) ntp = p.n_pairs - 1;
+                src[i] = reinterpret_cast<const char *>(p.w) + (((ntp * kps + k_begin) * 2 + (g & 1)) * 64 + lane) * 16;
+            } else {
+                const int g = f - A_PIECES;
+                long nt = nt0 + (g >> 1);
+                if (nt >= p.n_tiles) nt = p.n_tiles - 1;
+                src[i] = reinterpret_cast<const char *>(p.w) + (((nt * kps + k_begin) * 2 + (g & 1)) * 64 + lane) * 16;
+            }
+        }
+        auto issue = [&](int slot, int st) {
+            char *base = smem + slot * STAGE;
+#pragma unroll
+            for (int i = 0; i < LPW; ++i) dma16(src[i] + (long)st * 2048, base + (lw + i * NL) * 1024);
+        };
+        auto wait_younger = [&](int younger) {      // at most `younger` stages may still be in flight
+#define MQ_WS_WAIT(k) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((k) * LPW < 64 ? (k) * LPW : 0) : "memory")
+            switch (younger) {
+            case 0: MQ_WS_WAIT(0); break;
+            case 1: MQ_WS_WAIT(1); break;
+            case 2: MQ_WS_WAIT(2); break;
+            case 3: MQ_WS_WAIT(3); break;
+            case 4: MQ_WS_WAIT(4); break;
+            case 5: MQ_WS_WAIT(5); break;
+            case 6: MQ_WS_WAIT(6); break;
+            case 7: MQ_WS_WAIT(7); break;
+            default: MQ_WS_WAIT(0); break;
+            }
+        };
+        const int pre = nk < S ? nk : S;
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+            if (s < pre) issue(s, s);
+        MQ_STAMP_AT(1);
+        wait_younger(pre - 1);                       // stage 0 landed
+        MQ_STAMP_AT(2);
+        __builtin_amdgcn_s_barrier();                // B(0)
+        MQ_STAMP_AT(3);
+        int last = pre - 1;                          // last stage issued
+        int slot = S - 1;                            // slot of stage it-1 (refilled at B(it+1)), it = 0: none
+        long long tw = 0, tb = 0, ti = 0, tt = MQ_STAMP_T();
+        for (int it = 0; it < nk; ++it) {
+            const int need = it + 1 < nk ? it + 1 : nk - 1;
+            const int younger = last - need;
+            if (younger == S - 3) MQ_WS_WAIT(S - 3);   // steady state: S-3 stages stay in flight across the barrier
+            else wait_younger(younger > 0 ? younger : 0);
+            __builtin_amdgcn_s_barrier();            // B(it+1)
+            MQ_STAMP_ACC(tb, tt);
+#ifdef MQ_STAMP
+            if (it < 200) MQ_STAMP_PUT(32 + it, tt);   // barrier release times = step boundaries
+#endif
+            if (it >= 1 && last + 1 < nk) {
+                if (MQ_EXP != 6) issue(slot, last + 1);   // MQ_EXP 6: timing experiment, no LDS-DMA inside the k-loop
+                ++last;
+            }
+            if (++slot == S) slot = 0;
+        }
+        MQ_STAMP_PUT(16, tw); MQ_STAMP_PUT(17, tb); MQ_STAMP_PUT(18, ti);
+        __builtin_amdgcn_s_setprio(0);
+    } else {
+        // =========================== math waves =============================================
+        const int kg = wave / NMT, wm = (wave % NMT) / MW_N, wn = wave % MW_N;
+        // epilogue parameters -> LDS while the loaders fill the first stage
+        {
+            const int t = tid;                       // 0 .. NM*64-1
+            if (t < BN && EPI != EPI_I32) {
+                const long n = n0 + t;
+                const bool ok = n < p.N;
+                par_sw[t] = ok ? p.s_w[n] : 0.0f;
+                par_bs[t] = (ok && p.bias) ? p.bias[n] : 0.0f;
+                par_wz[t] = (ok && p.w0) ? p.w0[n] : 0.0f;
+            }
+            if (t < BM && EPI != EPI_I32) {
+                const long m = m0 + t;
+                float sx = p.sx0, xz = 0.0f;
+                if (m < p.M) {
+                    if (p.sx_vec) sx = p.sx_vec[m];
+                    else if (p.row_sel && p.row_sel[m]) sx = p.sx1;
+                    if (p.x0) xz = p.x0[m];
+                }
+                par_sx[t] = sx;
+                par_xz[t] = xz;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < NACC; ++a)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[a][i][j][e] = 0;
+
+        // V_MFMA_I32_32X32X32_I8: one wave per SIMD already runs it at ~85 % of the int8 peak, whereas
+        // the 16x16x64 form needs two waves per SIMD and tops out at ~70 % (tools/probes/math_loop.hip).
+        // Operand fragments out of the 16-row pieces: lane l holds row / channel (l & 31) = piece
+        // (l >> 4) & 1, row l & 15 of it, and the 16 k-bytes of chunk 2 sub + (l >> 5) of the k-tile;
+        // both operands use the same lane -> k map, so the (order-free) integer sum is exact.
+        const int lane_x = ((lane >> 4) & 1) * 2048 + ((lane >> 5) * 16 + (lane & 15)) * 16;
+        const int lane_w = (W_BITS == 4) ? ((lane >> 5) * 16 + (lane & 15)) * 16 + ((lane >> 4) & 1) * 8 : lane_x;
+        // Register sets, indexed by the K = 32 sub-step modulo 4: activation fragments X and packed weights
+        // WP are read TWO sub-steps ahead of their MFMAs (LDS latency under DMA traffic exceeds one
+        // sub-step of 3-4 MFMAs), the nibbles are unpacked one sub-step ahead into WU (parity).
+        v4i X[4][TM], WU[2][TN];
+        v4i WP[4][TN];      // W4: only the first two words are used
+        auto load_x = [&](int set, int slot, int sub) {          // sub = 0..3: K = 32 sub-steps of the stage
+            const char *xs = smem + slot * STAGE + (sub >> 1) * 1024 + (sub & 1) * 512;
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+                X[set][j] = *reinterpret_cast<const v4i *>(xs + (wm * TM + j) * 4096 + lane_x);
+        };
+        auto load_w = [&](int set, int slot, int sub) {
+            const char *ws = smem + slot * STAGE + A_BYTES + (sub >> 1) * 1024 + (sub & 1) * 512;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                if (W_BITS == 4) {
+                    const v2i pk = *reinterpret_cast<const v2i *>(ws + (wn * TN + i) * 2048 + lane_w);
+                    WP[set][i][0] = pk[0];
+                    WP[set][i][1] = pk[1];
+                } else {
+                    WP[set][i] = *reinterpret_cast<const v4i *>(ws + (wn * TN + i) * 4096 + lane_w);
+                }
+            }
+        };
+        auto unpack = [&](int from, int to) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                if (W_BITS == 4) {
+                    const int lo = WP[from][i][0], hi = WP[from][i][1];
+                    WU[to][i][0] = (lo << 4) & 0xF0F0F0F0;
+                    WU[to][i][1] = lo & 0xF0F0F0F0;
+                    WU[to][i][2] = (hi << 4) & 0xF0F0F0F0;
+                    WU[to][i][3] = hi & 0xF0F0F0F0;
+                } else {
+                    WU[to][i] = WP[from][i];
+                }
+            }
+        };
+        auto mfmas = [&](int sub) {
+            const int a = NACC == 2 ? (sub & 1) : 0;
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    acc[a][i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(WU[sub & 1][i], X[sub][j], acc[a][i][j], 0, 0, 0);
+        };
+        // One K = 32 sub-step: the MFMAs of sub-step s interleaved with the fragment reads of sub-step
+        // s+2 and the nibble unpack of sub-step s+1, so that every gap between two MFMAs (32 cycles of
+        // matrix-core time) carries its share of the LDS and VALU issue; grouped as
+        // [reads][unpack][MFMAs] the in-order wave leaves a bubble per sub-step.
+        constexpr int N_MFMA = TM * TN, N_DS = TM + TN, N_VALU = (W_BITS == 4) ? 6 * TN : 0;
+        constexpr int DS_PER_GAP = (N_DS + N_MFMA - 1) / N_MFMA, VALU_PER_GAP = (N_VALU + N_MFMA - 1) / N_MFMA;
+        auto substep = [&](int sub, int slot2, int sub2) {       // (slot2, sub2): where sub-step s+2 lives
+            __builtin_amdgcn_sched_barrier(0);
+            if (MQ_EXP != 8) {                   // MQ_EXP 8 / 9: timing experiments without the reads / the MFMAs
+                load_x((sub + 2) & 3, slot2, sub2);
+                load_w((sub + 2) & 3, slot2, sub2);
+            }
+            unpack((sub + 1) & 3, (sub + 1) & 1);
+            if (MQ_EXP != 9) mfmas(sub);
+            else {
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[0][0][j][0] += X[sub][j][0] ^ WU[sub & 1][0][j & 3];
+            }
+#pragma unroll
+            for (int m = 0; m < N_MFMA; ++m) {   // a single wave issues back-to-back LDS reads slowly: spread them
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, DS_PER_GAP, 0);        // DS reads
+                if (N_VALU) __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_GAP, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        MQ_STAMP_AT(1);
+        __builtin_amdgcn_s_barrier();                // B(0): stage 0 landed
+        MQ_STAMP_AT(2);
+        if constexpr (KS == 2) {
+            // Own sub-steps: group g takes sub-steps g and g + 2 of every stage.  Each own sub-step is an
+            // M phase (its MFMAs, ~32 cycles of matrix-core time each) and a P phase (unpack the next
+            // weights, issue the next fragment reads).  The two waves of a SIMD run these phases in
+            // opposite order -- group 0: M P M P, group 1: P M P M -- so one wave's VALU / LDS issue
+            // falls into the other's MFMA time; started in the same phase (both leave the barrier
+            // together) they would only queue for the matrix core and then for the VALU.
+            auto m_phase = [&](int set) {
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j)
+                        acc[0][i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(WU[set][i], X[set][j], acc[0][i][j], 0, 0, 0);
+            };
+            int cur = 0;
+            if (kg == 0) {
+                load_x(0, 0, 0); load_w(0, 0, 0);
+                load_x(1, 0, 2); load_w(1, 0, 2);
+                unpack(0, 0);
+                auto body = [&](int set, int slot_n, int sub_n) {   // M(q) | unpack(q+1) | reads of q+2
+                    __builtin_amdgcn_sched_barrier(0);
+                    m_phase(set);
+                    __builtin_amdgcn_sched_barrier(0);
+                    unpack(set ^ 1, set ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_x(set, slot_n, sub_n);
+                    load_w(set, slot_n, sub_n);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                for (int it = 0; it < nk; ++it) {
+                    __builtin_amdgcn_s_barrier();        // B(it+1): stage it+1 landed
+                    int nxt = cur + 1;
+                    if (nxt == S) nxt = 0;
+                    if (it + 1 >= nk) nxt = cur;         // last step: harmless re-reads of a live slot
+                    if (MQ_EXP == 7) { cur = nxt; continue; }
+                    body(0, nxt, 0);
+                    body(1, nxt, 2);
+                    cur = nxt;
+                }
+            } else {
+                load_x(0, 0, 1); load_w(0, 0, 1);
+                auto body = [&](int set, int slot_n, int sub_n) {   // unpack(q) | reads of q+1 | M(q)
+                    __builtin_amdgcn_sched_barrier(0);
+                    unpack(set, set);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_x(set ^ 1, slot_n, sub_n);
+                    load_w(set ^ 1, slot_n, sub_n);
+                    __builtin_amdgcn_sched_barrier(0);
+                    m_phase(set);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                for (int it = 0; it < nk; ++it) {
+                    __builtin_amdgcn_s_barrier();        // B(it+1): stage it+1 landed
+                    int nxt = cur + 1;
+                    if (nxt == S) nxt = 0;
+                    if (it + 1 >= nk) nxt = cur;
+                    if (MQ_EXP == 7) { cur = nxt; continue; }
+                    body(0, cur, 3);
+                    body(1, nxt, 1);
+                    cur = nxt;
+                }
+            }
+        } else {
+        load_x(0, 0, 0);
+        load_w(0, 0, 0);
+        load_x(1, 0, 1);
+        load_w(1, 0, 1);
+        unpack(0, 0);
+        int cur = 0;
+        for (int it = 0; it < nk; ++it) {
+            __builtin_amdgcn_s_barrier();            // B(it+1): stage it+1 landed
+            int nxt = cur + 1;
+            if (nxt == S) nxt = 0;
+            if (it + 1 >= nk) nxt = cur;             // last step: harmless re-reads of a live slot
+            if (MQ_EXP == 7) { cur = nxt; continue; }   // timing experiment: loaders alone
+            substep(0, cur, 2);
+            substep(1, cur, 3);
+            substep(2, nxt, 0);
+            substep(3, nxt, 1);
+            cur = nxt;
+        }
+        }
+        if (NACC == 2) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[0][i][j] += acc[1][i][j];
+        }
+    }
+
+    // =========================== epilogue: all waves ==========================================
+    MQ_STAMP_AT(4);
+    __syncthreads();                                 // the ring is free: park the raw accumulators
+    MQ_STAMP_AT(5);
+    if (wave < NM) {
+        // D layout of the 32x32 form: column (-> row m) = lane & 31, rows (-> channels) 8 q + 4 (lane >> 5) + e
+        const int kg = wave / NMT, wm = (wave % NMT) / MW_N, wn = wave % MW_N;
+        const int ml = lane & 31, nh = (lane >> 5) * 4;
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<v4i *>(smem + kg * (BM * PITCH) + ((wm * TM + j) * 32 + ml) * PITCH + ((wn * TN + i) * 32 + q * 8 + nh) * 4) =
+                        v4i{acc[0][i][j][4 * q], acc[0][i][j][4 * q + 1], acc[0][i][j][4 * q + 2], acc[0][i][j][4 * q + 3]};
+    }
+    __syncthreads();
+    MQ_STAMP_AT(6);
+
+    constexpr int LPR = BN / 8;                      // lanes per output row (8 channels per lane)
+    constexpr int RPI = NT / LPR;                    // rows per iteration of the whole workgroup
+    const int c8 = (tid % LPR) * 8;
+    const long n = n0 + c8;
+    const bool n_full = (n + 8 <= p.N) && p.vec_ok;
+    const bool to_partial = p.splits > 1;
+    float swv[8], bsv[8], wzv[8];
+    if (EPI != EPI_I32 && !to_partial) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            swv[e] = par_sw[c8 + e];
+            bsv[e] = par_bs[c8 + e];
+            wzv[e] = par_wz[c8 + e];
+        }
+    }
+#pragma unroll 1
+    for (int r0 = 0; r0 < BM; r0 += RPI) {
+        const int row = r0 + tid / LPR;
+        const long m = m0 + row;
+        if (row >= BM || m >= p.M || n >= p.N) continue;
+        v4i q0 = *reinterpret_cast<const v4i *>(smem + row * PITCH + c8 * 4);
+        v4i q1 = *reinterpret_cast<const v4i *>(smem + row * PITCH + c8 * 4 + 16);
+        if (KS == 2) {      // the two k groups' partial sums
+            q0 += *reinterpret_cast<const v4i *>(smem + BM * PITCH + row * PITCH + c8 * 4);
+            q1 += *reinterpret_cast<const v4i *>(smem + BM * PITCH + row * PITCH + c8 * 4 + 16);
+        }
+        int a[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+        if (W_BITS == 4) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] >>= 4;
+        }
+        if (to_partial || EPI == EPI_I32) {
+            int *o = to_partial ? p.partial + ((long)split * p.M + m) * p.N + n
+                                : reinterpret_cast<int *>(p.out) + m * p.ldo + n;
+            if (n_full) {
+                *reinterpret_cast<v4i *>(o) = v4i{a[0], a[1], a[2], a[3]};
+                *reinterpret_cast<v4i *>(o + 4) = v4i{a[4], a[5], a[6], a[7]};
+            } else {
+                for (int e = 0; e < 8; ++e)
+                    if (n + e < p.N) o[e] = a[e];
+            }
+            continue;
+        }
+        const float sx = par_sx[row], xz = par_xz[row];
+        float res[8];
+        if (p.residual) {
+            if (EPI == EPI_F32) {
+                const float *rp = reinterpret_cast<const float *>(p.residual) + m * p.ldr + n;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) res[e] = (n + e < p.N) ? rp[e] : 0.0f;
+            } else {
+                const unsigned short *rp = reinterpret_cast<const unsigned short *>(p.residual) + m * p.ldr + n;
+                if (n_full && p.res_vec) {
+                    const v8us rv = *reinterpret_cast<const v8us *>(rp);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        res[e] = (EPI == EPI_F16) ? f16_bits_to_f32(rv[e]) : bf16_bits_to_f32(rv[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const unsigned short rb = (n + e < p.N) ? rp[e] : (unsigned short)0;
+                        res[e] = (EPI == EPI_F16) ? f16_bits_to_f32(rb) : bf16_bits_to_f32(rb);
+                    }
+                }
+            }
+        }
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = (float)a[e] * sx;
+            t = t * swv[e];
+            if (p.bias) t = t + bsv[e];
+            if (p.x0) {
+                const float pr = xz * wzv[e];
+                t = t + pr;
+            }
+            if (p.residual) {   // torch: hidden + linear(x), the Linear's output rounded first
+                if (EPI == EPI_F16) t = f16_bits_to_f32(f32_to_f16_bits(t));
+                if (EPI == EPI_BF16) t = bf16_bits_to_f32(f32_to_bf16_bits(t));
+                t = t + res[e];
+            }
+            y[e] = t;
+        }
+        if (EPI == EPI_F32) {
+            float *o = reinterpret_cast<float *>(p.out) + m * p.ldo + n;
+            if (n_full) {
+                *reinterpret_cast<v4f *>(o) = v4f{y[0], y[1], y[2], y[3]};
+                *reinterpret_cast<v4f *>(o + 4) = v4f{y[4], y[5], y[6], y[7]};
+            } else {
+                for (int e = 0; e < 8; ++e)
+                    if (n + e < p.N) o[e] = y[e];
+            }
+        } else {
+            v8us h;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                h[e] = (EPI == EPI_F16) ? f32_to_f16_bits(y[e]) : f32_to_bf16_bits(y[e]);
+            unsigned short *o = reinterpret_cast<unsigned short *>(p.out) + m * p.ldo + n;
+            if (n_full) {
+                *reinterpret_cast<v8us *>(o) = h;
+            } else {
+                for (int e = 0; e < 8; ++e)
+                    if (n + e < p.N) o[e] = h[e];
+            }
+        }
+    }
+    MQ_STAMP_AT(7);
+}
+
+template <int BM, int BN, int MW_M, int MW_N, int KS, int NL, int S, int W_BITS, int EPI>
+static int launch_ws(const GemmArgs &p, hipStream_t st)
+{
+    constexpr int PIECES = (BM / 16) * 2 + ((W_BITS == 4) ? (BN / 32) * 2 : (BN / 16) * 2);
+    constexpr int SMEM = S * PIECES * 1024 + (3 * BN + 2 * BM) * 4;
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    auto kern = gemm_ws_kernel<BM, BN, MW_M, MW_N, KS, NL, S, W_BITS, EPI>;
+    int rc = ensure_dynamic_lds((const void *)kern, SMEM);
+    if (rc != MQ_OK) return rc;
+    GemmArgs g = p;
+    set_geometry(g, BM, BN, 128);
+    hipLaunchKernelGGL(kern, dim3(g.m_blocks * g.n_blocks * (unsigned)g.splits), dim3((MW_M * MW_N * KS + NL) * 64), SMEM, st, g);
+    return check_launch("gemm_ws");
+}
+
+template <int W_BITS, int EPI>
+int dispatch_ws(const GemmArgs &p, int tile, hipStream_t st)
+{
+    switch (tile) {
+    case 40: return launch_ws<96, 128, 1, 4, 2, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI>(p, st);
+    case 41: return launch_ws<128, 128, 2, 4, 1, 4, (W_BITS == 4 ? 6 : 4), W_BITS, EPI>(p, st);
+    case 42:
+        if constexpr (W_BITS == 4) return launch_ws<192, 128, 2, 4, 1, 4, 4, W_BITS, EPI>(p, st);
+        else break;
+    case 43: return launch_ws<64, 128, 1, 4, 2, 4, (W_BITS == 4 ? 8 : 6), W_BITS, EPI>(p, st);
+    case 44:
+        if constexpr (W_BITS == 4) return launch_ws<128, 128, 1, 4, 2, 4, 6, W_BITS, EPI>(p, st);
+        else return launch_ws<128, 128, 2, 4, 1, 4, 4, W_BITS, EPI>(p, st);
+    // one wave per SIMD (comparison points of DESIGN 4.1)
+    case 50: return launch_ws<96, 128, 1, 4, 1, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI>(p, st);
+    case 51: return launch_ws<128, 128, 1, 4, 1, 4, (W_BITS == 4 ? 6 : 4), W_BITS, EPI>(p, st);
+    default: break;
+    }
+    return fail(MQ_EINVAL, "gemm_ws: unknown tile %d", tile);
+}
+
+// explicit instantiations used by gemm_w4a8.hip
+#define MQ_WS_INST(B, E) template int dispatch_ws<B, E>(const GemmArgs &, int, hipStream_t);
+MQ_WS_INST(4, EPI_F16) MQ_WS_INST(4, EPI_BF16) MQ_WS_INST(4, EPI_F32) MQ_WS_INST(4, EPI_I32)
+MQ_WS_INST(8, EPI_F16) MQ_WS_INST(8, EPI_BF16) MQ_WS_INST(8, EPI_F32) MQ_WS_INST(8, EPI_I32)
+
+}  // namespace mq

@@ -84,7 +84,7 @@ __device__ __forceinline__ void had_emit1(const HadArgs &p, long row, long col, 
     float r;
     const int q = had_finish<DT, QUANT>(p, row, col, v, s, &r);
     if (QUANT) {
-        p.qout[row * p.ldq + col] = (int8_t)q;
+        p.qout[act_offset(row, col, p.K_pad, p.ldq)] = (int8_t)q;
     } else {
         typedef typename Elem<DT>::T T;
         reinterpret_cast<T *>(p.out)[row * p.ldo + col] = Elem<DT>::st(r);
@@ -101,7 +101,7 @@ __device__ __forceinline__ void had_emit4(const HadArgs &p, long row, long col, 
 #pragma unroll
     for (int e = 0; e < 4; ++e) q[e] = had_finish<DT, QUANT>(p, row, col + e, v[e], s, &r[e]);
     if (QUANT) {
-        int8_t *o = p.qout + row * p.ldq + col;
+        int8_t *o = p.qout + act_offset(row, col, p.K_pad, p.ldq);
         if (aligned) {
             *reinterpret_cast<unsigned *>(o) = (q[0] & 0xff) | ((q[1] & 0xff) << 8) |
                                                ((q[2] & 0xff) << 16) | ((unsigned)(q[3] & 0xff) << 24);
@@ -154,7 +154,12 @@ __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
         for (int t = tid; t < K * WPR; t += THREADS) hw[t] = gw[t];
     }
 
-    for (long row = blockIdx.x; row < p.M; row += gridDim.x) {
+    // tiled int8 output: the 16 rows of a piece row are handled on one XCD (tiled_row_of, mq_common.h)
+    const bool remap = QUANT && p.ldq == MQ_LD_TILED && (gridDim.x & 7) == 0;
+    const long v_end = remap ? ceil_div(p.M, 128) * 128 : p.M;
+    for (long v = blockIdx.x; v < v_end; v += gridDim.x) {
+        const long row = remap ? tiled_row_of(v) : v;
+        if (row >= p.M) continue;                  // uniform over the workgroup
         const T *xr = reinterpret_cast<const T *>(p.x) + row * p.ldx;
         const float s = (p.row_sel && p.row_sel[row]) ? p.s1 : p.s0;
 
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
             }
         }
         if (QUANT) {
-            for (long c = n + tid; c < p.K_pad; c += HAD_THREADS) p.qout[row * p.ldq + c] = 0;
+            for (long c = n + tid; c < p.K_pad; c += HAD_THREADS) p.qout[act_offset(row, c, p.K_pad, p.ldq)] = 0;
         }
         __syncthreads();  // the staged row is reused by the next row
     }
@@ -392,17 +397,16 @@ static int launch_hadamard_t(HadArgs p, hipStream_t st)
     const size_t lds = (size_t)p.y_bytes + (p.K > 1 ? (size_t)p.K * wpr * 4 : 0);
     if (lds > 160 * 1024) return fail(MQ_EUNSUPPORTED, "mq_hadamard: n=%ld needs %zu B of LDS (> 160 KiB)", p.n, lds);
     auto kern = hadamard_kernel<DT, QUANT, HALF_LDS, THREADS, ACT>;
-    static size_t lds_granted = 0;   // per instantiation; raised outside any stream capture (first call)
-    if (lds > lds_granted) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return fail((int)e, "hadamard: set smem attr: %s", hipGetErrorString(e));
-        lds_granted = 160 * 1024;
+    {   // per device and instantiation; the first call of a shape happens outside any stream capture
+        const int rc = ensure_dynamic_lds((const void *)kern, 160 * 1024);
+        if (rc != MQ_OK) return rc;
     }
     long per_cu = (160 * 1024) / (long)lds;
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
     long blocks = 256L * per_cu;
     if (blocks > p.M) blocks = p.M;
+    if (QUANT && p.ldq == MQ_LD_TILED) blocks = ceil_div(blocks, 8) * 8;   // XCD-consistent row map (tiled_row_of)
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), lds, st, p);
     return check_launch("hadamard");
 }
@@ -449,7 +453,8 @@ static int hadamard_common(HadArgs p, int x_dtype, bool quant, void *stream)
     p.vec_ok2 = p.x2 && (((uintptr_t)p.x2) % 16 == 0) && ((p.ldx * esz) % 16 == 0);
     hipStream_t st = (hipStream_t)stream;
     if (quant) {
-        MQ_REQUIRE(p.qout && p.K_pad >= p.n && p.ldq >= p.K_pad, "mq_hadamard_quant_i8: bad output geometry");
+        MQ_REQUIRE(p.qout && p.K_pad >= p.n && (p.ldq == MQ_LD_TILED ? p.K_pad % 64 == 0 : p.ldq >= p.K_pad),
+                   "mq_hadamard_quant_i8: bad output geometry");
         MQ_REQUIRE(((uintptr_t)p.qout) % 4 == 0, "mq_hadamard_quant_i8: out must be 4-byte aligned");
         switch (x_dtype) {
         case MQ_F16: return launch_hadamard_dt<MQ_F16, true>(p, st);

@@ -15,6 +15,7 @@ namespace mq {
 char *last_error_buf();
 int fail(int code, const char *fmt, ...);
 int check_launch(const char *what);
+int ensure_dynamic_lds(const void *kernel, int bytes);   // per device, thread-safe (runtime.hip)
 
 #define MQ_REQUIRE(cond, ...)                                   \
     do {                                                        \
@@ -23,6 +24,7 @@ int check_launch(const char *what);
 
 // ---- vector types -----------------------------------------------------------
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned short v8us __attribute__((ext_vector_type(8)));
@@ -160,5 +162,25 @@ template <int DT> __device__ __forceinline__ float act_quick_gelu(float x)
 }
 
 __host__ __device__ inline long ceil_div(long a, long b) { return (a + b - 1) / b; }
+
+// Byte offset of element (row, col) of the int8 activation matrix handed from the quantizers to
+// the GEMM: row-major with leading dimension ld, or the TILED layout (ld == MQ_LD_TILED,
+// include/mquant_hip.h): [row/16][col/64] pieces of 1 KiB, 16-byte chunk ((col/16)%4, row%16) inside.
+// A 4-, 8- or 16-byte group that starts at a multiple of its size stays inside one chunk.
+__host__ __device__ inline long act_offset(long row, long col, long K_pad, long ld)
+{
+    if (ld != MQ_LD_TILED) return row * ld + col;
+    return ((row >> 4) * (K_pad >> 6) + (col >> 6)) * 1024 + ((((col >> 4) & 3) << 4) + (row & 15)) * 16 + (col & 15);
+}
+
+// Rows -> workgroups for kernels that own whole rows and write the tiled layout: the 16 rows of a
+// piece row go to workgroups on ONE XCD (block b runs on XCD b % 8, gridDim % 8 == 0), so the eight
+// 16-byte chunks that share a 128-byte line meet in one L2 instead of being written back by eight.
+// v = virtual row index (block + iteration * grid); returns the row (may be >= M: skip it).
+__device__ __forceinline__ long tiled_row_of(long v)
+{
+    const long xcd = v & 7, i = v >> 3;
+    return (((i >> 4) << 3) + xcd) * 16 + (i & 15);
+}
 
 }  // namespace mq

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(RQ_THREADS) void rmsn_quant_kernel(RqArgs p)
             for (int j = 0; j < 4; ++j)
                 pk[j] = (q[4 * j] & 0xff) | ((q[4 * j + 1] & 0xff) << 8) | ((q[4 * j + 2] & 0xff) << 16) |
                         ((q[4 * j + 3] & 0xff) << 24);
-            *reinterpret_cast<v4i *>(p.out + row * p.ldo + ch * 16) = pk;
+            *reinterpret_cast<v4i *>(p.out + act_offset(row, ch * 16, p.K_pad, p.ldo)) = pk;
             if (p.y) {
                 T *yd = reinterpret_cast<T *>(p.y) + row * p.ldy + ch * 16;
 #pragma unroll
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(RQ_THREADS) void rmsn_quant_kernel(RqArgs p)
     }
     // zero the K .. K_pad tail of the int8 row (the GEMM reads whole 128-byte k-steps)
     for (long k = p.K + t * 16L; k < p.K_pad; k += RQ_THREADS * 16L)
-        *reinterpret_cast<v4i *>(p.out + row * p.ldo + k) = v4i{0, 0, 0, 0};
+        *reinterpret_cast<v4i *>(p.out + act_offset(row, k, p.K_pad, p.ldo)) = v4i{0, 0, 0, 0};
 }
 
 }  // namespace mq
@@ -128,7 +128,8 @@ extern "C" int mq_rmsn_quantize_i8(const void *x, int x_dtype, long M, long K, l
     MQ_REQUIRE(x && out && M >= 0 && K > 0 && ldx >= K, "mq_rmsn_quantize_i8: bad shape");
     MQ_REQUIRE(K % 16 == 0 && K <= 16L * RQ_THREADS * RQ_MAX_CHUNKS,
                "mq_rmsn_quantize_i8: K must be a multiple of 16 and <= %d (got %ld)", 16 * RQ_THREADS * RQ_MAX_CHUNKS, K);
-    MQ_REQUIRE(K_pad >= K && K_pad % 16 == 0 && ldo >= K_pad && ldo % 16 == 0, "mq_rmsn_quantize_i8: bad K_pad / ldo");
+    MQ_REQUIRE(K_pad >= K && K_pad % 16 == 0 && (ldo == MQ_LD_TILED ? K_pad % 64 == 0 : (ldo >= K_pad && ldo % 16 == 0)),
+               "mq_rmsn_quantize_i8: bad K_pad / ldo");
     MQ_REQUIRE(!y_out || ldy >= K, "mq_rmsn_quantize_i8: ldy < K");
     MQ_REQUIRE(scale0 > 0.0f && mean_dim > 0.0f, "mq_rmsn_quantize_i8: scale and mean_dim must be positive");
     MQ_REQUIRE(((uintptr_t)x) % 16 == 0 && (ldx * (x_dtype == MQ_F32 ? 4 : 2)) % 16 == 0,

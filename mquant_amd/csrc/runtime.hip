@@ -1,6 +1,9 @@
 // runtime.hip -- error plumbing, version / device queries of the C ABI.
 #include <stdarg.h>
 
+#include <mutex>
+#include <vector>
+
 #include "mq_common.h"
 
 namespace mq {
@@ -24,6 +27,32 @@ int check_launch(const char *what)
 {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, "%s: launch failed: %s", what, hipGetErrorString(e));
+    return MQ_OK;
+}
+
+// Kernels that need more than 64 KiB of dynamic LDS must be told so once PER DEVICE (the attribute
+// lives in the per-device function object): with the reference's device_map="auto" placement one
+// process drives several GPUs ("every buffer follows x.device").
+int ensure_dynamic_lds(const void *kernel, int bytes)
+{
+    struct Entry { int dev; const void *fn; int granted; };
+    static std::mutex mu;
+    static std::vector<Entry> table;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail((int)e, "hipGetDevice: %s", hipGetErrorString(e));
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto &t : table)
+        if (t.dev == dev && t.fn == kernel) {
+            if (t.granted >= bytes) return MQ_OK;
+            e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) return fail((int)e, "set dynamic LDS size %d: %s", bytes, hipGetErrorString(e));
+            t.granted = bytes;
+            return MQ_OK;
+        }
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return fail((int)e, "set dynamic LDS size %d: %s", bytes, hipGetErrorString(e));
+    table.push_back({dev, kernel, bytes});
     return MQ_OK;
 }
 

@@ -10,6 +10,7 @@ Reference semantics: ``ActQuantWrapper.forward``, fake_quant/quant_utils.py:330-
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
@@ -26,18 +27,27 @@ class HadamardSpec:
     fp32_had: bool = False
 
 
+#: layout of the int8 activations between the quantizer and the GEMM: "tiled" (MQ_LD_TILED: one
+#: contiguous KiB per MFMA fragment, what the wave-specialised GEMM kernels stream) or "rows"
+#: (row-major, the round-1 layout; kept for A/B measurements).
+ACT_LAYOUT = os.environ.get("MQ_ACT_LAYOUT", "tiled")
+
+
 class Workspace:
     """Per-device cache of int8 activation buffers keyed by (rows, K_pad)."""
 
     def __init__(self):
-        self._a: Dict[Tuple[int, int, int], torch.Tensor] = {}
+        self._a: Dict[Tuple[int, int, int, str], object] = {}
         self._x0: Dict[Tuple[int, int], torch.Tensor] = {}
 
-    def act(self, device, M: int, K_pad: int) -> torch.Tensor:
-        key = (device.index or 0, M, K_pad)
+    def act(self, device, M: int, K_pad: int):
+        key = (device.index or 0, M, K_pad, ACT_LAYOUT)
         buf = self._a.get(key)
         if buf is None:
-            buf = torch.empty((M, K_pad), dtype=torch.int8, device=device)
+            if ACT_LAYOUT == "tiled":
+                buf = ops.TiledAct.empty(M, K_pad, device)
+            else:
+                buf = torch.empty((M, K_pad), dtype=torch.int8, device=device)
             self._a[key] = buf
         return buf
 

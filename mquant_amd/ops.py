@@ -22,19 +22,111 @@ def dtype_code(dt: torch.dtype) -> int:
         raise TypeError(f"unsupported activation dtype {dt}") from None
 
 
+LD_TILED = 0   # include/mquant_hip.h MQ_LD_TILED
+
+
+class TiledAct:
+    """int8 activations in the TILED layout (``MQ_LD_TILED``): ``data`` is [ceil(M/16), K_pad/64, 64, 16],
+    one 1 KiB piece = the MFMA operand fragment of a 16-row x 64-k tile in lane order.  The GEMM
+    fetches a piece with one contiguous LDS-DMA (3x the L2 rate of gathering rows)."""
+    __slots__ = ("data", "M", "K_pad")
+
+    def __init__(self, data: torch.Tensor, M: int, K_pad: int):
+        assert data.dtype == torch.int8 and data.is_contiguous() and K_pad % 64 == 0
+        assert data.numel() >= ceil_to(M, 16) * K_pad
+        self.data, self.M, self.K_pad = data, M, K_pad
+
+    @staticmethod
+    def empty(M: int, K_pad: int, device) -> "TiledAct":
+        return TiledAct(torch.empty((ceil_to(max(M, 1), 16) // 16, K_pad // 64, 64, 16), dtype=torch.int8,
+                                    device=device), M, K_pad)
+
+    @property
+    def device(self):
+        return self.data.device
+
+    @property
+    def is_cuda(self):
+        return self.data.is_cuda
+
+    def data_ptr(self) -> int:
+        return self.data.data_ptr()
+
+    def to_rows(self) -> torch.Tensor:
+        """Row-major [M, K_pad] copy (tests, debugging)."""
+        mt, kt = ceil_to(max(self.M, 1), 16) // 16, self.K_pad // 64
+        t = self.data.reshape(-1)[: mt * kt * 1024].reshape(mt, kt, 4, 16, 16)   # [mt][kt][c][r][16]
+        return t.permute(0, 3, 1, 2, 4).reshape(mt * 16, self.K_pad)[: self.M].contiguous()
+
+    @staticmethod
+    def from_rows(a: torch.Tensor) -> "TiledAct":
+        """Tile a row-major int8 [M, K_pad] matrix with torch ops (tests; the quantizer kernels write
+        the layout directly)."""
+        M, K_pad = a.shape
+        mt, kt = ceil_to(max(M, 1), 16) // 16, K_pad // 64
+        full = torch.zeros((mt * 16, K_pad), dtype=torch.int8, device=a.device)
+        full[:M] = a
+        t = full.reshape(mt, 16, kt, 4, 16).permute(0, 2, 3, 1, 4).contiguous()    # [mt][kt][c][r][16]
+        return TiledAct(t.reshape(mt, kt, 64, 16), M, K_pad)
+
+
+def _a_args(a):
+    """(pointer, leading dimension, M, K_pad) of an int8 activation operand in either layout."""
+    if isinstance(a, TiledAct):
+        return a.data_ptr(), LD_TILED, a.M, a.K_pad
+    assert a.dtype == torch.int8 and a.dim() == 2 and a.stride(1) == 1
+    return a.data_ptr(), a.stride(0), a.shape[0], a.shape[1]
+
+
+def _out_act(out, tiled: bool, M: int, K_pad_default: int, device):
+    """Destination of a quantizer: (object to return, pointer, K_pad, leading dimension)."""
+    if out is None:
+        out = TiledAct.empty(M, K_pad_default, device) if tiled else \
+            torch.empty((M, K_pad_default), dtype=torch.int8, device=device)
+    if isinstance(out, TiledAct):
+        assert out.M == M
+        return out, out.data_ptr(), out.K_pad, LD_TILED
+    return out, out.data_ptr(), out.shape[1], out.stride(0)
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+def _ptr(t) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
 def _need_cuda(*ts):
+    dev = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise _lib.MQuantHipError(
                 "the W4A8 path runs on the GPU only (got a CPU tensor); there is no CPU fallback")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise _lib.MQuantHipError(f"operands live on different devices ({dev} and {t.device})")
+
+
+def _on_device(fn):
+    """Run the wrapped op with the FIRST tensor argument's device current: the library launches on
+    the current device and its current stream, and with the reference's device_map="auto" placement
+    a wrapper's tensors may live on a GPU that is not the current one."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        for a in args:
+            if isinstance(a, (torch.Tensor, TiledAct)) and a.is_cuda:
+                if a.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(a.device):
+                        return fn(*args, **kwargs)
+                break
+        return fn(*args, **kwargs)
+    return wrapped
 
 
 def ceil_to(v: int, m: int) -> int:
@@ -50,46 +142,45 @@ def _rows(x: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- quantizer
+@_on_device
 def quantize_act_i8(x: torch.Tensor, scale0: float = 1.0, scale1: Optional[float] = None, *,
                     scale_vec0: Optional[torch.Tensor] = None,
                     scale_vec1: Optional[torch.Tensor] = None,
                     row_sel: Optional[torch.Tensor] = None, skip_col0: bool = False,
-                    out: Optional[torch.Tensor] = None,
-                    x0_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """fp -> int8 levels, [M, K] -> [M, ceil128(K)] (pad columns are zero)."""
+                    out=None, x0_out: Optional[torch.Tensor] = None, tiled: bool = False):
+    """fp -> int8 levels, [M, K] -> [M, ceil128(K)] (pad columns are zero); ``tiled`` (or a
+    ``TiledAct`` destination) selects the layout the GEMM streams fastest."""
     x2 = _rows(x)
     _need_cuda(x2, scale_vec0, scale_vec1, row_sel, out)
     M, K = x2.shape
-    K_pad = ceil_to(K, 128) if out is None else out.shape[1]
-    if out is None:
-        out = torch.empty((M, K_pad), dtype=torch.int8, device=x.device)
+    out, optr, K_pad, ldo = _out_act(out, tiled, M, ceil_to(K, 128), x.device)
     if skip_col0 and x0_out is None:
         x0_out = torch.empty((M,), dtype=torch.float32, device=x.device)
     call("mq_quantize_act_i8", x2.data_ptr(), dtype_code(x2.dtype), M, K, x2.stride(0),
          float(scale0), float(scale0 if scale1 is None else scale1),
          _ptr(scale_vec0), _ptr(scale_vec1), _ptr(row_sel), int(skip_col0), _ptr(x0_out),
-         out.data_ptr(), K_pad, out.stride(0), _stream())
+         optr, K_pad, ldo, _stream())
     return out, x0_out
 
 
+@_on_device
 def rmsn_quantize_i8(x: torch.Tensor, mean_dim: float, eps: float, scale0: float,
                      scale1: Optional[float] = None, *, row_sel: Optional[torch.Tensor] = None,
-                     out: Optional[torch.Tensor] = None, want_y: bool = False):
+                     out=None, want_y: bool = False, tiled: bool = False):
     """Weight-less RMS norm (module_util.RMSN) + static int8 quantizer in one pass.
-    Returns (int8 [M, ceil128(K)], normalised activations in x's dtype | None)."""
+    Returns (int8 [M, ceil128(K)] or TiledAct, normalised activations in x's dtype | None)."""
     x2 = _rows(x)
     _need_cuda(x2, row_sel, out)
     M, K = x2.shape
-    K_pad = ceil_to(K, 128) if out is None else out.shape[1]
-    if out is None:
-        out = torch.empty((M, K_pad), dtype=torch.int8, device=x.device)
+    out, optr, K_pad, ldo = _out_act(out, tiled, M, ceil_to(K, 128), x.device)
     y = torch.empty((M, K), dtype=x.dtype, device=x.device) if want_y else None
     call("mq_rmsn_quantize_i8", x2.data_ptr(), dtype_code(x2.dtype), M, K, x2.stride(0), float(mean_dim),
          float(eps), float(scale0), float(scale0 if scale1 is None else scale1), _ptr(row_sel),
-         _ptr(y), K, out.data_ptr(), K_pad, out.stride(0), _stream())
+         _ptr(y), K, optr, K_pad, ldo, _stream())
     return out, (y.reshape(x.shape) if want_y else None)
 
 
+@_on_device
 def fakequant_act(x: torch.Tensor, scale0: float = 1.0, scale1: Optional[float] = None, *,
                   scale_vec0: Optional[torch.Tensor] = None,
                   scale_vec1: Optional[torch.Tensor] = None,
@@ -107,6 +198,7 @@ def fakequant_act(x: torch.Tensor, scale0: float = 1.0, scale1: Optional[float] 
 
 
 # --------------------------------------------------------------------------- Hadamard
+@_on_device
 def hadamard(x: torch.Tensor, n: int, K: int, had_bits: Optional[torch.Tensor],
              fp32_had: bool = False) -> torch.Tensor:
     """Rotated activations in x's dtype, last dim zero-padded from x.shape[-1] to n."""
@@ -119,26 +211,24 @@ def hadamard(x: torch.Tensor, n: int, K: int, had_bits: Optional[torch.Tensor],
     return out.reshape(*x.shape[:-1], n)
 
 
+@_on_device
 def hadamard_quant_i8(x: torch.Tensor, n: int, K: int, had_bits: Optional[torch.Tensor],
                       scale0: float, scale1: Optional[float] = None, *, fp32_had: bool = False,
                       row_sel: Optional[torch.Tensor] = None, skip_col0: bool = False,
-                      out: Optional[torch.Tensor] = None,
-                      x0_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+                      out=None, x0_out: Optional[torch.Tensor] = None, tiled: bool = False):
     x2 = _rows(x)
     _need_cuda(x2, had_bits, row_sel, out)
     M, n_in = x2.shape
-    K_pad = ceil_to(n, 128) if out is None else out.shape[1]
-    if out is None:
-        out = torch.empty((M, K_pad), dtype=torch.int8, device=x.device)
+    out, optr, K_pad, ldo = _out_act(out, tiled, M, ceil_to(n, 128), x.device)
     if skip_col0 and x0_out is None:
         x0_out = torch.empty((M,), dtype=torch.float32, device=x.device)
     call("mq_hadamard_quant_i8", x2.data_ptr(), dtype_code(x2.dtype), M, n_in, x2.stride(0), n, K,
          _ptr(had_bits), int(fp32_had), float(scale0), float(scale0 if scale1 is None else scale1),
-         _ptr(row_sel), int(skip_col0), _ptr(x0_out), out.data_ptr(), K_pad, out.stride(0),
-         _stream())
+         _ptr(row_sel), int(skip_col0), _ptr(x0_out), optr, K_pad, ldo, _stream())
     return out, x0_out
 
 
+@_on_device
 def rope_inplace(x: torch.Tensor, heads: int, head_dim: int, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
     """Rotate-half RoPE in place on the first heads*head_dim columns of x [T, >= heads*head_dim]
     (x may be a column slice of a wider tensor).  cos / sin: [T, head_dim], x's dtype."""
@@ -153,11 +243,12 @@ def rope_inplace(x: torch.Tensor, heads: int, head_dim: int, cos: torch.Tensor, 
 ACT_SILU_MUL, ACT_QUICK_GELU = 1, 2
 
 
+@_on_device
 def act_hadamard_quant_i8(x: torch.Tensor, x2: Optional[torch.Tensor], act: int, n: int, K: int,
                           had_bits: Optional[torch.Tensor], scale0: float, scale1: Optional[float] = None, *,
                           fp32_had: bool = False, row_sel: Optional[torch.Tensor] = None,
-                          skip_col0: bool = False, out: Optional[torch.Tensor] = None,
-                          x0_out: Optional[torch.Tensor] = None):
+                          skip_col0: bool = False, out=None,
+                          x0_out: Optional[torch.Tensor] = None, tiled: bool = False):
     """silu(x) * x2 (ACT_SILU_MUL) or quick_gelu(x) (ACT_QUICK_GELU) -> [pad] -> Hadamard -> int8,
     one launch.  x and x2 may be column slices of one tensor (same row stride)."""
     a = _rows(x)
@@ -166,18 +257,17 @@ def act_hadamard_quant_i8(x: torch.Tensor, x2: Optional[torch.Tensor], act: int,
     if b is not None:
         assert b.shape == a.shape and b.stride(0) == a.stride(0) and b.dtype == a.dtype
     M, n_in = a.shape
-    K_pad = ceil_to(n, 128) if out is None else out.shape[1]
-    if out is None:
-        out = torch.empty((M, K_pad), dtype=torch.int8, device=x.device)
+    out, optr, K_pad, ldo = _out_act(out, tiled, M, ceil_to(n, 128), x.device)
     if skip_col0 and x0_out is None:
         x0_out = torch.empty((M,), dtype=torch.float32, device=x.device)
     call("mq_act_hadamard_quant_i8", a.data_ptr(), _ptr(b), int(act), dtype_code(a.dtype), M, n_in, a.stride(0),
          n, K, _ptr(had_bits), int(fp32_had), float(scale0), float(scale0 if scale1 is None else scale1),
-         _ptr(row_sel), int(skip_col0), _ptr(x0_out), out.data_ptr(), K_pad, out.stride(0), _stream())
+         _ptr(row_sel), int(skip_col0), _ptr(x0_out), optr, K_pad, ldo, _stream())
     return out, x0_out
 
 
 # --------------------------------------------------------------------------- weights
+@_on_device
 def pack_i4(q: torch.Tensor) -> torch.Tensor:
     _need_cuda(q)
     q = q.to(torch.int8).contiguous()
@@ -187,6 +277,7 @@ def pack_i4(q: torch.Tensor) -> torch.Tensor:
     return out.reshape(*q.shape[:-1], cols // 2)
 
 
+@_on_device
 def unpack_i4(p: torch.Tensor) -> torch.Tensor:
     _need_cuda(p)
     p = p.contiguous()
@@ -196,6 +287,7 @@ def unpack_i4(p: torch.Tensor) -> torch.Tensor:
     return out.reshape(*p.shape[:-1], half * 2)
 
 
+@_on_device
 def weight_levels(w: torch.Tensor, scale: torch.Tensor, bits: int) -> torch.Tensor:
     """Integer levels of a fake-quantized weight: clamp(rint(w / scale[n]), -2^(b-1), 2^(b-1)-1)."""
     _need_cuda(w, scale)
@@ -211,6 +303,7 @@ def weight_levels(w: torch.Tensor, scale: torch.Tensor, bits: int) -> torch.Tens
     return q
 
 
+@_on_device
 def wquant_sym(w: torch.Tensor, bits: int = 4, mse: bool = False, norm: float = 2.4, grid: int = 100,
                maxshrink: float = 0.8, want_levels: bool = True, want_packed: bool = False,
                want_wq: bool = False):
@@ -232,6 +325,7 @@ def wquant_sym(w: torch.Tensor, bits: int = 4, mse: bool = False, norm: float = 
     return scale, levels, packed, (wq.reshape(w.shape) if want_wq else None)
 
 
+@_on_device
 def gptq_block(W: torch.Tensor, i1: int, i2: int, Hinv: torch.Tensor, scale: torch.Tensor, bits: int,
                Q: torch.Tensor, Err: torch.Tensor) -> None:
     """Column loop of one GPTQ block (``mq_gptq_block``): reads W[:, i1:i2], writes Q[:, i1:i2] and
@@ -246,6 +340,7 @@ def gptq_block(W: torch.Tensor, i1: int, i2: int, Hinv: torch.Tensor, scale: tor
          Q.data_ptr() + i1 * fsz, Q.stride(0), Err.data_ptr(), Err.stride(0), _stream())
 
 
+@_on_device
 def prepack(q: torch.Tensor, bits: int, zero_col0: bool = False) -> torch.Tensor:
     """int levels [N, K] -> the pre-tiled image streamed by gemm_w4a8."""
     _need_cuda(q)
@@ -274,10 +369,11 @@ def splitk_workspace(device, nbytes: int = 64 << 20) -> torch.Tensor:
 
 
 def gemm_debug_force(tile: int = -1, splits: int = 0) -> None:
-    """Tuning hook: force the tile shape (0: 128x128, 1: 256x256, 2: 256x128) / split-K."""
+    """Tuning hook: force the tile shape (ids: csrc/gemm_w4a8.hip dispatch_tile) / split-K."""
     call("mq_gemm_debug_force", tile, splits)
 
 
+@_on_device
 def gemm_w4a8(a: torch.Tensor, w_img: torch.Tensor, w_bits: int, N: int, s_x0: float,
               s_w: torch.Tensor, *, s_x1: Optional[float] = None,
               row_sel: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
@@ -285,87 +381,87 @@ def gemm_w4a8(a: torch.Tensor, w_img: torch.Tensor, w_bits: int, N: int, s_x0: f
               out_dtype: torch.dtype = torch.float16, M: Optional[int] = None,
               out: Optional[torch.Tensor] = None, use_workspace: bool = True) -> torch.Tensor:
     _need_cuda(a, w_img, s_w, row_sel, bias, x0, w0, out)
-    assert a.dtype == torch.int8 and a.dim() == 2 and a.stride(1) == 1
-    M = a.shape[0] if M is None else M
-    K_pad = a.shape[1]
+    aptr, lda, M_a, K_pad = _a_args(a)
+    M = M_a if M is None else M
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=a.device)
     ws = splitk_workspace(a.device) if use_workspace else None
-    call("mq_gemm_w4a8_ws", a.data_ptr(), a.stride(0), w_img.data_ptr(), w_bits, M, N, K_pad,
+    call("mq_gemm_w4a8_ws", aptr, lda, w_img.data_ptr(), w_bits, M, N, K_pad,
          float(s_x0), float(s_x0 if s_x1 is None else s_x1), _ptr(row_sel), s_w.data_ptr(),
          _ptr(bias), _ptr(x0), _ptr(w0), out.data_ptr(), dtype_code(out.dtype), out.stride(0),
          _ptr(ws), 0 if ws is None else ws.numel(), _stream())
     return out
 
 
+@_on_device
 def quantize_act_dyn_i8(x: torch.Tensor, bits: int = 8, clip_ratio: float = 1.0, *, skip_col0: bool = False,
-                        out: Optional[torch.Tensor] = None):
+                        out=None, tiled: bool = False):
     """Dynamic symmetric per-token quantizer (the reference's default activation mode).
     Returns (int8 [M, ceil128(K)], per-row scales fp32 [M], column 0 as fp32 [M] | None)."""
     x2 = _rows(x)
     _need_cuda(x2, out)
     M, K = x2.shape
-    K_pad = ceil_to(K, 128) if out is None else out.shape[1]
-    if out is None:
-        out = torch.empty((M, K_pad), dtype=torch.int8, device=x.device)
+    out, optr, K_pad, ldo = _out_act(out, tiled, M, ceil_to(K, 128), x.device)
     scale = torch.empty((M,), dtype=torch.float32, device=x.device)
     x0 = torch.empty((M,), dtype=torch.float32, device=x.device) if skip_col0 else None
     call("mq_quantize_act_dyn_i8", x2.data_ptr(), dtype_code(x2.dtype), M, K, x2.stride(0), int(bits),
-         float(clip_ratio), int(skip_col0), _ptr(x0), scale.data_ptr(), out.data_ptr(), K_pad, out.stride(0),
+         float(clip_ratio), int(skip_col0), _ptr(x0), scale.data_ptr(), optr, K_pad, ldo,
          _stream())
     return out, scale, x0
 
 
+@_on_device
 def gemm_w4a8_rowscale(a: torch.Tensor, w_img: torch.Tensor, w_bits: int, N: int, s_x_rows: torch.Tensor,
                        s_w: torch.Tensor, *, bias: Optional[torch.Tensor] = None, x0: Optional[torch.Tensor] = None,
                        w0: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.float16,
                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _need_cuda(a, w_img, s_x_rows, s_w, bias, x0, w0, out)
-    assert a.dtype == torch.int8 and a.dim() == 2 and a.stride(1) == 1 and s_x_rows.dtype == torch.float32
-    M, K_pad = a.shape
+    assert s_x_rows.dtype == torch.float32
+    aptr, lda, M, K_pad = _a_args(a)
     assert s_x_rows.numel() == M and s_x_rows.is_contiguous()
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=a.device)
     ws = splitk_workspace(a.device)
-    call("mq_gemm_w4a8_rowscale_ws", a.data_ptr(), a.stride(0), w_img.data_ptr(), w_bits, M, N, K_pad,
+    call("mq_gemm_w4a8_rowscale_ws", aptr, lda, w_img.data_ptr(), w_bits, M, N, K_pad,
          s_x_rows.data_ptr(), s_w.data_ptr(), _ptr(bias), _ptr(x0), _ptr(w0), out.data_ptr(),
          dtype_code(out.dtype), out.stride(0), _ptr(ws), 0 if ws is None else ws.numel(), _stream())
     return out
 
 
+@_on_device
 def gemm_w4a8_residual(a: torch.Tensor, w_img: torch.Tensor, w_bits: int, N: int, s_x0: float, s_w: torch.Tensor,
                        residual: torch.Tensor, *, s_x1: Optional[float] = None, row_sel: Optional[torch.Tensor] = None,
                        bias: Optional[torch.Tensor] = None, x0: Optional[torch.Tensor] = None,
                        w0: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """residual + Linear(x) in one launch; the output has the residual's dtype (may alias it)."""
     _need_cuda(a, w_img, s_w, residual, row_sel, bias, x0, w0, out)
-    assert a.dtype == torch.int8 and a.dim() == 2 and a.stride(1) == 1
-    M, K_pad = a.shape
+    aptr, lda, M, K_pad = _a_args(a)
     assert residual.shape == (M, N) and residual.stride(1) == 1
     if out is None:
         out = torch.empty((M, N), dtype=residual.dtype, device=a.device)
     assert out.dtype == residual.dtype
     ws = splitk_workspace(a.device)
-    call("mq_gemm_w4a8_residual_ws", a.data_ptr(), a.stride(0), w_img.data_ptr(), w_bits, M, N, K_pad,
+    call("mq_gemm_w4a8_residual_ws", aptr, lda, w_img.data_ptr(), w_bits, M, N, K_pad,
          float(s_x0), float(s_x0 if s_x1 is None else s_x1), _ptr(row_sel), s_w.data_ptr(), _ptr(bias), _ptr(x0),
          _ptr(w0), residual.data_ptr(), residual.stride(0), out.data_ptr(), dtype_code(out.dtype), out.stride(0),
          _ptr(ws), 0 if ws is None else ws.numel(), _stream())
     return out
 
 
+@_on_device
 def gemm_w4a8_i32(a: torch.Tensor, w_img: torch.Tensor, w_bits: int, N: int,
                   use_workspace: bool = True) -> torch.Tensor:
     _need_cuda(a, w_img)
-    assert a.dtype == torch.int8 and a.dim() == 2 and a.stride(1) == 1
-    M, K_pad = a.shape
+    aptr, lda, M, K_pad = _a_args(a)
     acc = torch.empty((M, N), dtype=torch.int32, device=a.device)
     ws = splitk_workspace(a.device) if use_workspace else None
-    call("mq_gemm_w4a8_i32_ws", a.data_ptr(), a.stride(0), w_img.data_ptr(), w_bits, M, N, K_pad,
+    call("mq_gemm_w4a8_i32_ws", aptr, lda, w_img.data_ptr(), w_bits, M, N, K_pad,
          acc.data_ptr(), acc.stride(0), _ptr(ws), 0 if ws is None else ws.numel(), _stream())
     return acc
 
 
 # --------------------------------------------------------------------------- observers
+@_on_device
 def minmax_channels(x: torch.Tensor, col_begin: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
     x2 = _rows(x)
     _need_cuda(x2)
@@ -377,6 +473,7 @@ def minmax_channels(x: torch.Tensor, col_begin: int = 0) -> Tuple[torch.Tensor, 
     return mn, mx
 
 
+@_on_device
 def minmax_tensor(x: torch.Tensor, col_begin: int = 0) -> torch.Tensor:
     """Returns a device tensor [min, max] (fp32)."""
     x2 = _rows(x)

@@ -1,0 +1,253 @@
+"""GPU parity of the TILED activation layout (MQ_LD_TILED) and of the wave-specialised GEMM kernels
+(csrc/gemm_ws.hip, V_MFMA_I32_32X32X32_I8) that consume it.
+
+Bar as everywhere: int8 levels and int32 accumulators bit-exact against the CPU oracle, fp outputs
+bit-exact against the oracle's single-rounded fp32 epilogue."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from golden_inputs import make_w, make_x
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+DTYPES = [torch.float16, torch.bfloat16, torch.float32]
+MODE = {torch.float16: 1, torch.bfloat16: 2, torch.float32: 0}
+WS_TILES = (40, 41, 42, 43, 44, 50, 51)
+
+
+def ops():
+    from mquant_amd import ops as o
+    return o
+
+
+def to_dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def test_layout_formula_of_the_header():
+    """include/mquant_hip.h: byte offset of (m, k) = ((m/16)(K_pad/64) + k/64) 1024 + (((k/16)%4) 16 + m%16) 16 + k%16."""
+    o = ops()
+    M, K_pad = 37, 256
+    a = torch.arange(M * K_pad, dtype=torch.int32).reshape(M, K_pad).to(torch.int8).to(DEV)
+    t = o.TiledAct.from_rows(a)
+    flat = t.data.reshape(-1).cpu().numpy()
+    ar = a.cpu().numpy()
+    for m, k in [(0, 0), (5, 17), (36, 255), (16, 64), (31, 130), (15, 63), (32, 192)]:
+        off = ((m // 16) * (K_pad // 64) + k // 64) * 1024 + (((k // 16) % 4) * 16 + m % 16) * 16 + k % 16
+        assert flat[off] == ar[m, k], (m, k)
+    assert torch.equal(t.to_rows(), a)
+
+
+# ------------------------------------------------------------------------------------- quantizers
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(1, 16), (7, 100), (33, 1176), (64, 3584), (130, 640)])
+def test_static_quantizer_tiled_equals_oracle(dtype, shape):
+    x = make_x(3, shape, outlier_gain=30.0)
+    xt = to_dev(x, dtype)
+    M, K = shape
+    sel = to_dev((np.arange(M) % 3 == 0).astype(np.uint8))
+    q, x0 = ops().quantize_act_i8(xt, 0.0371, 0.0113, row_sel=sel, skip_col0=True, tiled=True)
+    assert isinstance(q, ops().TiledAct) and q.K_pad == (K + 127) // 128 * 128
+    xr = xt.float().cpu().numpy()
+    ref = np.where(sel.cpu().numpy()[:, None] != 0, oracle.quant_static(xr, np.float32(0.0113)),
+                   oracle.quant_static(xr, np.float32(0.0371)))
+    ref[:, 0] = 0
+    got = q.to_rows().cpu().numpy()
+    np.testing.assert_array_equal(got[:, :K], ref)
+    assert not got[:, K:].any()
+    np.testing.assert_array_equal(x0.cpu().numpy(), xr[:, 0])
+    q2, _ = ops().quantize_act_i8(xt, 0.0371, 0.0113, row_sel=sel, skip_col0=True)
+    assert torch.equal(q.to_rows(), q2)
+
+
+@pytest.mark.parametrize("n_in,n", [(5120, 5120), (18944, 19968), (1280, 1280), (700, 768)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_hadamard_quant_tiled_equals_row_major(had_table, n_in, n, dtype):
+    o = ops()
+    K = {5120: 40, 19968: 156, 1280: 20, 768: 12}[n]
+    bits = to_dev(had_table["words"][K])
+    for M in (5, 48, 131):
+        x = to_dev(make_x(M + n, (M, n_in)), dtype)
+        sel = to_dev((np.arange(M) >= M // 2).astype(np.uint8))
+        rows, x0r = o.hadamard_quant_i8(x, n, K, bits, 0.05, 0.02, row_sel=sel, skip_col0=True)
+        tiled, x0t = o.hadamard_quant_i8(x, n, K, bits, 0.05, 0.02, row_sel=sel, skip_col0=True, tiled=True)
+        assert torch.equal(tiled.to_rows(), rows) and torch.equal(x0r, x0t)
+    # the row-major result itself is pinned to the oracle in test_gpu_kernels.py
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+def test_fused_activation_rmsn_and_dynamic_quantizers_tiled(had_table, dtype):
+    o = ops()
+    M, n_in, n, K = 70, 18944 // 4, 19968 // 4, 156       # 4736 -> 4992 = 156 x 32
+    bits = to_dev(had_table["words"][K])
+    g = to_dev(make_x(1, (M, n_in)), dtype)
+    u = to_dev(make_x(2, (M, n_in)), dtype)
+    rows, _ = o.act_hadamard_quant_i8(g, u, o.ACT_SILU_MUL, n, K, bits, 0.04)
+    tiled, _ = o.act_hadamard_quant_i8(g, u, o.ACT_SILU_MUL, n, K, bits, 0.04, tiled=True)
+    assert torch.equal(tiled.to_rows(), rows)
+    x = to_dev(make_x(3, (M, 1280)), dtype)
+    rows, _ = o.rmsn_quantize_i8(x, 1280.0, 1e-6, 0.03)
+    tiled, _ = o.rmsn_quantize_i8(x, 1280.0, 1e-6, 0.03, tiled=True)
+    assert torch.equal(tiled.to_rows(), rows)
+    rows, s_r, x0_r = o.quantize_act_dyn_i8(x, 8, 0.9, skip_col0=True)
+    tiled, s_t, x0_t = o.quantize_act_dyn_i8(x, 8, 0.9, skip_col0=True, tiled=True)
+    assert torch.equal(tiled.to_rows(), rows) and torch.equal(s_r, s_t) and torch.equal(x0_r, x0_t)
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+def _levels(seed, shape, bits):
+    lim = 1 << (bits - 1)
+    q = np.random.default_rng(seed).integers(-lim, lim, size=shape, dtype=np.int8)
+    q.reshape(-1)[:4] = [-lim, lim - 1, -lim, lim - 1]
+    return q
+
+
+@pytest.mark.parametrize("w_bits", [4, 8])
+@pytest.mark.parametrize("M,N,K", [(300, 520, 1408), (96, 128, 128), (17, 40, 256), (768, 1280, 640)])
+def test_every_wave_specialised_tile_is_exact(w_bits, M, N, K):
+    """All instantiations behind dispatch_ws, with and without split-K, ragged edges in M and N:
+    int32 accumulators and the fp16 epilogue against the oracle."""
+    o = ops()
+    rng = np.random.default_rng(M + N + K)
+    a = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+    a[0, :8] = [-128, 127, -128, 127, -128, -128, 127, 127]
+    w = _levels(7, (N, K), w_bits)
+    s_w = rng.uniform(0.001, 0.01, size=N).astype(np.float32)
+    bias = rng.normal(size=N).astype(np.float32)
+    acc_ref = oracle.gemm_i32(a, w)
+    y_ref = oracle.round_to(oracle.epilogue(acc_ref, np.float32(0.02), s_w, bias=bias), 1)
+    at = o.TiledAct.from_rows(to_dev(a))
+    img = o.prepack(to_dev(w), w_bits)
+    swt, bt = to_dev(s_w), to_dev(bias)
+    o.splitk_workspace(torch.device(DEV), 64 << 20)
+    try:
+        for tile in WS_TILES:
+            if w_bits == 8 and tile == 42:
+                continue                      # 192 x 128 exists for int4 weights only
+            for splits in (1, 3):
+                o.gemm_debug_force(tile, splits)
+                acc = o.gemm_w4a8_i32(at, img, w_bits, N)
+                np.testing.assert_array_equal(acc.cpu().numpy(), acc_ref, err_msg=f"tile {tile} splits {splits}")
+                y = o.gemm_w4a8(at, img, w_bits, N, 0.02, swt, bias=bt)
+                np.testing.assert_array_equal(y.float().cpu().numpy(), y_ref, err_msg=f"tile {tile} splits {splits}")
+    finally:
+        o.gemm_debug_force(-1, 0)
+
+
+def test_transpose_detecting_and_worst_case_magnitude_tiled():
+    o = ops()
+    M = N = 64
+    K = 128
+    a = np.zeros((M, K), dtype=np.int8)
+    a[np.arange(M), np.arange(M)] = 1
+    w = np.zeros((N, K), dtype=np.int8)
+    for n in range(N):
+        for k in range(K):
+            w[n, k] = ((3 * n + 5 * k) % 15) - 7
+    acc = o.gemm_w4a8_i32(o.TiledAct.from_rows(to_dev(a)), o.prepack(to_dev(w), 4), 4, N)
+    np.testing.assert_array_equal(acc.cpu().numpy(), w[:, :M].T.astype(np.int32))
+    K = 30720
+    a = np.full((16, K), -128, dtype=np.int8)
+    w = np.full((16, K), -8, dtype=np.int8)
+    acc = o.gemm_w4a8_i32(o.TiledAct.from_rows(to_dev(a)), o.prepack(to_dev(w), 4), 4, 16)
+    assert int(acc.max()) == int(acc.min()) == 128 * 8 * K
+
+
+@pytest.mark.parametrize("out_dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(48, 80, 256), (130, 36, 1280), (768, 256, 3584)])
+def test_dequant_epilogue_with_every_optional_term_tiled(out_dtype, M, N, K):
+    o = ops()
+    rs = np.random.RandomState(M * N)
+    a = rs.randint(-128, 128, size=(M, K)).astype(np.int8)
+    w = _levels(11, (N, K), 4)
+    s_w = (0.001 + rs.rand(N) * 0.004).astype(np.float32)
+    bias = (rs.randn(N) * 0.1).astype(np.float32)
+    sel = (np.arange(M) >= M // 3).astype(np.uint8)
+    x0 = rs.randn(M).astype(np.float32)
+    w0 = (rs.randn(N) * 0.02).astype(np.float32)
+    sx0, sx1 = 0.031, 0.0077
+    img = o.prepack(to_dev(w), 4, zero_col0=True)
+    at = o.TiledAct.from_rows(to_dev(a))
+    w_eff = w.copy()
+    w_eff[:, 0] = 0
+    acc = oracle.gemm_i32(a, w_eff)
+    ref = oracle.round_to(oracle.epilogue(acc, np.float32(sx0), s_w, bias=bias, sx1=np.float32(sx1), row_sel=sel,
+                                          x0=x0, w0=w0), MODE[out_dtype])
+    try:
+        for tile in (-1, 40, 43, 44):
+            o.gemm_debug_force(tile, 0)
+            y = o.gemm_w4a8(at, img, 4, N, sx0, to_dev(s_w), s_x1=sx1, row_sel=to_dev(sel), bias=to_dev(bias),
+                            x0=to_dev(x0), w0=to_dev(w0), out_dtype=out_dtype)
+            np.testing.assert_array_equal(y.float().cpu().numpy(), ref, err_msg=f"tile {tile}")
+    finally:
+        o.gemm_debug_force(-1, 0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_residual_and_row_scale_entry_points_tiled(dtype):
+    o = ops()
+    M, N, K = 130, 200, 640
+    rng = np.random.default_rng(3)
+    a = to_dev(rng.integers(-128, 128, size=(M, K), dtype=np.int8))
+    at = o.TiledAct.from_rows(a)
+    img = o.prepack(to_dev(rng.integers(-8, 8, size=(N, K), dtype=np.int8)), 4)
+    s_w = to_dev(rng.uniform(0.001, 0.01, size=N).astype(np.float32))
+    bias = to_dev(rng.normal(size=N).astype(np.float32))
+    res = to_dev(rng.normal(size=(M, N)).astype(np.float32) * 3).to(dtype)
+    s_rows = to_dev(rng.uniform(0.01, 0.05, size=M).astype(np.float32))
+    want = o.gemm_w4a8_residual(a, img, 4, N, 0.02, s_w, res, bias=bias)
+    got = o.gemm_w4a8_residual(at, img, 4, N, 0.02, s_w, res, bias=bias)
+    assert torch.equal(got, want)
+    want = o.gemm_w4a8_rowscale(a, img, 4, N, s_rows, s_w, bias=bias, out_dtype=dtype)
+    got = o.gemm_w4a8_rowscale(at, img, 4, N, s_rows, s_w, bias=bias, out_dtype=dtype)
+    assert torch.equal(got, want)
+
+
+def test_symmetric_kernels_accept_the_tiled_layout():
+    """The 256 x 256 kernels (gate_up, split-K down_proj) read tiled activations too."""
+    o = ops()
+    M, N, K = 300, 520, 1408
+    rng = np.random.default_rng(9)
+    a = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+    w = _levels(5, (N, K), 4)
+    acc_ref = oracle.gemm_i32(a, w)
+    at = o.TiledAct.from_rows(to_dev(a))
+    img = o.prepack(to_dev(w), 4)
+    o.splitk_workspace(torch.device(DEV), 64 << 20)
+    try:
+        for tile in (1, 3, 13, 10, 26, 31, 35, 2):
+            for splits in (1, 3):
+                o.gemm_debug_force(tile, splits)
+                np.testing.assert_array_equal(o.gemm_w4a8_i32(at, img, 4, N).cpu().numpy(), acc_ref,
+                                              err_msg=f"tile {tile} splits {splits}")
+    finally:
+        o.gemm_debug_force(-1, 0)
+
+
+def test_engine_uses_the_tiled_layout_end_to_end(had_table):
+    """W4A8Linear.forward (quantize -> GEMM through the workspace) equals the oracle composition."""
+    from mquant_amd import engine
+    o = ops()
+    assert engine.ACT_LAYOUT == "tiled"
+    M, n_in, n, N, K = 100, 1216, 1280, 200, 20
+    hk = had_table["mats"][K]
+    x = to_dev(make_x(5, (M, n_in)), torch.float16)
+    W = make_w(6, (N, n))
+    s_w, levels = oracle.wquant_sym(W, bits=4)
+    rot = oracle.hadamard(x.float().cpu().numpy(), n, K, hk, mid_round=1, out_round=1)
+    s_x = float(np.float32(np.abs(rot).max() / 127.0))
+    q_ref = oracle.quant_static(rot, np.float32(s_x))
+    y_ref = oracle.round_to(oracle.epilogue(oracle.gemm_i32(q_ref, levels), np.float32(s_x), s_w), 1)
+    lin = engine.W4A8Linear(to_dev(levels), to_dev(s_w), 4, None, s_x,
+                            had=engine.HadamardSpec(n, K, to_dev(had_table["words"][K])), in_features=n_in)
+    y = lin(x)
+    np.testing.assert_array_equal(y.float().cpu().numpy(), y_ref)
+    a, _ = lin.quantize(x)
+    assert isinstance(a, o.TiledAct)
+    np.testing.assert_array_equal(a.to_rows().cpu().numpy()[:, :n], q_ref)

@@ -1,0 +1,25 @@
+#!/bin/bash
+# usage: tools/bench_prof.sh <out-prefix> [bench flags] -> rocprofv3 --kernel-trace --stats of bench.py, our kernels per (name, grid)
+cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+OUT=$1; shift
+rm -rf gpurun_out/bp; mkdir -p gpurun_out/bp $(dirname $OUT)
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/bp -o b -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-full-prefill "$@" > ${OUT}_bench.json 2> gpurun_out/bp/err
+python3 - "$OUT" <<'PY'
+import collections, csv, sys
+rows = list(csv.DictReader(open("gpurun_out/bp/b_kernel_trace.csv")))
+agg = collections.OrderedDict()
+for r in rows:
+    n = r["Kernel_Name"]
+    if "mq::" not in n:
+        continue
+    name = n.split("(")[0].replace("void ", "")
+    key = (name, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]))
+    agg.setdefault(key, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+tot = sum(sum(v) for v in agg.values())
+with open(sys.argv[1] + "_kernel_stats.csv", "w") as fh:
+    fh.write("kernel,workgroups,calls,avg_us,min_us,total_ms,share\n")
+    for (name, blocks), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        fh.write(f'"{name}",{blocks},{len(v)},{sum(v)/len(v)/1e3:.2f},{min(v)/1e3:.2f},{sum(v)/1e6:.3f},{sum(v)/tot:.4f}\n')
+print(open(sys.argv[1] + "_kernel_stats.csv").read())
+PY
+rm -f gpurun_out/bp/b_kernel_trace.csv

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--configs", default="-1:0,0:1,2:1,1:1")
     ap.add_argument("--only", default="")
     ap.add_argument("--bits", type=int, default=4)
+    ap.add_argument("--tiled", action="store_true", help="activations in the tiled layout for every config (ids >= 40 always)")
     args = ap.parse_args()
     cfgs = [tuple(int(v) for v in c.split(":")) for c in args.configs.split(",")]
     dev = torch.device("cuda:0")
@@ -54,13 +55,17 @@ def main():
         out = torch.empty((M, N), dtype=torch.float16, device=dev)
         ref = None
         cols = []
+        a_t = ops.TiledAct.from_rows(a)
         for tile, splits in cfgs:
-            ops.gemm_debug_force(tile, splits)
-            acc = ops.gemm_w4a8_i32(a, img, args.bits, N)
+            ops.gemm_debug_force(-1, 0)
             if ref is None:
-                ref = acc
-            ok = bool(torch.equal(acc, ref))
-            us = bench(lambda: ops.gemm_w4a8(a, img, args.bits, N, 0.02, s_w, out=out))
+                ref = ops.gemm_w4a8_i32(a, img, args.bits, N)
+                yref = ops.gemm_w4a8(a, img, args.bits, N, 0.02, s_w)
+            ops.gemm_debug_force(tile, splits)
+            aa = a_t if (args.tiled or tile >= 40) else a
+            acc = ops.gemm_w4a8_i32(aa, img, args.bits, N)
+            ok = bool(torch.equal(acc, ref)) and bool(torch.equal(ops.gemm_w4a8(aa, img, args.bits, N, 0.02, s_w), yref))
+            us = bench(lambda: ops.gemm_w4a8(aa, img, args.bits, N, 0.02, s_w, out=out))
             cols.append(f"{us:8.1f} {2.0 * M * N * K / us / 1e6:7.0f}{'' if ok else ' MISMATCH'}")
         print(f"{name:14s} {M:5d} {N:6d} {K:6d} | " + " | ".join(cols))
     ops.gemm_debug_force(-1, 0)

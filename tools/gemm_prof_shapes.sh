@@ -1,0 +1,27 @@
+#!/bin/bash
+# usage: tools/gemm_prof_shapes.sh <configs> [bits] [extra gemm_bench flags] -> kernel durations (rocprofv3) per model shape
+cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/gp
+for s in vis.qkv vis.proj vis.fc1 vis.fc2 llm.q/o llm.kv "llm.qkv" "llm.gate_up" llm.down; do
+  rm -f gpurun_out/gp/t_kernel_trace.csv
+  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/gp -o t -- python3 tools/gemm_bench.py --only "$s" --configs="$1" --bits ${2:-4} $3 > gpurun_out/gp/log 2>&1
+  echo "== $s"
+  python3 - <<'PY'
+import collections, csv
+rows = list(csv.DictReader(open("gpurun_out/gp/t_kernel_trace.csv")))
+agg = collections.OrderedDict()
+for r in rows:
+    n = r["Kernel_Name"]
+    if "mq::" not in n or ("gemm" not in n and "splitk" not in n):
+        continue
+    name = n.split("(")[0].replace("void ", "")
+    key = (name, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]))
+    agg.setdefault(key, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+for (name, blocks), v in agg.items():
+    if len(v) < 10:
+        continue   # the int32 parity calls
+    v = sorted(v)
+    print(f"   {name:58s} blocks {blocks:5d} n {len(v):3d} median {v[len(v)//2]/1e3:7.1f} us  min {v[0]/1e3:7.1f}")
+PY
+done
+rm -f gpurun_out/gp/t_kernel_trace.csv
