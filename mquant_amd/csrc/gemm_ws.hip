@@ -416,6 +416,61 @@ __global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(G
             wzv[e] = par_wz[c8 + e];
         }
     }
+    // Fast path (what every Linear of the prefill takes): whole 8-channel groups, fp16 / bf16 / fp32
+    // output, no residual, no split-K.  Straight-line code: all slab reads first, then the arithmetic,
+    // then the stores back to back -- this part runs once per workgroup with every workgroup of the
+    // launch in it at the same time, so its latency chain is launch time ("fixed cost").
+    if (EPI != EPI_I32 && !to_partial && !p.residual && __all(n_full)) {
+        constexpr int ITERS = (BM + RPI - 1) / RPI;
+        const int lrow = tid / LPR;
+        v4i q0[ITERS], q1[ITERS];
+        float sxr[ITERS], xzr[ITERS];
+#pragma unroll
+        for (int t = 0; t < ITERS; ++t) {
+            const int row = (t * RPI + lrow < BM) ? t * RPI + lrow : BM - 1;
+            q0[t] = *reinterpret_cast<const v4i *>(smem + row * PITCH + c8 * 4);
+            q1[t] = *reinterpret_cast<const v4i *>(smem + row * PITCH + c8 * 4 + 16);
+            if (KS == 2) {
+                q0[t] += *reinterpret_cast<const v4i *>(smem + BM * PITCH + row * PITCH + c8 * 4);
+                q1[t] += *reinterpret_cast<const v4i *>(smem + BM * PITCH + row * PITCH + c8 * 4 + 16);
+            }
+            sxr[t] = par_sx[row];
+            xzr[t] = par_xz[row];
+        }
+        const bool has_bias = p.bias != nullptr, has_x0 = p.x0 != nullptr;
+#pragma unroll
+        for (int t = 0; t < ITERS; ++t) {
+            const long m = m0 + t * RPI + lrow;
+            int a[8] = {q0[t][0], q0[t][1], q0[t][2], q0[t][3], q1[t][0], q1[t][1], q1[t][2], q1[t][3]};
+            float y[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (W_BITS == 4) a[e] >>= 4;
+                float v = (float)a[e] * sxr[t];
+                v = v * swv[e];
+                if (has_bias) v = v + bsv[e];
+                if (has_x0) {
+                    const float pr = xzr[t] * wzv[e];
+                    v = v + pr;
+                }
+                y[e] = v;
+            }
+            if (m >= p.M || t * RPI + lrow >= BM) continue;
+            if (EPI == EPI_F32) {
+                float *o = reinterpret_cast<float *>(p.out) + m * p.ldo + n;
+                *reinterpret_cast<v4f *>(o) = v4f{y[0], y[1], y[2], y[3]};
+                *reinterpret_cast<v4f *>(o + 4) = v4f{y[4], y[5], y[6], y[7]};
+            } else {
+                v8us h;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    h[e] = (EPI == EPI_F16) ? f32_to_f16_bits(y[e]) : f32_to_bf16_bits(y[e]);
+                *reinterpret_cast<v8us *>(reinterpret_cast<unsigned short *>(p.out) + m * p.ldo + n) = h;
+            }
+        }
+        MQ_STAMP_AT(7);
+        return;
+    }
 #pragma unroll 1
     for (int r0 = 0; r0 < BM; r0 += RPI) {
         const int row = r0 + tid / LPR;
@@ -529,18 +584,20 @@ template <int W_BITS, int EPI>
 int dispatch_ws(const GemmArgs &p, int tile, hipStream_t st)
 {
     switch (tile) {
-    case 40: return launch_ws<96, 128, 1, 4, 2, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI>(p, st);
+    // production shapes: one math wave per SIMD (1 x 4 wave tiles) or two (2 x 4), four loader waves
+    case 40: return launch_ws<96, 128, 1, 4, 1, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI>(p, st);
     case 41: return launch_ws<128, 128, 2, 4, 1, 4, (W_BITS == 4 ? 6 : 4), W_BITS, EPI>(p, st);
     case 42:
         if constexpr (W_BITS == 4) return launch_ws<192, 128, 2, 4, 1, 4, 4, W_BITS, EPI>(p, st);
         else break;
-    case 43: return launch_ws<64, 128, 1, 4, 2, 4, (W_BITS == 4 ? 8 : 6), W_BITS, EPI>(p, st);
+    case 43: return launch_ws<64, 128, 1, 4, 1, 4, (W_BITS == 4 ? 8 : 6), W_BITS, EPI>(p, st);
+    // two k groups per wave tile (sub-steps of opposite parity, phases M P M P / P M P M): measured on
+    // par with the above; kept selectable for comparison
     case 44:
         if constexpr (W_BITS == 4) return launch_ws<128, 128, 1, 4, 2, 4, 6, W_BITS, EPI>(p, st);
-        else return launch_ws<128, 128, 2, 4, 1, 4, 4, W_BITS, EPI>(p, st);
-    // one wave per SIMD (comparison points of DESIGN 4.1)
-    case 50: return launch_ws<96, 128, 1, 4, 1, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI>(p, st);
-    case 51: return launch_ws<128, 128, 1, 4, 1, 4, (W_BITS == 4 ? 6 : 4), W_BITS, EPI>(p, st);
+        else return launch_ws<128, 128, 1, 4, 1, 4, 4, W_BITS, EPI>(p, st);
+    case 45: return launch_ws<96, 128, 1, 4, 2, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI>(p, st);
+    case 46: return launch_ws<64, 128, 1, 4, 2, 4, (W_BITS == 4 ? 8 : 6), W_BITS, EPI>(p, st);
     default: break;
     }
     return fail(MQ_EINVAL, "gemm_ws: unknown tile %d", tile);

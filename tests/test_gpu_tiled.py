@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 DTYPES = [torch.float16, torch.bfloat16, torch.float32]
 MODE = {torch.float16: 1, torch.bfloat16: 2, torch.float32: 0}
-WS_TILES = (40, 41, 42, 43, 44, 50, 51)
+WS_TILES = (40, 41, 42, 43, 44, 45, 46)
 
 
 def ops():
