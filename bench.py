@@ -9,13 +9,18 @@ inputs resident in HBM.  Attention, norms, RoPE and lm_head are outside the path
 section 8) and are not executed.  Weights are random with the real shapes; data is synthetic.
 
     python bench.py --gpus N --steps K --warmup W
-N > 1 is launched by torch.distributed.run, one rank per GPU; every rank prefills its own
-sample (batch sharding, weak scaling) and the ranks exchange last-token logits with one RCCL
-all_gather per step.  Rank 0 prints ONE JSON line.
+N > 1: one rank per GPU over RCCL.  Started under torch.distributed.run (the driver's command) the
+process is a rank; started plainly with --gpus N it spawns the N ranks itself as FRESH child
+processes (before anything touches the GPU) and returns their exit code.  Every rank prefills its
+own image+prompt sample (batch sharding, sample i -> rank i % N, weak scaling); the ranks exchange
+their real last-token logits with one RCCL all_gather per step, and rank 0 checks the gathered
+logits against its own single-GPU computation of every sample.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,6 +30,71 @@ if ROOT not in sys.path:
 
 PEAK_INT8_TOPS = 5000.0   # dense int8 MFMA, 2 x the 2.5 PF bf16 dense peak (MI355X_MICROARCH.md)
 VOCAB = 152064
+
+
+def cpu_baseline_reference(budget_s: float = 40.0):
+    """The reference's CPU path timed on the host cores: this repository's ``fake_quant`` package in
+    its SIMULATED mode (fp32 torch ops on fake-quantized tensors, pinned to the reference's forward by
+    the goldens of tests/test_fake_quant_cpu.py / test_gpu_wrapper_golden.py), CPU tensors,
+    torch.set_num_threads(all cores), the full row count, ONE instance of each of the 14 layer shapes
+    including zero pad + matmul_hadU + split; scaled by the instance counts to one prefill."""
+    import functools
+    import torch
+    from fake_quant import hadamard_utils as hu, quant_utils as qu, utils as fq_utils
+    from fake_quant.gptq.rtn import rtn_module
+    from mquant_amd import workload
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    torch.set_grad_enabled(False)
+
+    class A:
+        skip_names = []
+    t_begin = time.perf_counter()
+    est, measured, detail, skipped = 0.0, 0.0, [], []
+    for sp in workload.qwen2vl_7b_specs(msq=False):
+        if time.perf_counter() - t_begin > budget_s:
+            skipped.append(sp.name)
+            continue
+        g = torch.Generator().manual_seed(len(detail))
+        lin = torch.nn.Linear(sp.k, sp.n, bias=sp.bias)
+        lin.weight.data = torch.randn((sp.n, sp.k), generator=g) * 0.02
+        wrap = qu.ActQuantWrapper(lin)
+        if sp.had_K:
+            hadK, Kh = hu.get_hadK(sp.k)
+            wrap.online_full_had, wrap.had_K, wrap.K = True, hadK, Kh
+        if sp.split:
+            wrap.split = True
+            wrap.split_weights()
+        if sp.k != sp.k_in:
+            wrap.register_forward_pre_hook(functools.partial(fq_utils.revise_down_input, new_size=sp.k))
+        rtn_module(wrap, "layer", 4, True, False, [], {})
+        wrap.real_quant = False                       # the simulated (reference) evaluation, not the HIP backend
+        wrap.simulate_on_cpu = True                   # explicit opt-in: the wrapper has no CPU fallback of its own
+        wrap.quantizer.configure(bits=8, sym=True, static=True, observer_type="minmax")
+        x = torch.randn((sp.M, sp.k_in), generator=g)
+        qu.calib_layer(wrap, [x[: min(sp.M, 64)]], A())
+        wrap(x[:8])                                   # first-call setup outside the timing
+        reps, t0 = 0, time.perf_counter()
+        while reps < 8 and (reps == 0 or time.perf_counter() - t0 < 1.0):   # ~1 s per shape, 10-20 s in all
+            wrap(x)
+            reps += 1
+        spent = time.perf_counter() - t0
+        dt = spent / reps
+        measured += spent
+        est += dt * sp.count
+        detail.append(f"{sp.name} {dt * 1e3:.0f} ms x{sp.count}")
+        del wrap, lin, x
+    if skipped:      # bounded run: the shapes not reached are charged at the measured seconds per op
+        done_ops = sum(2.0 * sp.M * sp.k * sp.n * sp.count for sp in workload.qwen2vl_7b_specs(msq=False) if sp.name not in skipped)
+        all_ops = sum(2.0 * sp.M * sp.k * sp.n * sp.count for sp in workload.qwen2vl_7b_specs(msq=False))
+        est *= all_ops / done_ops
+    return {"value": round(768.0 / est, 3), "unit": "tokens/s", "cores": cores, "kind": "reference",
+            "sample": f"fake_quant simulated ActQuantWrapper.forward (== reference, pinned by goldens) on CPU fp32 tensors, "
+                      f"torch {cores} threads, full rows, one instance per layer shape, {measured:.1f} s measured, scaled by "
+                      f"instance count to the 327-Linear prefill ({est:.1f} s per prefill)"
+                      + (f"; not reached within the time budget and charged pro rata by ops: {', '.join(skipped)}" if skipped else "")
+                      + "; " + ", ".join(detail)}
 
 
 def cpu_baseline(prefill_ops_total: float):
@@ -50,7 +120,7 @@ def cpu_baseline(prefill_ops_total: float):
         prepared.append((x, w, s_w, k, hK))
     ops_sample, reps = 0.0, 0
     t0 = time.perf_counter()
-    while reps < 16 and (reps == 0 or time.perf_counter() - t0 < 10.0):     # ~10 s of CPU work
+    while reps < 16 and (reps == 0 or time.perf_counter() - t0 < 5.0):      # ~5 s of CPU work
         for x, w, s_w, k, hK in prepared:
             if hK:
                 x = oracle.hadamard(x, k, hK, hk, mid_round=1, out_round=1)
@@ -132,7 +202,22 @@ def main():
     ap.add_argument("--ttft-iters", type=int, default=100)
     ap.add_argument("--batch", type=int, default=1,
                     help="image+prompt samples per GPU and step (the benchmark configuration is 1; >1 is a scaling study)")
+    ap.add_argument("--cpu-selftest", action="store_true",
+                    help="launcher / sharding self-test without a GPU: the ranks gather fake logits over gloo")
     args = ap.parse_args()
+
+    # ---- rank launcher: before torch.cuda / HIP is touched, and never by re-exec ---------------------
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            sys.exit(subprocess.call(cmd, env=env))       # fresh children; this process never initialised a GPU
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']} (start one rank per GPU)")
 
     import torch
     import torch.distributed as dist
@@ -141,6 +226,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    if args.cpu_selftest:
+        from mquant_amd import shard
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if distributed:
+            dist.init_process_group(backend="gloo")
+        mine = shard.shard_indices(world, rank, world)
+        local = torch.stack([torch.arange(64, dtype=torch.float32) + 1000.0 * i for i in mine])
+        full = shard.gather_logits(local, world) if distributed else local
+        ok = bool(torch.equal(full, torch.stack([torch.arange(64, dtype=torch.float32) + 1000.0 * i for i in range(world)])))
+        if rank == 0:
+            print(json.dumps({"selftest": "launcher + batch shard + gather_logits over gloo", "n_gpus": world,
+                              "gathered_ok": ok}), flush=True)
+        if distributed:
+            dist.destroy_process_group()
+        sys.exit(0 if ok else 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
@@ -153,8 +253,22 @@ def main():
     pf = workload.Prefill(specs, device=dev, dtype=torch.float16, share_groups=not args.no_fuse)
     tokens_per_step = workload.M_LLM * args.batch if not args.tiny else specs[-1].M
 
-    logits_local = torch.zeros((1, VOCAB), dtype=torch.float16, device=dev)
-    logits_all = torch.zeros((world, VOCAB), dtype=torch.float16, device=dev) if distributed else None
+    # N > 1: sample i runs on rank i (one sample per rank and step); the exchanged tensor is the REAL
+    # last-token logits of this rank's sample from the whole synthetic prefill.  Static scales are
+    # replicated constants: every rank calibrates on sample 0 with the same seeds.
+    logits_local, logits_all, fp_logits = None, None, None
+    if distributed and not args.tiny:
+        from mquant_amd import shard
+        from mquant_amd.full_prefill import FullPrefill
+        fp_logits = FullPrefill(pf, fused_glue=True)
+        fp_logits.calibrate()
+        fp_logits.set_sample(rank)
+        logits_local = fp_logits.step().to(torch.float16).clone()
+        torch.cuda.synchronize(dev)
+    elif distributed:
+        logits_local = torch.full((1, VOCAB), float(rank), dtype=torch.float16, device=dev)
+    if distributed:
+        logits_all = torch.zeros((world, VOCAB), dtype=torch.float16, device=dev)
 
     def capture(fn):
         """Launch-bound inner loop -> one hipGraph (the kernels themselves are unchanged)."""
@@ -194,6 +308,20 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * tokens_per_step * args.steps / elapsed
 
+    logits_check = None
+    if distributed:
+        gathered = shard.gather_logits(logits_local, world) if not args.tiny else logits_all
+        torch.cuda.synchronize(dev)
+        if rank == 0 and fp_logits is not None:
+            # rank r's result for sample r must equal the single-GPU result for the same sample
+            same = []
+            for i in range(world):
+                fp_logits.set_sample(i)
+                ref = fp_logits.step().to(torch.float16)
+                same.append(bool(torch.equal(ref[0], gathered[i])))
+            logits_check = {"samples": world, "equal_to_single_gpu": all(same), "per_sample": same,
+                            "all_gather_bytes": int(world * VOCAB * 2)}
+
     # ---- kernel attribution: the GEMM launches of a step alone, HIP events on the launch stream
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = max(3, min(args.steps, 10))
@@ -214,20 +342,24 @@ def main():
     torch.cuda.synchronize(dev)
     quant_ms = e0.elapsed_time(e1) / reps
     launches = pf.gemm_launches()
-    traffic, traffic_note = None, "no profiles/r1_traffic.json"
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_traffic.json")
+    traffic, traffic_note, traffic_source = None, "no profiles/r2_traffic.json", None
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_traffic.json")
     if os.path.exists(tpath) and not args.tiny and args.batch == 1:
         # HBM bytes per GEMM launch from the PMC passes (tools/pmc_traffic.py); counters cannot be
-        # read inside the timed run, so this is the committed measurement of the same command
+        # read inside the timed run, so this is the committed measurement of the same command -- with
+        # the commit and command it was taken at, so that a stale file is detectable
         with open(tpath) as fh:
             tj = json.load(fh)
         traffic = tj["kernels"].get("gemm", {}).get("hbm_bytes_per_launch")
         traffic_note = tj["corrections"]
+        traffic_source = {"file": "profiles/r2_traffic.json", "measured_at_commit": tj.get("commit"),
+                          "command": tj.get("command")}
     achieved = pf.gemm_ops() / (gemm_ms * 1e-3) / 1e12
-    roofline = {"bound": "mfma", "kernel": "gemm_w4a8_kernel (V_MFMA_I32_16X16X64_I8)",
+    roofline = {"bound": "mfma", "kernel": "gemm_ws_kernel (V_MFMA_I32_32X32X32_I8) / gemm_w4a8_kernel 256x256 (V_MFMA_I32_16X16X64_I8)",
                 "achieved": round(achieved, 2), "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
                 "frac": round(achieved / PEAK_INT8_TOPS, 4), "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_note": traffic_note,
+                "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": round(pf.gemm_bytes() / launches),
                 "launches_per_step": launches,
                 "avg_launch_us": round(gemm_ms * 1e3 / launches, 3),
@@ -241,7 +373,9 @@ def main():
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int8",
-            "data": "synthetic (random weights with the real shapes, random activations with outlier channels)",
+            "data": "synthetic (random weights with the real shapes, all 327 weight images distinct = 3.65 GB streamed per step; "
+                    "random activations with outlier channels; layers of equal (M, k_in) read the SAME synthetic input tensor and "
+                    "share one output buffer, which flatters the caches slightly on the activation side)",
             "config": {"workload": "Qwen2-VL-7B W4A8 MSQ prefill, 1x448^2 image (1024 vision tokens) + "
                                    "512 text tokens, 327 wrapped Linears, M_llm=768" + ("" if args.batch == 1 else f", x{args.batch} samples per step (scaling study, not the benchmark configuration)") + ("" if args.no_fuse else " (q/k/v and gate/up share one quantization and one GEMM)") if not args.tiny
                        else "tiny debug shapes",
@@ -253,12 +387,18 @@ def main():
             "roofline": roofline}
     if not (args.tiny or args.no_full_prefill or args.no_fuse or args.batch != 1):
         line["full_prefill"] = full_prefill_report(pf, dev, args)
+    if logits_check is not None:
+        line["logits_check"] = logits_check
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            line["cpu_baseline"] = cpu_baseline(float(pf.gemm_ops()))
+            line["cpu_baseline"] = cpu_baseline_reference()
         except Exception as exc:  # the baseline is a report, never a reason to lose the line
-            line["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port",
+            line["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "reference",
                                     "sample": f"failed: {exc!r}"}
+        try:                      # second, labelled number: the C port of the integer path (oracle/mq_oracle.c)
+            line["cpu_baseline_port"] = cpu_baseline(float(pf.gemm_ops()))
+        except Exception as exc:
+            line["cpu_baseline_port"] = {"value": None, "kind": "port", "sample": f"failed: {exc!r}"}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if distributed:

@@ -67,11 +67,13 @@ class GPTQ:
         Q = torch.zeros_like(W)
         idx = torch.arange(self.columns, device=self.dev)
         H[idx, idx] += percdamp * torch.mean(torch.diag(H))
+        Hinv = torch.cholesky_inverse(torch.linalg.cholesky(H))   # a non-positive-definite Hessian raises, as upstream
         try:
-            Hinv = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H)), upper=True)
-        except Exception:   # not positive definite: plain RTN, as upstream
-            self.layer.weight.data = self.quantizer.quantize(W if perm is None else W[:, invperm]).to(
-                self.layer.weight.data.dtype)
+            Hinv = torch.linalg.cholesky(Hinv, upper=True)
+        except Exception:   # upstream guards only this last factorisation: fall back to plain RTN
+            logging.warning("GPTQ: upper Cholesky of the inverse Hessian failed, falling back to RTN")
+            Wq = self.quantizer.quantize(W if perm is None else W[:, invperm])
+            self.layer.weight.data = Wq.reshape(self.layer.weight.shape).to(self.layer.weight.data.dtype)
             return
         qz = self.quantizer
         fused = (self.use_kernel and W.is_cuda and groupsize == -1 and blocksize <= 128 and qz.sym

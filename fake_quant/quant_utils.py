@@ -422,6 +422,16 @@ class ActQuantWrapper(torch.nn.Module):
         if scale.numel() == 1:
             scale = scale.expand(W2.shape[0]).contiguous()
         levels = ops.weight_levels(W2, scale, wq.bits)
+        # the attached quantizer must be the one that produced these weights (one scale per output
+        # channel): levels * scale has to give the stored fake-quantized weight back, else the wrapper
+        # would silently run on a different integer grid (e.g. a group-wise GPTQ quantizer that only
+        # remembers its last column group)
+        back = (levels.float() * scale[:, None]).to(W2.dtype)
+        if not torch.equal(back, W2):
+            bad = float((back.float() - W2.float()).abs().max())
+            raise RuntimeError(f"ActQuantWrapper: weights of '{name}' are not on the attached quantizer's grid "
+                               f"(max deviation {bad:.3g}); refusing to build the integer backend")
+        del back
         w0 = None
         bias = wmod.bias
         if self.split:
@@ -465,7 +475,10 @@ class ActQuantWrapper(torch.nn.Module):
     def _rotate(self, x, x_dtype):
         if self.pad_to is not None and x.shape[-1] < self.pad_to:
             x = torch.nn.functional.pad(x, (0, self.pad_to - x.shape[-1]))
-        if self.online_full_had:
+        if self.online_full_had and not x.is_cuda and getattr(self, "simulate_on_cpu", False):
+            # cpu_baseline opt-in: the reference's own CPU operator (hadamard_utils.py:79-100)
+            x = hadamard_utils.matmul_hadU(x.float() if self.fp32_had else x).to(x_dtype)
+        elif self.online_full_had:
             if self.fp32_had:
                 x = hadamard_utils.matmul_hadU_cuda(x.float(), self.had_K, self.K).to(x_dtype)
             else:
@@ -496,7 +509,9 @@ class ActQuantWrapper(torch.nn.Module):
         if self._real_ready(x):
             return self._forward_real(x)
         qz = self.quantizer
-        if qz.static and qz.quant and not x.is_cuda:
+        if qz.static and qz.quant and not x.is_cuda and not getattr(self, "simulate_on_cpu", False):
+            # There is no CPU fallback.  ``simulate_on_cpu`` is an explicit opt-in used by bench.py's
+            # cpu_baseline only: it times the reference's own simulated evaluation on the host cores.
             from mquant_amd._lib import MQuantHipError
             raise MQuantHipError("ActQuantWrapper: static quantized forward needs a CUDA tensor "
                                  "(no CPU fallback)")

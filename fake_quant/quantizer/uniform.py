@@ -18,6 +18,14 @@ class UniformQuantizer(BaseQuantizer):
 
     def update_quantization_params(self, *args, **kwargs):
         self.scale, self.zero_point = self.observer.get_quantization_params(*args, **kwargs)
+        self._cache_host_params()
+
+    def _cache_host_params(self):
+        """Host copies of what the fused kernel needs, taken ONCE per parameter update: reading them on
+        every forward would be a device->host sync per call (and breaks hipGraph capture)."""
+        self._cached_for = (self.scale, self.zero_point)
+        self._zp_is_zero = self.zero_point is None or not bool(torch.any(self.zero_point != 0))
+        self._scale_host = float(self.scale) if (self.scale is not None and self.scale.numel() == 1) else None
 
     def _params(self, inputs, scale, zero_point):
         scale = self.scale if scale is None else scale
@@ -35,16 +43,20 @@ class UniformQuantizer(BaseQuantizer):
         return (inputs - z) * s
 
     def _fused_ok(self, x):
-        return (x.is_cuda and self.module_type == "activation" and x.dim() in (2, 3)
+        if not (x.is_cuda and self.module_type == "activation" and x.dim() in (2, 3)
                 and x.dtype in (torch.float16, torch.bfloat16, torch.float32)
-                and self.bit_type.bits == 8 and self.bit_type.signed
-                and self.scale is not None and not bool(torch.any(self.zero_point != 0)))
+                and self.bit_type.bits == 8 and self.bit_type.signed and self.scale is not None):
+            return False
+        if getattr(self, "_cached_for", None) is None or self._cached_for[0] is not self.scale \
+                or self._cached_for[1] is not self.zero_point:
+            self._cache_host_params()          # parameters assigned directly (checkpoints, tests)
+        return self._zp_is_zero
 
     def forward(self, inputs):
         if self._fused_ok(inputs):
             from mquant_amd import ops
             if self.scale.numel() == 1:
-                return ops.fakequant_act(inputs, float(self.scale))
+                return ops.fakequant_act(inputs, self._scale_host)
             vec = self.scale.reshape(-1).to(device=inputs.device, dtype=torch.float32).contiguous()
             return ops.fakequant_act(inputs, scale_vec0=vec)
         return super().forward(inputs)

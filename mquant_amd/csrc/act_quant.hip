@@ -17,11 +17,21 @@ __global__ __launch_bounds__(256) void act_quant_kernel(
 {
     typedef typename Elem<DT>::T T;
     const long chunks_per_row = K_pad / 16;
-    const long total = M * chunks_per_row;
+    const long total = (!DEQUANT && ldo == MQ_LD_TILED) ? ((M + 15) / 16) * 16 * chunks_per_row : M * chunks_per_row;
     for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < total;
          c += (long)gridDim.x * blockDim.x) {
         long row, col;
-        if (total < (1L << 31)) {                // 32-bit divide: a 64-bit one costs ~100 cycles per thread
+        if (!DEQUANT && ldo == MQ_LD_TILED) {
+            // tiled output: a wave writes ONE contiguous 1 KiB piece (16 rows x 64 channels, lane =
+            // 16 chunk + row) instead of 64 chunks scattered over 16 pieces; its reads become a
+            // 16-row gather of 128-byte segments
+            const unsigned piece = (unsigned)(c >> 6), kts = (unsigned)(K_pad >> 6);   // < 2^31 pieces (checked by the launcher)
+            const int l = (int)(c & 63);
+            const unsigned mt = piece / kts;             // uniform per wave
+            row = (long)mt * 16 + (l & 15);
+            col = (long)(piece - mt * kts) * 64 + (l >> 4) * 16;
+            if (row >= M) continue;
+        } else if (total < (1L << 31)) {                // 32-bit divide: a 64-bit one costs ~100 cycles per thread
             const unsigned r32 = (unsigned)c / (unsigned)chunks_per_row;
             row = r32;
             col = (long)((unsigned)c - r32 * (unsigned)chunks_per_row) * 16;
@@ -97,7 +107,7 @@ static int launch_act_quant(const void *x, long M, long K, long ldx, float scale
                             hipStream_t st)
 {
     typedef typename Elem<DT>::T T;
-    const long total = M * (K_pad / 16);
+    const long total = ((!DEQUANT && ldo == MQ_LD_TILED) ? ((M + 15) / 16) * 16 : M) * (K_pad / 16);
     if (total == 0) return MQ_OK;
     const int vec_ok = (((uintptr_t)x) % 16 == 0) && ((ldx * (long)sizeof(T)) % 16 == 0);
     long blocks = ceil_div(total, 256);

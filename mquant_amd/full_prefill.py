@@ -39,7 +39,7 @@ def _rope(x, cos, sin):
 
 
 class FullPrefill:
-    def __init__(self, pf: Prefill, seed: int = 7, fused_glue: bool = True):
+    def __init__(self, pf: Prefill, seed: int = 7, fused_glue: bool = True, sample: int = 0):
         #: norm -> quantize and activation -> Hadamard -> quantize as single launches
         self.fused_glue = fused_glue
         assert pf.share_groups, "the chained prefill uses the fused q/k/v and gate/up GEMMs"
@@ -52,13 +52,28 @@ class FullPrefill:
         rnd = lambda *shape, std=1.0: (torch.randn(shape, generator=g, device=self.dev) * std).to(self.dtype)
         self.patches = rnd(M_VIS, 1176)
         self.text_embeds = rnd(M_TXT, LLM_DIM)
-        self.lm_head = rnd(VOCAB, LLM_DIM, std=0.02)
+        self.lm_head = rnd(VOCAB, LLM_DIM, std=0.02)             # a weight: the same for every sample
+        self.sample = sample
+        if sample:
+            self.set_sample(sample)
         self.vcos, self.vsin = _rope_tables(M_VIS, VIS_DIM // VIS_HEADS, self.dev, self.dtype)
         self.lcos, self.lsin = _rope_tables(M_MERGED + M_TXT, HEAD_DIM, self.dev, self.dtype, 1e6)
         self.vcos2, self.vsin2 = self.vcos[:, 0].contiguous(), self.vsin[:, 0].contiguous()     # [T, d] for the kernel
         self.lcos2, self.lsin2 = self.lcos[:, 0].contiguous(), self.lsin[:, 0].contiguous()
         self.calibrating = False
         self.logits = None
+
+    def set_sample(self, sample: int) -> None:
+        """Inputs of image+prompt ``sample`` (batch sharding: sample i runs on rank i % world).  Sample 0
+        is the calibration sample; weights and static scales do not depend on the sample."""
+        g = torch.Generator(device=self.dev).manual_seed(104729 + 7919 * sample)
+        rnd = lambda *shape: torch.randn(shape, generator=g, device=self.dev).to(self.dtype)
+        if sample == 0:
+            g0 = torch.Generator(device=self.dev).manual_seed(7)
+            rnd = lambda *shape: torch.randn(shape, generator=g0, device=self.dev).to(self.dtype)
+        self.patches = rnd(M_VIS, 1176)
+        self.text_embeds = rnd(M_TXT, LLM_DIM)
+        self.sample = sample
 
     # -- one wrapped Linear (or fused group) -----------------------------------------------
     def _lin(self, L: Layer, x: torch.Tensor, residual: torch.Tensor = None) -> torch.Tensor:

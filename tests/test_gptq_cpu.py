@@ -271,3 +271,26 @@ def test_minicpmv_driver_walks_the_expected_modules():
     assert {"model.vpm.embeddings.patch_embedding", "model.vpm.encoder.layers.0.self_attn.out_proj.module",
             "model.resampler.proj_fc.module", "model.llm.model.layers.1.mlp.down_proj.module"} <= set(q)
     assert all(_on_grid(w.module.weight.data, w.weight_quantizers["module"]) for w in wrappers.values())
+
+
+def _llm_wrappers_after_gptq(**over):
+    from fake_quant import gptq, quant_utils as qu
+    vlm = ToyVlm("qwen2vl")
+    args = gptq_args(quant_visual_clip=False, quant_cross_attention=False, **over)
+    qu.qwen2vl_add_act_qaunt(vlm, args)
+    q = gptq.qwen2vl_rtn_gptq_fwrd_plus(vlm, ToyDataset(4), "cpu", "toy", args)   # the name exam/quant_qwen2vl.py calls
+    assert q
+    wrappers = qu.find_qlayers(vlm.model, [qu.ActQuantWrapper])
+    llm = [w for n, w in wrappers.items() if ".layers." in n]
+    assert llm
+    return llm
+
+
+def test_group_wise_gptq_does_not_attach_a_partial_quantizer():
+    """--w_groupsize > 0 with static_groups=False leaves a quantizer that only remembers its LAST column
+    group: the wrappers must not get it (they would rebuild integer levels on the wrong grid)."""
+    assert all(not w.weight_quantizers for w in _llm_wrappers_after_gptq(w_groupsize=8))
+
+
+def test_per_channel_gptq_still_attaches():
+    assert all(w.weight_quantizers for w in _llm_wrappers_after_gptq())
