@@ -426,12 +426,12 @@ class ActQuantWrapper(torch.nn.Module):
         # channel): levels * scale has to give the stored fake-quantized weight back, else the wrapper
         # would silently run on a different integer grid (e.g. a group-wise GPTQ quantizer that only
         # remembers its last column group)
-        back = (levels.float() * scale[:, None]).to(W2.dtype)
-        if not torch.equal(back, W2):
-            bad = float((back.float() - W2.float()).abs().max())
+        # (any weight is within half a step of SOME level, so the test is the MEAN distance: ~0.25 steps for
+        # a foreign grid, at most a few 1e-2 for half-precision roundings of scale * level, 0 in fp32)
+        dev_steps = ((levels.float() * scale[:, None] - W2.float()).abs() / scale[:, None]).mean()
+        if float(dev_steps) > 0.12:
             raise RuntimeError(f"ActQuantWrapper: weights of '{name}' are not on the attached quantizer's grid "
-                               f"(max deviation {bad:.3g}); refusing to build the integer backend")
-        del back
+                               f"(mean distance {float(dev_steps):.3g} quantization steps); refusing to build the integer backend")
         w0 = None
         bias = wmod.bias
         if self.split:
