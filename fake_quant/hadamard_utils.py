@@ -72,13 +72,18 @@ def sign_words(had: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(packed).view("<u4").reshape(K, wpr)
 
 
-def had_sign_bits(K: int, device) -> torch.Tensor:
-    """Word-aligned sign rows of hadK (see ``sign_words``) on ``device``, cached."""
+def had_sign_bits(K: int, device, prepared: bool = True) -> torch.Tensor:
+    """Sign rows of hadK on ``device``, cached: by default the PREPARED descriptor (int64 tensor: the
+    word-aligned sign rows of ``sign_words`` followed by the MFMA lane masks, built once by
+    ``mq_hadamard_prepare``); ``prepared=False`` gives the plain int32 words of the C ABI."""
     device = torch.device(device)
-    key = (K, device.type, device.index)
+    key = (K, device.type, device.index, bool(prepared and device.type == "cuda"))
     t = _BITS_CACHE.get(key)
     if t is None:
         t = torch.from_numpy(sign_words(_had_np(K)).view(np.int32).copy()).to(device)
+        if key[3]:
+            from mquant_amd import ops
+            t = ops.hadamard_prepare(t, K)
         _BITS_CACHE[key] = t
     return t
 
@@ -151,7 +156,11 @@ def _bits_for(hadK, K: int, device):
                         np.array_equal(np.sign(hadK.detach().cpu().float().numpy()), ref)):
         return had_sign_bits(K, device)
     words = sign_words(hadK.detach().cpu().float().numpy())
-    return torch.from_numpy(words.view(np.int32).copy()).to(device)
+    t = torch.from_numpy(words.view(np.int32).copy()).to(device)
+    if t.is_cuda:
+        from mquant_amd import ops
+        t = ops.hadamard_prepare(t, K)
+    return t
 
 
 def _hadamard_torch(X: torch.Tensor, hadK, K: int) -> torch.Tensor:

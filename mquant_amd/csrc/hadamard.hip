@@ -33,6 +33,9 @@ struct HadArgs {
     long M, n_in, ldx, n;
     int K, m;
     const uint8_t *had_bits;
+    const unsigned long long *masks = nullptr;   // prepared descriptor (mq_hadamard_prepare): lane masks of the sign operand
+    int unit_j = 1, unit_g = 4;                  // K x K stage: a wave owns unit_j 16-row tiles x unit_g 16-column tiles
+    int stagger = 0;                             // cycles by which the 2nd, 3rd ... workgroup of a CU starts late
     int fp32_had;
     void *out;
     long ldo;
@@ -50,6 +53,8 @@ struct HadArgs {
     int y_bytes;       // LDS bytes of the staged row
 };
 
+
+static int g_had_stagger = 0;   // tuning hook (measured slower in every setting): 0 = off, -1 = one K x K stage, > 0 = cycles
 
 // storage of the staged row in LDS: 16-bit when the values are exactly half-precision
 template <int DT, bool HALF_LDS> struct Stage;
@@ -117,7 +122,109 @@ __device__ __forceinline__ void had_emit4(const HadArgs &p, long row, long col, 
     }
 }
 
-template <int DT, bool QUANT, bool HALF_LDS, int THREADS, bool ACT = false>
+// two adjacent columns col, col+1 of one row (col even)
+template <int DT, bool QUANT>
+__device__ __forceinline__ void had_emit2(const HadArgs &p, long row, long col, const float v[2], float s)
+{
+    float r[2];
+    int q[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) q[e] = had_finish<DT, QUANT>(p, row, col + e, v[e], s, &r[e]);
+    if (QUANT) {
+        *reinterpret_cast<unsigned short *>(p.qout + act_offset(row, col, p.K_pad, p.ldq)) =
+            (unsigned short)((q[0] & 0xff) | ((q[1] & 0xff) << 8));
+    } else {
+        typedef typename Elem<DT>::T T;
+        T *o = reinterpret_cast<T *>(p.out) + row * p.ldo + col;
+        o[0] = Elem<DT>::st(r[0]);
+        o[1] = Elem<DT>::st(r[1]);
+    }
+}
+
+// K x K stage for one unit of UJ 16-row tiles x UG 16-column tiles, sign operands from the prepared
+// lane masks: per 4-wide k-step UJ v_cndmask (the +-1.0f operand of a 16-row tile: ONE VALU op, the
+// 64-bit lane mask arrives by scalar load), UG fp16->fp32 conversions of the staged row and UJ*UG
+// V_MFMA_F32_16X16X4_F32.  The fp32 MFMA shares the vector ALU's datapath, so every VALU instruction
+// beside it is lost matrix time: the round-1 form (one tile x four column tiles, three VALU ops per
+// sign operand) spent 8 VALU per 4 MFMAs, a 5 x 2 unit spends 7 per 10.
+template <int DT, bool QUANT, bool HALF_LDS, int UJ, int UG>
+__device__ __forceinline__ void had_kxk_unit(const HadArgs &p, long row, float s, const char *ybase, int row_bytes, int swz,
+                                             int jg, int cg, int lane)
+{
+    typedef Stage<DT, HALF_LDS> S;
+    typedef typename S::T YT;
+    constexpr int ESZ = (int)sizeof(YT);
+    const int K = p.K, m = p.m, ksteps = K / 4, JT = (K + 15) / 16;
+    const int lc = lane & 15, lk = lane >> 4;
+    jg = __builtin_amdgcn_readfirstlane(jg);        // wave-uniform: the mask loads below become scalar loads
+    cg = __builtin_amdgcn_readfirstlane(cg);
+    v4f acc[UJ][UG];
+    float posv[UJ], negv[UJ];
+#pragma unroll
+    for (int jj = 0; jj < UJ; ++jj) {
+        const int j = (jg * UJ + jj) * 16 + lc;
+        posv[jj] = j < K ? 1.0f : 0.0f;            // rows past K contribute nothing (their outputs are never stored)
+        negv[jj] = j < K ? -1.0f : 0.0f;
+#pragma unroll
+        for (int g = 0; g < UG; ++g) acc[jj][g] = v4f{0.f, 0.f, 0.f, 0.f};
+    }
+    const int col0 = cg * (16 * UG) + UG * lc;      // this lane's UG adjacent columns
+    int c0 = col0 * ESZ;
+    if (swz) c0 ^= (lk & 1) << 7;                   // k = 4 t + lk: the row swizzle is a per-lane constant
+    const char *yp = ybase + lk * row_bytes + c0;
+    const int kstride = 4 * row_bytes;
+    typedef const __attribute__((address_space(4))) unsigned long long cmask_t;
+    // masks[t][jt] (JT tiles per k-step, contiguous): the unit's UJ masks of a step are adjacent; tiles past
+    // JT alias the last one (posv = negv = 0 there)
+    int jts[UJ];
+#pragma unroll
+    for (int jj = 0; jj < UJ; ++jj) jts[jj] = (jg * UJ + jj < JT) ? jg * UJ + jj : JT - 1;
+    // (fetching the masks / staged values of step t+1 during step t was measured slower: the register
+    // copies are VALU work too, and VALU work is what this kernel is bound by -- DESIGN 4.2)
+    for (int t = 0; t < ksteps; ++t) {
+        const char *src = yp + t * kstride;
+        float b[UG];
+        if (HALF_LDS) {
+            if (UG == 2) {
+                const unsigned hv = *reinterpret_cast<const unsigned *>(src);
+                b[0] = S::ld((YT)(hv & 0xffff));
+                b[1] = S::ld((YT)(hv >> 16));
+            } else {
+                const v4us hv = *reinterpret_cast<const v4us *>(src);
+#pragma unroll
+                for (int g = 0; g < UG; ++g) b[g] = S::ld((YT)hv[g]);
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < UG; ++g) b[g] = *reinterpret_cast<const float *>(src + 4 * g);
+        }
+#pragma unroll
+        for (int jj = 0; jj < UJ; ++jj) {
+            const unsigned long long mask = ((cmask_t *)(p.masks))[(long)t * JT + jts[jj]];   // scalar load
+            // lane l: bit l set <=> hadK[16 jt + (l & 15)][4 t + (l >> 4)] == -1; one v_cndmask with the SGPR pair
+            const float a = __builtin_amdgcn_inverse_ballot_w64(mask) ? negv[jj] : posv[jj];
+#pragma unroll
+            for (int g = 0; g < UG; ++g) acc[jj][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[g], acc[jj][g], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int jj = 0; jj < UJ; ++jj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = (jg * UJ + jj) * 16 + lk * 4 + r;
+            if (j < K) {
+                if (UG == 4) {
+                    const float v4[4] = {acc[jj][0][r], acc[jj][1][r], acc[jj][2][r], acc[jj][3][r]};
+                    had_emit4<DT, QUANT>(p, row, (long)j * m + col0, v4, s, (p.ldq & 3) == 0);
+                } else {
+                    const float v2[2] = {acc[jj][0][r], acc[jj][1][r]};
+                    had_emit2<DT, QUANT>(p, row, (long)j * m + col0, v2, s);
+                }
+            }
+        }
+}
+
+template <int DT, bool QUANT, bool HALF_LDS, int THREADS, bool ACT = false, int UNIT = 0>
 __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
 {
     constexpr int HAD_THREADS = THREADS;
@@ -154,6 +261,15 @@ __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
         for (int t = tid; t < K * WPR; t += THREADS) hw[t] = gw[t];
     }
 
+    // The workgroups that share a CU would otherwise march through load -> K x K stage -> store in
+    // lockstep (all waiting for HBM, then all queueing for the fp32 MFMA, then all storing): the 2nd and
+    // 3rd resident workgroup of a CU start one K x K stage later each, so that one workgroup's matrix
+    // phase covers its neighbours' memory phases.  Block b is expected in slot b / 256 of its CU (the
+    // dispatcher fills the 256 CUs round-robin); a different placement only changes the timing.
+    if (p.stagger > 0 && blockIdx.x >= 256) {
+        const long long until = clock64() + (long long)(blockIdx.x >> 8) * p.stagger;
+        while (clock64() < until) __builtin_amdgcn_s_sleep(32);
+    }
     // tiled int8 output: the 16 rows of a piece row are handled on one XCD (tiled_row_of, mq_common.h)
     const bool remap = QUANT && p.ldq == MQ_LD_TILED && (gridDim.x & 7) == 0;
     const long v_end = remap ? ceil_div(p.M, 128) * 128 : p.M;
@@ -308,6 +424,14 @@ __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
                         had_emit1<DT, QUANT>(p, row, idx + i,
                                              S::ld(*reinterpret_cast<const YT *>(ybase + yoff(0, (int)(idx + i)))), s);
             }
+        } else if (UNIT == 5) {
+            // prepared descriptor: mask-driven 5 x 2 units (had_kxk_unit), one unit per wave for K = 156, m = 128.
+            // Its own instantiation: the 40 accumulator registers must not raise the register count (and lower
+            // the occupancy) of the shapes that take the classic path below.
+            const int JT = (K + 15) / 16;
+            const int JG = (JT + 4) / 5, CG = m / 32;
+            for (int u = wave; u < JG * CG; u += HAD_WAVES)
+                had_kxk_unit<DT, QUANT, HALF_LDS, 5, 2>(p, row, s, ybase, row_bytes, swz, u / CG, u % CG, lane);
         } else if (m >= 64) {
             const int JT = (K + 15) / 16;
             const int CG = m / 64;
@@ -385,7 +509,7 @@ __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
     }
 }
 
-template <int DT, bool QUANT, bool HALF_LDS, int THREADS, bool ACT = false>
+template <int DT, bool QUANT, bool HALF_LDS, int THREADS, bool ACT = false, int UNIT = 0>
 static int launch_hadamard_t(HadArgs p, hipStream_t st)
 {
     const int esz = HALF_LDS ? 2 : 4;
@@ -396,7 +520,7 @@ static int launch_hadamard_t(HadArgs p, hipStream_t st)
     const size_t wpr = (p.K + 31) / 32;
     const size_t lds = (size_t)p.y_bytes + (p.K > 1 ? (size_t)p.K * wpr * 4 : 0);
     if (lds > 160 * 1024) return fail(MQ_EUNSUPPORTED, "mq_hadamard: n=%ld needs %zu B of LDS (> 160 KiB)", p.n, lds);
-    auto kern = hadamard_kernel<DT, QUANT, HALF_LDS, THREADS, ACT>;
+    auto kern = hadamard_kernel<DT, QUANT, HALF_LDS, THREADS, ACT, UNIT>;
     {   // per device and instantiation; the first call of a shape happens outside any stream capture
         const int rc = ensure_dynamic_lds((const void *)kern, 160 * 1024);
         if (rc != MQ_OK) return rc;
@@ -407,8 +531,34 @@ static int launch_hadamard_t(HadArgs p, hipStream_t st)
     long blocks = 256L * per_cu;
     if (blocks > p.M) blocks = p.M;
     if (QUANT && p.ldq == MQ_LD_TILED) blocks = ceil_div(blocks, 8) * 8;   // XCD-consistent row map (tiled_row_of)
+    p.stagger = 0;
+    if (p.K > 1 && p.m >= 64 && blocks > 256 && blocks <= 256 * per_cu && g_had_stagger != 0) {
+        // K x K stage of one row with the CU's matrix cores to itself: MFMAs per SIMD x 32 cycles
+        const long mfmas = (long)(p.K / 4) * ((p.K + 15) / 16) * (p.m / 16);
+        const long cyc = mfmas / 4 * 32;
+        p.stagger = (int)(g_had_stagger > 0 ? g_had_stagger : cyc);
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), lds, st, p);
     return check_launch("hadamard");
+}
+
+// Prepared descriptor: [K][ceil(K/32)] sign words (as passed to mq_hadamard*) followed, 8-byte aligned, by
+// the lane masks of the MFMA sign operand: masks[t][jt] for t < K/4, jt < ceil(K/16), bit l set when
+// hadK[16 jt + (l & 15)][4 t + (l >> 4)] == -1 (rows >= K: 0).
+__global__ __launch_bounds__(64) void hadamard_prepare_kernel(const unsigned *words, int K, unsigned *out_words,
+                                                                unsigned long long *out_masks)
+{
+    const int WPR = (K + 31) / 32, ksteps = K / 4;
+    const int lane = threadIdx.x;
+    for (int i = blockIdx.x * 64 + lane; i < K * WPR; i += gridDim.x * 64) out_words[i] = words[i];
+    const int JT = (K + 15) / 16;
+    for (int u = blockIdx.x; u < JT * ksteps; u += gridDim.x) {
+        const int t = u / JT, jt = u - t * JT;                      // masks[t][jt]
+        const int j = jt * 16 + (lane & 15), k = 4 * t + (lane >> 4);
+        const bool neg = j < K && ((words[j * WPR + (k >> 5)] >> (k & 31)) & 1u) == 0;   // bit set = +1
+        const unsigned long long mask = __ballot(neg);
+        if (lane == 0) out_masks[u] = mask;
+    }
 }
 
 static int g_had_threads = 0;   // 0: choose by shape
@@ -418,12 +568,20 @@ static int launch_hadamard(const HadArgs &p, hipStream_t st)
 {
     // 8 waves per row pay off once the K x K stage has enough (16 rows x 64 columns) units to
     // keep them busy (down_proj: 10 x 2 = 20 units; measured 83 -> 76 us), else 4 waves
-    const int units = (p.K > 1 && p.m >= 64) ? ((p.K + 15) / 16) * (p.m / 64) : 0;
-    const int threads = g_had_threads ? g_had_threads : (units >= 16 ? 512 : 256);
+    int units = (p.K > 1 && p.m >= 64) ? ((p.K + 15) / 16) * (p.m / 64) : 0;
+    int threads = g_had_threads ? g_had_threads : (units >= 16 ? 512 : 256);
+    if (p.masks && p.K > 1 && p.m >= 64) {          // mask-driven units: one unit per wave where possible
+        const int JT = (p.K + 15) / 16;
+        units = p.unit_j == 5 ? ((JT + 4) / 5) * (p.m / 32) : p.unit_j == 3 ? ((JT + 2) / 3) * (p.m / 32) : JT * (p.m / 64);
+        if (!g_had_threads) threads = units >= 8 ? 512 : 256;
+    }
+    const bool unit5 = p.masks && p.unit_j == 5 && threads == 512;
     if (QUANT && p.act != MQ_ACT_NONE) {
+        if (unit5) return launch_hadamard_t<DT, QUANT, HALF_LDS, 512, QUANT, 5>(p, st);
         if (threads == 512) return launch_hadamard_t<DT, QUANT, HALF_LDS, 512, QUANT>(p, st);
         return launch_hadamard_t<DT, QUANT, HALF_LDS, 256, QUANT>(p, st);
     }
+    if (unit5) return launch_hadamard_t<DT, QUANT, HALF_LDS, 512, false, 5>(p, st);
     if (threads == 512) return launch_hadamard_t<DT, QUANT, HALF_LDS, 512>(p, st);
     return launch_hadamard_t<DT, QUANT, HALF_LDS, 256>(p, st);
 }
@@ -447,6 +605,25 @@ static int hadamard_common(HadArgs p, int x_dtype, bool quant, void *stream)
     p.inv_sqrt_n = 1.0f / sqrtf((float)p.n);
     MQ_REQUIRE((p.m & (p.m - 1)) == 0, "mq_hadamard: n/K=%d is not a power of two", p.m);
     MQ_REQUIRE(p.K == 1 || (p.K % 4 == 0 && p.had_bits && ((uintptr_t)p.had_bits) % 4 == 0), "mq_hadamard: K=%d needs 4-byte aligned had_words and K %% 4 == 0", p.K);
+    // fp32_had carries flags: bit 0 = --fp32_had, bit 1 = had_words is a prepared descriptor (mq_hadamard_prepare)
+    const bool prepared = (p.fp32_had & MQ_HAD_PREPARED) != 0;
+    p.fp32_had &= MQ_HAD_FP32;
+    p.masks = nullptr;
+    p.unit_j = 1; p.unit_g = 4;
+    if (prepared && p.K > 1) {
+        MQ_REQUIRE(((uintptr_t)p.had_bits) % 8 == 0, "mq_hadamard: a prepared descriptor is 8-byte aligned");
+        const size_t words_bytes = ((size_t)p.K * ((p.K + 31) / 32) * 4 + 7) / 8 * 8;
+        p.masks = reinterpret_cast<const unsigned long long *>(p.had_bits + words_bytes);
+        const int JT = (p.K + 15) / 16;
+        // measured (profiles/r2_hadamard.txt): the 5 x 2 units pay off for the large factors (K = 140 / 156 /
+        // 172, down_proj 76 -> 72 us); for small K the round-1 form (one tile x four column tiles) is faster
+        if (p.m >= 64 && p.m % 32 == 0 && JT >= 8) {
+            p.unit_j = 5;
+            p.unit_g = 2;
+        } else {
+            p.masks = nullptr;
+        }
+    }
     MQ_REQUIRE(p.ldx >= p.n_in, "mq_hadamard: ldx < n_in");
     const size_t esz = (x_dtype == MQ_F32) ? 4 : 2;
     p.vec_ok = (((uintptr_t)p.x) % 16 == 0) && ((p.ldx * esz) % 16 == 0);
@@ -474,9 +651,33 @@ static int hadamard_common(HadArgs p, int x_dtype, bool quant, void *stream)
 
 }  // namespace mq
 
+extern "C" size_t mq_hadamard_prepared_bytes(int K)
+{
+    if (K <= 1 || K % 4 != 0) return 0;
+    const size_t words_bytes = ((size_t)K * ((K + 31) / 32) * 4 + 7) / 8 * 8;
+    return words_bytes + (size_t)((K + 15) / 16) * (K / 4) * 8;
+}
+
+extern "C" int mq_hadamard_prepare(const uint32_t *had_words, int K, void *descriptor, void *stream)
+{
+    using namespace mq;
+    MQ_REQUIRE(K > 1 && K % 4 == 0 && had_words && descriptor, "mq_hadamard_prepare: K=%d must be a multiple of 4 (> 1), buffers non-null", K);
+    MQ_REQUIRE(((uintptr_t)descriptor) % 8 == 0 && ((uintptr_t)had_words) % 4 == 0, "mq_hadamard_prepare: alignment");
+    const size_t words_bytes = ((size_t)K * ((K + 31) / 32) * 4 + 7) / 8 * 8;
+    hipLaunchKernelGGL(hadamard_prepare_kernel, dim3(64), dim3(64), 0, (hipStream_t)stream, had_words, K,
+                       reinterpret_cast<unsigned *>(descriptor),
+                       reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(descriptor) + words_bytes));
+    return check_launch("hadamard_prepare");
+}
+
 extern "C" int mq_hadamard_debug_threads(int threads)
 {
-    mq::g_had_threads = (threads == 512 || threads == 256) ? threads : 0;
+    // 256 / 512: threads per row; 0: by shape; negative values tune the workgroup stagger:
+    // -1 = default (one K x K stage), -2 = off, -(1000 + c) = c cycles
+    if (threads <= -1000) mq::g_had_stagger = -threads - 1000;
+    else if (threads == -2) mq::g_had_stagger = 0;
+    else if (threads == -1) mq::g_had_stagger = -1;
+    else mq::g_had_threads = (threads == 512 || threads == 256) ? threads : 0;
     return MQ_OK;
 }
 

@@ -198,6 +198,26 @@ def fakequant_act(x: torch.Tensor, scale0: float = 1.0, scale1: Optional[float] 
 
 
 # --------------------------------------------------------------------------- Hadamard
+HAD_FP32, HAD_PREPARED = 1, 2      # include/mquant_hip.h MQ_HAD_*
+
+
+@_on_device
+def hadamard_prepare(words: torch.Tensor, K: int) -> torch.Tensor:
+    """Sign words [K, ceil(K/32)] (int32) -> prepared descriptor (``mq_hadamard_prepare``): the words plus
+    the 64-lane masks of the MFMA sign operand.  Returned as an int64 tensor; every Hadamard op below
+    recognises it by that dtype and sets MQ_HAD_PREPARED.  Results are identical, the K x K stage is faster."""
+    _need_cuda(words)
+    assert words.dtype == torch.int32 and words.is_contiguous()
+    nbytes = _lib.load().mq_hadamard_prepared_bytes(K)
+    out = torch.zeros((nbytes // 8,), dtype=torch.int64, device=words.device)
+    call("mq_hadamard_prepare", words.data_ptr(), K, out.data_ptr(), _stream())
+    return out
+
+
+def _had_flags(had_bits: Optional[torch.Tensor], fp32_had: bool) -> int:
+    return (HAD_FP32 if fp32_had else 0) | (HAD_PREPARED if had_bits is not None and had_bits.dtype == torch.int64 else 0)
+
+
 @_on_device
 def hadamard(x: torch.Tensor, n: int, K: int, had_bits: Optional[torch.Tensor],
              fp32_had: bool = False) -> torch.Tensor:
@@ -207,7 +227,7 @@ def hadamard(x: torch.Tensor, n: int, K: int, had_bits: Optional[torch.Tensor],
     M, n_in = x2.shape
     out = torch.empty((M, n), dtype=x.dtype, device=x.device)
     call("mq_hadamard", x2.data_ptr(), dtype_code(x2.dtype), M, n_in, x2.stride(0), n, K,
-         _ptr(had_bits), int(fp32_had), out.data_ptr(), out.stride(0), _stream())
+         _ptr(had_bits), _had_flags(had_bits, fp32_had), out.data_ptr(), out.stride(0), _stream())
     return out.reshape(*x.shape[:-1], n)
 
 
@@ -223,7 +243,7 @@ def hadamard_quant_i8(x: torch.Tensor, n: int, K: int, had_bits: Optional[torch.
     if skip_col0 and x0_out is None:
         x0_out = torch.empty((M,), dtype=torch.float32, device=x.device)
     call("mq_hadamard_quant_i8", x2.data_ptr(), dtype_code(x2.dtype), M, n_in, x2.stride(0), n, K,
-         _ptr(had_bits), int(fp32_had), float(scale0), float(scale0 if scale1 is None else scale1),
+         _ptr(had_bits), _had_flags(had_bits, fp32_had), float(scale0), float(scale0 if scale1 is None else scale1),
          _ptr(row_sel), int(skip_col0), _ptr(x0_out), optr, K_pad, ldo, _stream())
     return out, x0_out
 
@@ -261,7 +281,7 @@ def act_hadamard_quant_i8(x: torch.Tensor, x2: Optional[torch.Tensor], act: int,
     if skip_col0 and x0_out is None:
         x0_out = torch.empty((M,), dtype=torch.float32, device=x.device)
     call("mq_act_hadamard_quant_i8", a.data_ptr(), _ptr(b), int(act), dtype_code(a.dtype), M, n_in, a.stride(0),
-         n, K, _ptr(had_bits), int(fp32_had), float(scale0), float(scale0 if scale1 is None else scale1),
+         n, K, _ptr(had_bits), _had_flags(had_bits, fp32_had), float(scale0), float(scale0 if scale1 is None else scale1),
          _ptr(row_sel), int(skip_col0), _ptr(x0_out), optr, K_pad, ldo, _stream())
     return out, x0_out
 

@@ -251,3 +251,37 @@ def test_engine_uses_the_tiled_layout_end_to_end(had_table):
     a, _ = lin.quantize(x)
     assert isinstance(a, o.TiledAct)
     np.testing.assert_array_equal(a.to_rows().cpu().numpy()[:, :n], q_ref)
+
+
+# ------------------------------------------------------------------- prepared Hadamard descriptor
+@pytest.mark.parametrize("n_in,n,K", [(18944, 19968, 156), (5120, 5120, 40), (11008, 11008, 172), (1280, 1280, 20),
+                                      (8192, 8192, 1), (3456, 3456, 108), (4480, 4480, 140), (6656, 6656, 52)])
+@pytest.mark.parametrize("dtype,fp32_had", [(torch.float16, False), (torch.bfloat16, False), (torch.float16, True),
+                                            (torch.float32, False)])
+def test_prepared_descriptor_gives_identical_results(had_table, n_in, n, K, dtype, fp32_had):
+    """mq_hadamard_prepare + MQ_HAD_PREPARED (lane masks, 5 x 2 / 3 x 2 / 1 x 4 units) == plain sign words,
+    bit for bit, for the rotated activations and for the fused quantizer in both layouts."""
+    o = ops()
+    words = to_dev(had_table["words"][K]) if K > 1 else None
+    desc = o.hadamard_prepare(words, K) if K > 1 else None
+    x = to_dev(make_x(n + K, (9, n_in)), dtype)
+    y0 = o.hadamard(x, n, K, words, fp32_had)
+    y1 = o.hadamard(x, n, K, desc, fp32_had)
+    assert torch.equal(y0, y1)
+    sel = to_dev((np.arange(9) % 2).astype(np.uint8))
+    q0, z0 = o.hadamard_quant_i8(x, n, K, words, 0.05, 0.021, fp32_had=fp32_had, row_sel=sel, skip_col0=True)
+    q1, z1 = o.hadamard_quant_i8(x, n, K, desc, 0.05, 0.021, fp32_had=fp32_had, row_sel=sel, skip_col0=True)
+    q2, _ = o.hadamard_quant_i8(x, n, K, desc, 0.05, 0.021, fp32_had=fp32_had, row_sel=sel, skip_col0=True, tiled=True)
+    assert torch.equal(q0, q1) and torch.equal(z0, z1) and torch.equal(q2.to_rows(), q0)
+
+
+def test_prepared_descriptor_against_the_oracle(had_table):
+    o = ops()
+    n_in, n, K = 18944, 19968, 156
+    x = to_dev(make_x(77, (6, n_in)), torch.float16)
+    desc = o.hadamard_prepare(to_dev(had_table["words"][K]), K)
+    rot = oracle.hadamard(x.float().cpu().numpy(), n, K, had_table["mats"][K], mid_round=1, out_round=1)
+    y = o.hadamard(x, n, K, desc)
+    np.testing.assert_array_equal(y.float().cpu().numpy(), rot)
+    q, _ = o.hadamard_quant_i8(x, n, K, desc, 0.05)
+    np.testing.assert_array_equal(q.cpu().numpy()[:, :n], oracle.quant_static(rot, np.float32(0.05)))
