@@ -23,6 +23,16 @@ class GPTQ:
         self.nsamples = 0
         self.quantizer = None
 
+    @staticmethod
+    def _kernel_device(W):
+        return W.is_cuda
+
+    @staticmethod
+    def _block(W, i1, i2, Hrows, scale, bits, Q, E1):
+        """Column loop of one block: reads W[:, i1:i2], writes Q[:, i1:i2] and E1 (mq_gptq_block)."""
+        from mquant_amd import ops
+        ops.gptq_block(W, i1, i2, Hrows, scale, bits, Q, E1)
+
     def add_batch(self, inp, out=None):
         """Running mean of 2 x x^T over every token seen so far."""
         if isinstance(self.layer, (torch.nn.Conv2d, torch.nn.Conv3d)):
@@ -76,11 +86,10 @@ class GPTQ:
             self.layer.weight.data = Wq.reshape(self.layer.weight.shape).to(self.layer.weight.data.dtype)
             return
         qz = self.quantizer
-        fused = (self.use_kernel and W.is_cuda and groupsize == -1 and blocksize <= 128 and qz.sym
+        fused = (self.use_kernel and self._kernel_device(W) and groupsize == -1 and blocksize <= 128 and qz.sym
                  and getattr(qz, "perchannel", False) and 2 <= qz.bits <= 8)
         if fused:
             # the per-column loop as ONE launch per block (mq_gptq_block, same operation order)
-            from mquant_amd import ops
             scale = qz.scale.reshape(-1).to(device=W.device, dtype=torch.float32).contiguous()
             W = W.contiguous()
             Hrows = Hinv.contiguous()      # row-major copy for the kernel; the trailing GEMM keeps
@@ -89,7 +98,7 @@ class GPTQ:
             for i1 in range(0, self.columns, blocksize):
                 i2 = min(i1 + blocksize, self.columns)
                 E1 = torch.empty((self.rows, i2 - i1), dtype=torch.float32, device=W.device)
-                ops.gptq_block(W, i1, i2, Hrows, scale, qz.bits, Q, E1)
+                self._block(W, i1, i2, Hrows, scale, qz.bits, Q, E1)
                 W[:, i2:] -= E1 @ Hinv[i1:i2, i2:]
         for i1 in ([] if fused else range(0, self.columns, blocksize)):
             i2 = min(i1 + blocksize, self.columns)

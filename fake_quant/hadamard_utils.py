@@ -144,7 +144,9 @@ def matmul_hadUt(X: torch.Tensor) -> torch.Tensor:
 def random_hadamard_matrix(size: int, device):
     """Q = H diag(+-1): signs from the global CPU RNG (torch.randint), fp64."""
     signs = torch.randint(low=0, high=2, size=(size,)).to(torch.float64) * 2 - 1
-    return matmul_hadU(torch.diag(signs)).to(device)
+    Q = matmul_hadU(torch.diag(signs)).to(device)
+    Q._mq_signs = signs            # structure tag: rotation_utils.mul_q runs sign flip + fast Hadamard on the GPU
+    return Q
 
 
 def _bits_for(hadK, K: int, device):

@@ -12,6 +12,8 @@ from fake_quant.rotation_utils import (
     bake_mean_into_linear,
     fuse_ln_linear,
     get_orthogonal_matrix,
+    mul_q,
+    mul_qt,
     rotate_conv,
     rotate_grouped_input_,
     rotate_linear_input_,
@@ -77,8 +79,7 @@ def rotate_internvl_mlp_output(layer, Q, is_visual=False, online_hadamard=False)
         apply_exact_had_to_linear(out, had_dim=-1, output=False)
     out.bias = bias
     if bias is not None:
-        W = out.weight.data
-        out.bias.data = (Q.to(device=W.device, dtype=torch.float64).T @ bias.data.double()).to(W.dtype)
+        out.bias.data = mul_qt(Q, bias.data, out.weight.data.dtype)
 
 
 def rotate_internvl_ov_proj(layer, head_num, head_dim, is_visual=False):
@@ -117,10 +118,9 @@ def rotate_internvl_embeddings(model, Q) -> None:
     rotate_vector_(model.language_model.model.tok_embeddings.weight, Q)
     last = model.mlp1[3]
     W = last.weight.data
-    Qd = Q.to(device=W.device, dtype=torch.float64)
-    last.weight.data = (Qd.T @ W.double()).to(W.dtype)
+    last.weight.data = mul_qt(Q, W)
     if last.bias is not None:
-        last.bias.data = (last.bias.data.double() @ Qd).to(W.dtype)
+        last.bias.data = mul_q(last.bias.data, Q, W.dtype)
 
 
 def rotate_internvl_head(model, Q: torch.Tensor) -> None:

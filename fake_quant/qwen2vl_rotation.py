@@ -14,7 +14,10 @@ from fake_quant.rotation_utils import (
     fuse_ln_linear,
     fuse_merger_linear,
     get_orthogonal_matrix,
+    mul_q,
+    mul_qt,
     pad_linear_inputs_,
+    q_to,
     rotate_conv,
     rotate_grouped_input_,
     rotate_linear_input_,
@@ -77,8 +80,7 @@ def rotate_qwen2vl_mlp_output(layer, Q, is_visual=False, online_hadamard=False):
         apply_exact_had_to_linear(out, had_dim=-1, output=False)
     out.bias = bias
     if bias is not None:
-        W = out.weight.data
-        out.bias.data = (Q.to(device=W.device, dtype=torch.float64).T @ bias.data.double()).to(W.dtype)
+        out.bias.data = mul_qt(Q, bias.data, out.weight.data.dtype)
 
 
 def rotate_qwen2vl_ov_proj(layer, head_num, head_dim, is_visual=False):
@@ -106,10 +108,9 @@ def rotate_qwen2vl_embeddings(model, Q) -> None:
     rotate_vector_(model.model.embed_tokens.weight, Q)
     last = model.visual.merger.mlp[2]                 # the merger's output feeds the LLM residual
     W = last.weight.data
-    Qd = Q.to(device=W.device, dtype=torch.float64)
-    last.weight.data = (Qd.T @ W.double()).to(W.dtype)
+    last.weight.data = mul_qt(Q, W)
     if last.bias is not None:
-        last.bias.data = (last.bias.data.double() @ Qd).to(W.dtype)
+        last.bias.data = mul_q(last.bias.data, Q, W.dtype)
 
 
 def rotate_qwen2vl_head(model, Q: torch.Tensor) -> None:
@@ -152,7 +153,7 @@ def rotate_qwen2vl_model(model, args):
         rotate_qwen2vl_head(model, Q)
         utils.cleanup_memory()
         for layer in tqdm.tqdm(model.model.layers, unit="layer", desc="LLM Rotating"):
-            Q = Q.to(next(layer.parameters()).device)
+            Q = q_to(Q, next(layer.parameters()).device)
             rotate_qwen2vl_attention_inputs(layer, Q)
             rotate_qwen2vl_attention_output(layer, Q)
             rotate_qwen2vl_mlp_input(layer, Q)

@@ -26,17 +26,68 @@ def _as64(t: torch.Tensor, like: torch.Tensor = None) -> torch.Tensor:
     return t if like is None else t.to(like.device)
 
 
+def q_to(Q: torch.Tensor, device) -> torch.Tensor:
+    """``Q.to(device)`` that keeps the structure tag of a random Hadamard rotation."""
+    Qd = Q.to(device)
+    if Qd is not Q and getattr(Q, "_mq_signs", None) is not None:
+        Qd._mq_signs = Q._mq_signs
+    return Qd
+
+
+def _structured(Q: torch.Tensor) -> bool:
+    """Q = diag(s) H_n / sqrt(n) from ``random_hadamard_matrix`` and a GPU to run on: the product
+    is a sign flip plus a fast Hadamard per row (``mq_rotate_f64``) instead of a dense fp64 GEMM."""
+    return getattr(Q, "_mq_signs", None) is not None and torch.cuda.is_available()
+
+
+def _signs_on(Q: torch.Tensor, device) -> torch.Tensor:
+    cache = Q.__dict__.setdefault("_mq_signs_dev", {})
+    key = (device.type, device.index)
+    if key not in cache:
+        cache[key] = Q._mq_signs.to(device=device, dtype=torch.float64).contiguous()
+    return cache[key]
+
+
+def mul_q(X: torch.Tensor, Q: torch.Tensor, dtype: torch.dtype = None) -> torch.Tensor:
+    """``(X.double() @ Q).to(dtype)`` over the last dim of X (|Q| = X.shape[-1]); dtype defaults to
+    X's.  Random-Hadamard Q on a GPU box: one fused fp64 launch; otherwise the dense product."""
+    dtype = X.dtype if dtype is None else dtype
+    if not _structured(Q):
+        return (X.double() @ _as64(Q, X)).to(dtype)
+    from fake_quant import hadamard_utils as hu
+    from mquant_amd import ops
+    work = X.device if X.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    n = Q.shape[0]
+    assert X.shape[-1] == n
+    Xw = X.to(work)
+    Xw = Xw.clone(memory_format=torch.contiguous_format) if Xw.data_ptr() == X.data_ptr() or not Xw.is_contiguous() else Xw
+    if Xw.dtype != dtype:                                  # the kernel casts back to the dtype it read
+        Xw = Xw.double()
+    _, K = hu.get_hadK(n)
+    words = None if K == 1 else hu.had_sign_bits(K, work, prepared=False)
+    ops.rotate_f64_(Xw, _signs_on(Q, work), K, words)
+    return Xw.to(device=X.device, dtype=dtype)
+
+
+def mul_qt(Q: torch.Tensor, W: torch.Tensor, dtype: torch.dtype = None) -> torch.Tensor:
+    """``(Q.T.double() @ W.double()).to(dtype)`` for a matrix or a vector W."""
+    dtype = W.dtype if dtype is None else dtype
+    if not _structured(Q):
+        return (_as64(Q, W).T @ W.double()).to(dtype)
+    if W.dim() == 1:
+        return mul_q(W, Q, dtype)                          # Q^T b == b Q for a vector
+    return mul_q(W.t().contiguous(), Q, dtype).t().contiguous()
+
+
 def rotate_linear_input_(linear, Q: torch.Tensor) -> None:
-    W = linear.weight.data
-    linear.weight.data = (W.double() @ _as64(Q, W)).to(W.dtype)
+    linear.weight.data = mul_q(linear.weight.data, Q)
 
 
 def rotate_linear_output_(linear, Q: torch.Tensor) -> None:
     W = linear.weight.data
-    Qt = _as64(Q, W).T
-    linear.weight.data = (Qt @ W.double()).to(W.dtype)
+    linear.weight.data = mul_qt(Q, W)
     if linear.bias is not None:
-        linear.bias.data = (Qt @ linear.bias.data.double()).to(W.dtype)
+        linear.bias.data = mul_qt(Q, linear.bias.data, W.dtype)
 
 
 def rotate_grouped_input_(linear, Q: torch.Tensor) -> None:
@@ -45,12 +96,12 @@ def rotate_grouped_input_(linear, Q: torch.Tensor) -> None:
     W = linear.weight.data
     out_f, in_f = W.shape
     g = Q.shape[0]
-    linear.weight.data = (W.double().reshape(out_f, -1, g) @ _as64(Q, W)).to(W.dtype).reshape(out_f, in_f).contiguous()
+    linear.weight.data = mul_q(W.reshape(out_f, -1, g), Q).reshape(out_f, in_f).contiguous()
 
 
 def rotate_vector_(param: torch.Tensor, Q: torch.Tensor) -> None:
     """param <- param Q for embedding tables / positional tensors whose last dim is the model dim."""
-    param.data = (param.data.double() @ _as64(Q, param.data)).to(param.data.dtype)
+    param.data = mul_q(param.data, Q)
 
 
 # ------------------------------------------------------------------------------- LayerNorm fusion
@@ -130,22 +181,21 @@ def get_orthogonal_matrix(size, mode, device=utils.DEV):
 def rotate_conv(layer, Q_v, embed_dims) -> None:
     """Rotate the OUTPUT channels of a patch-embedding convolution."""
     W = layer.weight.data
-    layer.weight.data = (_as64(Q_v, W).T @ W.double().view(embed_dims, -1)).to(W.dtype).view(W.shape)
+    layer.weight.data = mul_qt(Q_v, W.reshape(embed_dims, -1)).view(W.shape)
     if layer.bias is not None:
-        layer.bias.data = (layer.bias.data.double() @ _as64(Q_v, W)).to(W.dtype)
+        layer.bias.data = mul_q(layer.bias.data, Q_v, W.dtype)
 
 
 def rotate_value_output_heads_(v_weight, v_bias, o_proj, Q_head, head_num, head_dim):
     """Per-head rotation of the V projection's outputs and the O projection's inputs by the same
     head_dim x head_dim matrix.  Returns the new (v_weight, v_bias)."""
     dt = v_weight.dtype
-    Qh = _as64(Q_head, v_weight)
-    Wv = v_weight.double().T.reshape(-1, head_num, head_dim)
-    v_weight = (Wv @ Qh).reshape(-1, head_num * head_dim).T.to(dt)
+    Wv = v_weight.T.reshape(-1, head_num, head_dim)
+    v_weight = mul_q(Wv, Q_head, dt).reshape(-1, head_num * head_dim).T
     if v_bias is not None:
-        v_bias = (v_bias.double().reshape(head_num, head_dim) @ Qh).to(dt).reshape(-1)
-    Wo = o_proj.weight.data.double().reshape(-1, head_num, head_dim)
-    o_proj.weight.data = (Wo @ Qh).reshape(-1, head_num * head_dim).to(dt)
+        v_bias = mul_q(v_bias.reshape(head_num, head_dim), Q_head, dt).reshape(-1)
+    Wo = o_proj.weight.data.reshape(-1, head_num, head_dim)
+    o_proj.weight.data = mul_q(Wo, Q_head, dt).reshape(-1, head_num * head_dim)
     return v_weight, v_bias
 
 
@@ -303,7 +353,7 @@ def rotate_o_ln_proj(layer, Q_o):
     """Older layout: ``proj`` is a bare parameter and ln_post keeps its bias."""
     rotate_linear_output_(layer.attn_pool.attn.out_proj, Q_o)
     rotate_vector_(layer.ln_post.bias, Q_o)
-    layer.proj.data = (Q_o.to(layer.proj.device).double().T @ layer.proj.data.double()).to(layer.proj.data.dtype)
+    layer.proj.data = mul_qt(Q_o, layer.proj.data)
 
 
 def rotate_o_ln_proj_fc(layer, Q_o, is_minicpmv=False):

@@ -33,6 +33,7 @@ extern "C" {
 #define MQ_F16 0
 #define MQ_BF16 1
 #define MQ_F32 2
+#define MQ_F64 3   /* mq_rotate_f64 only */
 
 #define MQ_OK 0
 #define MQ_EINVAL (-1)      /* bad argument (shape / alignment / dtype)          */
@@ -228,6 +229,20 @@ int mq_wquant_sym(const void *w, int w_dtype, long N, long K, long ldw, int bits
  * ------------------------------------------------------------------------- */
 int mq_rope_inplace(void *x, int x_dtype, long T, int heads, int head_dim, long ldx,
                     const void *cos, const void *sin, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Offline rotation of weight rows in fp64.  Replaces the dense
+ *   W <- (W.double() @ Q).to(W.dtype),  Q = random_hadamard_matrix(n) = diag(s) H_n / sqrt(n)
+ * of fake_quant/rotation_utils.py (rotate_* helpers) as driven by qwen2vl_rotation.py:232-332 and
+ * internvl_rotation.py:223-303; Q is built at hadamard_utils.py:107-112.  In place, per row:
+ *   x <- cast( (H_K (x) H_{n/K}) (s . x) / (double)sqrtf(n) ),   flat index = k*(n/K) + j,
+ * evaluated in fp64 (sign flip, butterflies, K x K sign stage, one division), cast to x's dtype
+ * through fp32 like torch's double -> half conversion.  signs: n doubles (+-1), NULL = no flip
+ * (plain H_n, e.g. the per-head Hadamard).  had_words as for mq_hadamard (plain words, NULL when
+ * K == 1).  Q^T W is the same call on the rows of W^T.  n * 8 bytes must fit the 160 KiB LDS.
+ * ------------------------------------------------------------------------- */
+int mq_rotate_f64(void *x, int dtype, long M, long n, long ld, const double *signs,
+                  int K, const uint32_t *had_words, void *stream);
 
 /* ---------------------------------------------------------------------------
  * GPTQ: the column loop of one lazy-batch block, gptq/gptq_utils.py:258-279 (symmetric

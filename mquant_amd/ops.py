@@ -361,6 +361,24 @@ def gptq_block(W: torch.Tensor, i1: int, i2: int, Hinv: torch.Tensor, scale: tor
 
 
 @_on_device
+def rotate_f64_(x: torch.Tensor, signs, K: int, had_words) -> torch.Tensor:
+    """In place ``x <- cast((H_K (x) H_{n/K}) (signs . x) / sqrt(n))`` over the last dim, evaluated in
+    fp64 (``mq_rotate_f64``).  x: [..., n] with contiguous rows; signs: float64 [n] or None;
+    had_words: the plain int32 sign words of hadK (None when K == 1)."""
+    _need_cuda(x)
+    n = x.shape[-1]
+    x2 = x.view(-1, n)
+    assert x2.stride(1) == 1
+    code = 3 if x.dtype == torch.float64 else dtype_code(x.dtype)
+    if signs is not None:
+        _need_cuda(x, signs)
+        assert signs.dtype == torch.float64 and signs.numel() == n and signs.is_contiguous()
+    call("mq_rotate_f64", x2.data_ptr(), code, x2.shape[0], n, x2.stride(0) if x2.shape[0] > 1 else n,
+         0 if signs is None else signs.data_ptr(), K, 0 if had_words is None else had_words.data_ptr(), _stream())
+    return x
+
+
+@_on_device
 def prepack(q: torch.Tensor, bits: int, zero_col0: bool = False) -> torch.Tensor:
     """int levels [N, K] -> the pre-tiled image streamed by gemm_w4a8."""
     _need_cuda(q)

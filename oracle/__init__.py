@@ -250,3 +250,16 @@ def wquant_sym(w, bits=4, mse=False, norm=2.4, grid=100, maxshrink=0.8, want_lev
                          C.c_int(int(mse)), C.c_float(norm), C.c_int(grid),
                          C.c_float(maxshrink), _p(scale, C.c_float), _p(levels, C.c_int8))
     return scale, levels
+
+
+def gptq_block(W1, Hb, scale, bits):
+    """Column loop of one GPTQ block (reference gptq_utils.py:249-286, symmetric per-channel
+    quantizer without groups).  W1 [N, cols], Hb = Hinv[i1:i2, i1:i2], scale [N] -> (Q1, Err1)."""
+    W1, Hb, scale = _f32(W1), _f32(Hb), _f32(scale).reshape(-1)
+    N, cols = W1.shape
+    Q1 = np.zeros((N, cols), dtype=np.float32)
+    E1 = np.zeros((N, cols), dtype=np.float32)
+    lib().orc_gptq_block(_p(W1, C.c_float), C.c_long(N), C.c_long(cols), C.c_long(cols),
+                         _p(Hb, C.c_float), C.c_long(Hb.shape[1]), _p(scale, C.c_float), C.c_int(bits),
+                         _p(Q1, C.c_float), C.c_long(cols), _p(E1, C.c_float), C.c_long(cols))
+    return Q1, E1

@@ -493,3 +493,42 @@ void orc_wquant_sym(const float *w, long N, long K, int bits, int mse,
             }
     }
 }
+
+/* GPTQ lazy-batch block, per-column loop -- reference fake_quant/gptq/gptq_utils.py:249-286 with
+ * the symmetric per-channel quantizer without groups (quant_utils.py sym_quant_dequant: scale *
+ * clamp(round(w / scale), -(maxq+1), maxq)):
+ *     W1 = W[:, i1:i2].clone(); Hinv1 = Hinv[i1:i2, i1:i2]
+ *     for i in range(count):
+ *         w = W1[:, i]; d = Hinv1[i, i]
+ *         q = quantize(w); Q1[:, i] = q
+ *         err1 = (w - q) / d
+ *         W1[:, i:] -= err1.unsqueeze(1).matmul(Hinv1[i, i:].unsqueeze(0))   (K = 1: one product)
+ *         Err1[:, i] = err1
+ * Rows never interact; every statement is one fp32 operation with one rounding (the file is
+ * compiled with -ffp-contract=off).  W1 [N, ldw] is read only, H points at Hinv[i1, i1]. */
+void orc_gptq_block(const float *W1, long N, long cols, long ldw,
+                    const float *H, long ldh, const float *scale, int bits,
+                    float *Q1, long ldq, float *E1, long lde)
+{
+    const float hi = (float)((1 << (bits - 1)) - 1), lo = -(hi + 1.0f);
+    float *w = (float *)malloc(sizeof(float) * (size_t)(cols > 0 ? cols : 1));
+    for (long n = 0; n < N; ++n) {
+        const float s = scale[n];
+        for (long j = 0; j < cols; ++j) w[j] = W1[n * ldw + j];
+        for (long i = 0; i < cols; ++i) {
+            const float *hrow = H + i * ldh;
+            float lv = rintf(w[i] / s);
+            if (lv < lo) lv = lo;
+            if (lv > hi) lv = hi;
+            const float q = s * lv;
+            const float err = (w[i] - q) / hrow[i];
+            for (long j = i + 1; j < cols; ++j) {
+                const float prod = err * hrow[j];
+                w[j] = w[j] - prod;
+            }
+            Q1[n * ldq + i] = q;
+            E1[n * lde + i] = err;
+        }
+    }
+    free(w);
+}

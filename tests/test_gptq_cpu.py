@@ -60,6 +60,70 @@ def test_solver_matches_reference(golden_dir, case):
     assert out_err(layer.weight.data) < out_err(rtn.quantize(w_before))
 
 
+class OracleBlockGPTQ:
+    """Mixin: routes the solver's per-block column loop through oracle.gptq_block on the CPU (the
+    slot mq_gptq_block fills on the GPU)."""
+    use_kernel = True
+    calls = 0
+
+    @staticmethod
+    def _kernel_device(W):
+        return True
+
+    @classmethod
+    def _block(cls, W, i1, i2, Hrows, scale, bits, Q, E1):
+        import oracle
+        q, e = oracle.gptq_block(W[:, i1:i2].numpy(), Hrows[i1:i2, i1:i2].numpy(), scale.numpy(), bits)
+        Q[:, i1:i2] = torch.from_numpy(q)
+        E1.copy_(torch.from_numpy(e))
+        cls.calls += 1
+
+
+@pytest.mark.parametrize("case", ["plain", "actorder", "mse_w8", "wide", "conv2d"])
+def test_oracle_block_loop_reproduces_the_reference_goldens(golden_dir, case):
+    """orc_gptq_block (oracle/mq_oracle.c, restating gptq_utils.py:249-286) pinned: with the column
+    loop of every block computed by the oracle the solver lands on the reference's Q bit for bit."""
+    from fake_quant import quant_utils as qu
+    from fake_quant.gptq.gptq_utils import GPTQ
+    g = np.load(os.path.join(golden_dir, f"gptq_{case}.npz"))
+    seed, n_out, n_in, bits, mse, actorder, groupsize = [int(v) for v in g["meta"]]
+    assert groupsize == -1
+    layer, xs = build("conv" if case == "conv2d" else "linear", n_out, n_in, seed)
+    Solver = type("Solver", (OracleBlockGPTQ, GPTQ), {})
+    solver = Solver(layer)
+    solver.quantizer = qu.WeightQuantizer()
+    solver.quantizer.configure(bits, perchannel=True, sym=True, mse=bool(mse))
+    for x in xs:
+        solver.add_batch(x, None)
+    solver.fasterquant(percdamp=0.01, groupsize=-1, actorder=bool(actorder), static_groups=False)
+    assert Solver.calls == -(-n_in // 128)
+    np.testing.assert_array_equal(layer.weight.data.reshape(n_out, -1).numpy(), g["Q"])
+
+
+def test_oracle_block_loop_equals_torch_loop_with_errors():
+    """Err1 is not in the goldens (it only feeds the trailing update): check it against the torch loop."""
+    import oracle
+    N, cols, bits = 37, 100, 4
+    W = torch.from_numpy(make_w(5, (N, cols))) * 3.0
+    X = torch.from_numpy(make_x(6, (cols + 64, cols)))
+    H = X.T @ X / X.shape[0]
+    H += 0.01 * torch.mean(torch.diag(H)) * torch.eye(cols)
+    Hinv = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H)), upper=True).contiguous()
+    scale = W.abs().amax(1) / 7
+    W1 = W.clone()
+    Q1, E1 = torch.zeros_like(W1), torch.zeros_like(W1)
+    for i in range(cols):
+        w, d = W1[:, i], Hinv[i, i]
+        q = scale * torch.clamp(torch.round(w / scale), -8, 7)
+        Q1[:, i] = q
+        err = (w - q) / d
+        W1[:, i:] -= err.unsqueeze(1) @ Hinv[i, i:].unsqueeze(0)
+        E1[:, i] = err
+    q, e = oracle.gptq_block(W.numpy(), Hinv.numpy(), scale.numpy(), bits)
+    np.testing.assert_array_equal(q, Q1.numpy())
+    np.testing.assert_array_equal(e, E1.numpy())
+
+
 # ------------------------------------------------------------------------------------ drivers
 class ToyVlm:
     """VLMEvalKit-style wrapper around a toy HF module: .model, .generate(message=, dataset=)."""

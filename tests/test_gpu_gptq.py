@@ -1,4 +1,4 @@
-"""mq_gptq_block (the GPTQ column loop in one launch) against the torch loop it replaces, and the
+"""mq_gptq_block (the GPTQ column loop in one launch) against the oracle restatement of that loop, and the
 solver end to end on the GPU against the reference goldens."""
 import os
 
@@ -14,22 +14,12 @@ DEV = "cuda:0"
 torch.set_grad_enabled(False)
 
 
-def torch_block(W1, Hb, scale, bits):
-    maxq = 2 ** (bits - 1) - 1
-    W1 = W1.clone()
-    Q1, E1 = torch.zeros_like(W1), torch.zeros_like(W1)
-    for i in range(W1.shape[1]):
-        w, d = W1[:, i], Hb[i, i]
-        q = scale * torch.clamp(torch.round(w / scale), -(maxq + 1), maxq)
-        Q1[:, i] = q
-        err = (w - q) / d
-        W1[:, i:] -= err.unsqueeze(1) @ Hb[i, i:].unsqueeze(0)
-        E1[:, i] = err
-    return Q1, E1
-
-
-@pytest.mark.parametrize("N,cols,bits", [(200, 128, 4), (64, 100, 4), (1, 1, 4), (333, 37, 8), (4096, 128, 4)])
-def test_block_kernel_equals_torch_loop(N, cols, bits):
+@pytest.mark.parametrize("N,cols,bits", [(200, 128, 4), (64, 100, 4), (1, 1, 4), (333, 37, 8), (4096, 128, 4),
+                                         (65, 128, 2), (130, 64, 6)])
+def test_block_kernel_equals_the_oracle(N, cols, bits):
+    """mq_gptq_block against oracle.gptq_block (orc_gptq_block, pinned on the CPU to the reference's
+    GPTQ goldens in test_gptq_cpu.py): Q and Err bit for bit."""
+    import oracle
     from mquant_amd import ops
     columns = cols + 40
     W = torch.from_numpy(make_w(N + cols, (N, columns))).to(DEV) * 3.0
@@ -42,9 +32,10 @@ def test_block_kernel_equals_torch_loop(N, cols, bits):
     Q = torch.zeros_like(W)
     E = torch.empty((N, 128), device=DEV)
     ops.gptq_block(W, i1, i2, Hinv, scale, bits, Q, E)
-    Q_ref, E_ref = torch_block(W[:, i1:i2], Hinv[i1:i2, i1:i2], scale, bits)
-    torch.testing.assert_close(Q[:, i1:i2], Q_ref, rtol=0, atol=0)
-    torch.testing.assert_close(E[:, :cols], E_ref, rtol=0, atol=0)
+    q_ref, e_ref = oracle.gptq_block(W[:, i1:i2].cpu().numpy(), Hinv[i1:i2, i1:i2].cpu().numpy(),
+                                     scale.cpu().numpy(), bits)
+    np.testing.assert_array_equal(Q[:, i1:i2].cpu().numpy(), q_ref)
+    np.testing.assert_array_equal(E[:, :cols].cpu().numpy(), e_ref)
     assert float(Q[:, :i1].abs().max()) == 0.0 and float(Q[:, i2:].abs().max()) == 0.0
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM traffic per kernel launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
 
-usage: pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>
+usage: pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [commit] [command]
 
 Units and corrections (MI355X_MICROARCH.md, "HBM" and "rocprofv3 PMC slots"): both counters are in
 KiB; on gfx950 FETCH_SIZE tallies 128-byte read requests at 64 bytes, so wide coalesced reads are
@@ -13,7 +13,7 @@ import csv
 import json
 import sys
 
-FAMILIES = (("gemm_w4a8", "gemm"), ("splitk_reduce", "splitk_reduce"), ("hadamard_kernel", "hadamard"),
+FAMILIES = (("gemm_w4a8", "gemm"), ("gemm_ws", "gemm"), ("splitk_reduce", "splitk_reduce"), ("hadamard_kernel", "hadamard"),
             ("quantize_act", "act_quant"), ("act_quant", "act_quant"))
 
 
@@ -39,6 +39,8 @@ def main():
     fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
     res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python3 bench.py --no-graph",
            "corrections": "KiB -> bytes; FETCH_SIZE x2 (gfx950 counts 128 B requests as 64 B); WRITE_SIZE as read",
+           "commit": sys.argv[4] if len(sys.argv) > 4 else None,
+           "command": sys.argv[5] if len(sys.argv) > 5 else None,
            "kernels": {}}
     for fam in sorted(set(fetch) | set(write)):
         f, w = fetch.get(fam, []), write.get(fam, [])
