@@ -318,7 +318,8 @@ int mq_gemm_w4a8_i32_ws(const int8_t *a, long lda, const void *w, int w_bits,
                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* Tuning / test hook (process-wide, not part of the drop-in surface): force the tile shape
- * (-1 heuristic; ids as in csrc/gemm_w4a8.hip dispatch_tile) and the split-K factor (0 heuristic). */
+ * (-1 heuristic; ids as in csrc/gemm_w4a8.hip dispatch_tile) and the split-K factor (0 heuristic;
+ * bits 8..15 of a positive value force the number of m-groups of the XCD mapping, 0 = automatic). */
 int mq_gemm_debug_force(int tile, int splits);
 
 /* ---------------------------------------------------------------------------

@@ -47,32 +47,61 @@ struct GemmArgs {
     unsigned m_blocks = 1, n_blocks = 1;
     unsigned mag_m = 0, mag_n = 0;   // ceil(2^32 / d): n / d == umulhi(n, mag) for n, d < 2^16
     int kq = 0, kr = 0;              // k units per split: split s owns kq (+1 if s < kr) units from s*kq + min(s, kr)
+    // XCD grouping of the m-blocks (set_geometry): xm groups of mg = m_blocks / xm blocks each
+    unsigned xm = 1, mg = 1, mag_xm = 0;
 };
 
-inline void set_geometry(GemmArgs &p, int BM, int BN, int k_unit)
+// The 8 XCDs have private L2s: whatever two XCDs both touch crosses the fabric twice.  Work ids are
+// dealt to the XCDs in 8 contiguous ranges (tile_of_block) of the order (split, m-group, n-block,
+// m-block inside the group), so the weight panels are fetched by xm XCDs each and the activation rows
+// by ~8 / xm: fabric reads ~ W * xm + A * 8 / xm.  xm = the divisor of m_blocks that minimises it
+// (1 for the wide gate/up GEMM, 2 for down_proj, whose activations are 40 % of its weights' size).
+inline unsigned pick_m_groups(unsigned m_blocks, double w_bytes, double a_bytes)
+{
+    unsigned best = 1;
+    double best_cost = w_bytes + 8.0 * a_bytes;
+    for (unsigned xm = 2; xm <= 8 && xm <= m_blocks; ++xm) {
+        if (m_blocks % xm) continue;
+        const double cost = w_bytes * xm + a_bytes * 8.0 / xm;
+        if (cost < 0.97 * best_cost) { best = xm; best_cost = cost; }
+    }
+    return best;
+}
+
+extern int g_gemm_force_xm;   // debug (mq_gemm_debug_force, bits 8.. of `splits`); 0 = automatic
+
+inline void set_geometry(GemmArgs &p, int BM, int BN, int k_unit, int w_bits)
 {
     p.m_blocks = (unsigned)ceil_div(p.M, BM);
     p.n_blocks = (unsigned)ceil_div(p.n_tiles * 16, BN);
-    p.mag_m = (unsigned)(((1ULL << 32) + p.m_blocks - 1) / p.m_blocks);
+    const double w_bytes = (double)p.n_tiles * 16.0 * (double)p.K_pad * (w_bits == 4 ? 0.5 : 1.0);
+    p.xm = pick_m_groups(p.m_blocks, w_bytes, (double)p.M * (double)p.K_pad);
+    if (g_gemm_force_xm > 0 && p.m_blocks % (unsigned)g_gemm_force_xm == 0) p.xm = (unsigned)g_gemm_force_xm;
+    p.mg = p.m_blocks / p.xm;
+    p.mag_m = (unsigned)(((1ULL << 32) + p.mg - 1) / p.mg);
     p.mag_n = (unsigned)(((1ULL << 32) + p.n_blocks - 1) / p.n_blocks);
+    p.mag_xm = (unsigned)(((1ULL << 32) + p.xm - 1) / p.xm);
     const long units = p.K_pad / k_unit;
     p.kq = (int)(units / p.splits);
     p.kr = (int)(units % p.splits);
 }
 
-// workgroup -> (bm, bn, split): XCD-aware and bijective.  Block b runs on XCD b % 8; the remap makes
-// the m-blocks that share a weight panel (and, under split-K, the tiles of one k-slice) consecutive
-// on ONE XCD, so a panel is fetched into one L2 once.
+// workgroup -> (bm, bn, split): XCD-aware and bijective.  Block b runs on XCD b % 8; the remap gives
+// every XCD one contiguous range of the order (split, m-group, n-block, m-block in group): the
+// m-blocks that share a weight panel (and, under split-K, the tiles of one k-slice) are consecutive on
+// ONE XCD, so a panel is fetched into one L2 once per m-group.
 __device__ __forceinline__ void tile_of_block(const GemmArgs &p, int &bm, int &bn, int &split)
 {
     const unsigned total = gridDim.x, b = blockIdx.x, xcd = b & 7, idx = b >> 3;
     const unsigned q = total >> 3, r = total & 7;
     const unsigned wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const unsigned rest = p.m_blocks == 1 ? wid : __umulhi(wid, p.mag_m);
-    bm = (int)(wid - rest * p.m_blocks);
-    const unsigned sp = p.n_blocks == 1 ? rest : __umulhi(rest, p.mag_n);
+    const unsigned t1 = p.mg == 1 ? wid : __umulhi(wid, p.mag_m);
+    const unsigned bm_in = wid - t1 * p.mg;
+    const unsigned t2 = p.n_blocks == 1 ? t1 : __umulhi(t1, p.mag_n);
+    bn = (int)(t1 - t2 * p.n_blocks);
+    const unsigned sp = p.xm == 1 ? t2 : __umulhi(t2, p.mag_xm);
     split = (int)sp;
-    bn = (int)(rest - sp * p.n_blocks);
+    bm = (int)((t2 - sp * p.xm) * p.mg + bm_in);
 }
 
 __device__ __forceinline__ void k_range_of_split(const GemmArgs &p, int split, int &k_begin, int &nk)

@@ -400,7 +400,7 @@ static int launch_gemm_pipe(const GemmArgs &p, hipStream_t st)
         if (rc != MQ_OK) return rc;
     }
     GemmArgs g = p;
-    set_geometry(g, 256, 256, 64);
+    set_geometry(g, 256, 256, 64, 4);
     hipLaunchKernelGGL(kern, dim3(g.m_blocks * g.n_blocks * (unsigned)g.splits), dim3(512), SMEM, st, g);
     int rc = check_launch("gemm_w4a8_pipe");
     if (rc != MQ_OK || p.splits == 1) return rc;
@@ -421,7 +421,7 @@ static int launch_gemm(const GemmArgs &p, hipStream_t st)
         if (rc != MQ_OK) return rc;
     }
     GemmArgs g = p;
-    set_geometry(g, BM, BN, 128);
+    set_geometry(g, BM, BN, 128, W_BITS);
     hipLaunchKernelGGL(kern, dim3(g.m_blocks * g.n_blocks * (unsigned)g.splits),
                        dim3(WARPS_M * WARPS_N * 64), SMEM, st, g);
     int rc = check_launch("gemm_w4a8");
@@ -527,6 +527,7 @@ static int dispatch_tile(const GemmArgs &p, int tile, hipStream_t st)
 }
 
 static int g_force_tile = -1, g_force_splits = 0;
+int g_gemm_force_xm = 0;
 
 static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, long M, long N,
                        long K_pad, float s_x0, float s_x1, const uint8_t *row_sel,
@@ -663,6 +664,7 @@ extern "C" int mq_gemm_w4a8_i32_ws(const int8_t *a, long lda, const void *w, int
 extern "C" int mq_gemm_debug_force(int tile, int splits)
 {
     mq::g_force_tile = tile;
-    mq::g_force_splits = splits;
+    mq::g_force_splits = splits > 0 ? (splits & 0xff) : 0;
+    mq::g_gemm_force_xm = splits > 0 ? (splits >> 8) & 0xff : 0;
     return MQ_OK;
 }

@@ -575,7 +575,7 @@ static int launch_ws(const GemmArgs &p, hipStream_t st)
     int rc = ensure_dynamic_lds((const void *)kern, SMEM);
     if (rc != MQ_OK) return rc;
     GemmArgs g = p;
-    set_geometry(g, BM, BN, 128);
+    set_geometry(g, BM, BN, 128, W_BITS);
     hipLaunchKernelGGL(kern, dim3(g.m_blocks * g.n_blocks * (unsigned)g.splits), dim3((MW_M * MW_N * KS + NL) * 64), SMEM, st, g);
     return check_launch("gemm_ws");
 }

@@ -79,7 +79,8 @@ def test_transposed_grouped_and_vector_forms():
 def test_rows_with_a_stride_and_in_place_use():
     from fake_quant import hadamard_utils as hu
     from mquant_amd import ops
-    n, K = 160, 20
+    n = 160
+    K = hu.get_hadK(n)[1]
     Q = _q(n, seed=9)
     buf = torch.randn(11, 256, device=DEV, dtype=torch.float64)
     keep = buf.clone()
@@ -120,7 +121,7 @@ def test_passes_on_the_gpu_reproduce_the_reference_weights(golden_dir, kind, whe
     keys = [k for k in g.files if k not in ("seed", "rot_seed", "logits")]
     assert sorted(keys) == sorted(sd.keys())
     for k in keys:
-        assert sd[k].device.type == where
+        assert sd[k].device.type == where or sd[k].numel() == 1, k      # RMSN's placeholder weight stays where it is made
         np.testing.assert_allclose(sd[k].cpu().numpy(), g[k], rtol=0, atol=1e-6, err_msg=k)
     np.testing.assert_allclose(model(pixels.to(where), ids.to(where)).cpu().numpy(), g["logits"], rtol=0, atol=2e-5)
 

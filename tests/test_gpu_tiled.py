@@ -285,3 +285,27 @@ def test_prepared_descriptor_against_the_oracle(had_table):
     np.testing.assert_array_equal(y.float().cpu().numpy(), rot)
     q, _ = o.hadamard_quant_i8(x, n, K, desc, 0.05)
     np.testing.assert_array_equal(q.cpu().numpy()[:, :n], oracle.quant_static(rot, np.float32(0.05)))
+
+
+@pytest.mark.parametrize("M,N,K", [(768, 1100, 512), (1000, 300, 384)])
+def test_every_m_grouping_of_the_xcd_mapping_is_a_bijection(M, N, K):
+    """tile_of_block with xm m-groups (gemm_common.h): forced through the debug hook (bits 8.. of
+    `splits`) for every divisor of the m-block count; a tile computed twice or never shows up as a
+    wrong accumulator."""
+    o = ops()
+    rng = np.random.default_rng(M + N)
+    a = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+    w = _levels(11, (N, K), 4)
+    acc_ref = oracle.gemm_i32(a, w)
+    at = o.TiledAct.from_rows(to_dev(a))
+    img = o.prepack(to_dev(w), 4)
+    o.splitk_workspace(torch.device(DEV), 64 << 20)
+    try:
+        for tile in (40, 41, 42, 43, 44, 3, 1):
+            for xm in (1, 2, 3, 4, 6, 8):
+                for splits in (1, 2):
+                    o.gemm_debug_force(tile, splits | (xm << 8))
+                    acc = o.gemm_w4a8_i32(at, img, 4, N)
+                    np.testing.assert_array_equal(acc.cpu().numpy(), acc_ref, err_msg=f"tile {tile} xm {xm} splits {splits}")
+    finally:
+        o.gemm_debug_force(-1, 0)

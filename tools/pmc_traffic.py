@@ -24,12 +24,15 @@ def family(name):
     return None
 
 
-def collect(path, counter):
+def collect(path, counter, by_grid=False):
     out = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
         fam = family(r["Kernel_Name"])
+        if fam and by_grid:
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("mq::", "")
+            fam = f'{name} x{int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1)}'
         if fam:
             out[fam].append(float(r["Counter_Value"]))
     return out
@@ -48,6 +51,14 @@ def main():
         wr = 1024.0 * sum(w) / max(len(w), 1)
         res["kernels"][fam] = {"launches_sampled": len(f), "read_bytes_per_launch": round(rd),
                                "write_bytes_per_launch": round(wr), "hbm_bytes_per_launch": round(rd + wr)}
+    # the same per (kernel instantiation, workgroup count): one line per layer shape
+    fetch, write = collect(sys.argv[1], "FETCH_SIZE", True), collect(sys.argv[2], "WRITE_SIZE", True)
+    res["by_launch_shape"] = {}
+    for key in sorted(set(fetch) | set(write)):
+        f, w = fetch.get(key, []), write.get(key, [])
+        res["by_launch_shape"][key] = {"launches_sampled": len(f),
+                                       "read_bytes_per_launch": round(2.0 * 1024.0 * sum(f) / max(len(f), 1)),
+                                       "write_bytes_per_launch": round(1024.0 * sum(w) / max(len(w), 1))}
     json.dump(res, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(res, indent=1))
 
