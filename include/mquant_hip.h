@@ -245,6 +245,22 @@ int mq_rotate_f64(void *x, int dtype, long M, long n, long ld, const double *sig
                   int K, const uint32_t *had_words, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * fp8 KV cache (BASELINE configuration 5).  No reference implementation exists
+ * (fake_quant/utils.py:220-267 are flags of a parser nobody calls): parity is UNPINNED, the checker
+ * is oracle/mq_oracle.c (orc_kv_quant_fp8 / orc_kv_dequant_fp8; its e4m3fn codec is pinned to
+ * torch.float8_e4m3fn on the CPU).  OCP e4m3fn (not fnuz), one static scale per KV head:
+ *   write:  q[t][h][d] = e4m3fn_rne(clamp(kv[t][h][d] / scale[h], -448, 448))
+ *   read:   out[t][h][d] = cast(float(q[t][h][d]) * scale[h])
+ * kv / out: [T][ld] elements with the heads * head_dim values of a token contiguous (ld lets the
+ * K or V slice of a fused qkv GEMM output be read in place); q: [T][ldo] bytes.  head_dim % 8 == 0,
+ * rows 16-byte aligned (8 for the fp8 side).
+ * ------------------------------------------------------------------------- */
+int mq_kv_quant_fp8(const void *kv, int dtype, long T, int heads, int head_dim, long ld,
+                    const float *scale, uint8_t *out, long ldo, void *stream);
+int mq_kv_dequant_fp8(const uint8_t *q, long T, int heads, int head_dim, long ld,
+                      const float *scale, void *out, int out_dtype, long ldo, void *stream);
+
+/* ---------------------------------------------------------------------------
  * GPTQ: the column loop of one lazy-batch block, gptq/gptq_utils.py:258-279 (symmetric
  * per-channel quantizer, no groups).  For i = 0..cols-1, per output row n:
  *   q = scale[n]*clamp(rint(w_i/scale[n]), -2^(bits-1), 2^(bits-1)-1);  err = (w_i - q)/Hinv1[i][i];

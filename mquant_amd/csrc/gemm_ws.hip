@@ -68,7 +68,8 @@ __global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(G
     static_assert(PIECES % NL == 0, "pieces must divide over the loader waves");
     static_assert(S >= 4 && S <= 8 && (S - 3) * LPW < 64, "ring depth (vmcnt is 6 bits)");
     static_assert(KS == 1 || KS == 2, "k groups");
-    static_assert(KS * BM * PITCH <= RING, "epilogue slab(s) must fit the ring");
+    static_assert(BM * PITCH <= RING, "epilogue slab must fit the ring");
+    constexpr bool TWO_SLABS = (KS == 2) && (2 * BM * PITCH <= RING);   // else the k groups are added through one slab
     static_assert(NM * 64 >= BN && NM * 64 >= BM, "parameter prefetch: one thread per channel / row");
     static_assert(KS == 1 || (W_BITS == 4 ? true : true), "k groups");
 
@@ -292,66 +293,48 @@ __global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(G
         __builtin_amdgcn_s_barrier();                // B(0): stage 0 landed
         MQ_STAMP_AT(2);
         if constexpr (KS == 2) {
-            // Own sub-steps: group g takes sub-steps g and g + 2 of every stage.  Each own sub-step is an
-            // M phase (its MFMAs, ~32 cycles of matrix-core time each) and a P phase (unpack the next
-            // weights, issue the next fragment reads).  The two waves of a SIMD run these phases in
-            // opposite order -- group 0: M P M P, group 1: P M P M -- so one wave's VALU / LDS issue
-            // falls into the other's MFMA time; started in the same phase (both leave the barrier
-            // together) they would only queue for the matrix core and then for the VALU.
-            auto m_phase = [&](int set) {
+            // Group g takes the K = 32 sub-steps g and g + 2 of every stage ("own steps", two per stage,
+            // register set = own step parity).  An own step is TM x TN >= 4 MFMAs (>= 128 cycles of
+            // matrix time), so its fragments are read ONE own step ahead (two sets instead of four: the
+            // wide wave tiles need the registers for accumulators) and the nibbles are unpacked at its
+            // start; the reads of the next own step are spread between the MFMAs.
+            auto own = [&](int set, int slot_n, int sub_n) {
+                __builtin_amdgcn_sched_barrier(0);
+                unpack(set, set);
+                __builtin_amdgcn_sched_barrier(0);
+                load_x(set ^ 1, slot_n, sub_n);
+                load_w(set ^ 1, slot_n, sub_n);
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
 #pragma unroll
                     for (int j = 0; j < TM; ++j)
                         acc[0][i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(WU[set][i], X[set][j], acc[0][i][j], 0, 0, 0);
+#ifdef MQ_OWN_INTERLEAVE
+#pragma unroll
+                for (int m = 0; m < N_MFMA; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, DS_PER_GAP, 0);
+                }
+#else
+                // all reads of the next own step first (their latency runs under this step's MFMAs)
+                __builtin_amdgcn_sched_group_barrier(0x100, N_DS, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, N_MFMA, 0);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
             };
+            load_x(0, 0, kg);
+            load_w(0, 0, kg);
             int cur = 0;
-            if (kg == 0) {
-                load_x(0, 0, 0); load_w(0, 0, 0);
-                load_x(1, 0, 2); load_w(1, 0, 2);
-                unpack(0, 0);
-                auto body = [&](int set, int slot_n, int sub_n) {   // M(q) | unpack(q+1) | reads of q+2
-                    __builtin_amdgcn_sched_barrier(0);
-                    m_phase(set);
-                    __builtin_amdgcn_sched_barrier(0);
-                    unpack(set ^ 1, set ^ 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    load_x(set, slot_n, sub_n);
-                    load_w(set, slot_n, sub_n);
-                    __builtin_amdgcn_sched_barrier(0);
-                };
-                for (int it = 0; it < nk; ++it) {
-                    __builtin_amdgcn_s_barrier();        // B(it+1): stage it+1 landed
-                    int nxt = cur + 1;
-                    if (nxt == S) nxt = 0;
-                    if (it + 1 >= nk) nxt = cur;         // last step: harmless re-reads of a live slot
-                    if (MQ_EXP == 7) { cur = nxt; continue; }
-                    body(0, nxt, 0);
-                    body(1, nxt, 2);
-                    cur = nxt;
+            for (int it = 0; it < nk; ++it) {
+                __builtin_amdgcn_s_barrier();        // B(it+1): stage it+1 landed
+                int nxt = cur + 1;
+                if (nxt == S) nxt = 0;
+                if (it + 1 >= nk) nxt = cur;         // last step: harmless re-reads of a live slot
+                if (MQ_EXP != 7) {
+                    own(0, cur, kg + 2);
+                    own(1, nxt, kg);
                 }
-            } else {
-                load_x(0, 0, 1); load_w(0, 0, 1);
-                auto body = [&](int set, int slot_n, int sub_n) {   // unpack(q) | reads of q+1 | M(q)
-                    __builtin_amdgcn_sched_barrier(0);
-                    unpack(set, set);
-                    __builtin_amdgcn_sched_barrier(0);
-                    load_x(set ^ 1, slot_n, sub_n);
-                    load_w(set ^ 1, slot_n, sub_n);
-                    __builtin_amdgcn_sched_barrier(0);
-                    m_phase(set);
-                    __builtin_amdgcn_sched_barrier(0);
-                };
-                for (int it = 0; it < nk; ++it) {
-                    __builtin_amdgcn_s_barrier();        // B(it+1): stage it+1 landed
-                    int nxt = cur + 1;
-                    if (nxt == S) nxt = 0;
-                    if (it + 1 >= nk) nxt = cur;
-                    if (MQ_EXP == 7) { cur = nxt; continue; }
-                    body(0, cur, 3);
-                    body(1, nxt, 1);
-                    cur = nxt;
-                }
+                cur = nxt;
             }
         } else {
         load_x(0, 0, 0);
@@ -385,18 +368,42 @@ __global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(G
     MQ_STAMP_AT(4);
     __syncthreads();                                 // the ring is free: park the raw accumulators
     MQ_STAMP_AT(5);
-    if (wave < NM) {
+    {
         // D layout of the 32x32 form: column (-> row m) = lane & 31, rows (-> channels) 8 q + 4 (lane >> 5) + e
         const int kg = wave / NMT, wm = (wave % NMT) / MW_N, wn = wave % MW_N;
         const int ml = lane & 31, nh = (lane >> 5) * 4;
+        auto cell = [&](int slab, int i, int j, int q) {
+            return reinterpret_cast<v4i *>(smem + slab * (BM * PITCH) + ((wm * TM + j) * 32 + ml) * PITCH + ((wn * TN + i) * 32 + q * 8 + nh) * 4);
+        };
+        auto park = [&](int slab) {
 #pragma unroll
-        for (int j = 0; j < TM; ++j)
+            for (int j = 0; j < TM; ++j)
 #pragma unroll
-            for (int i = 0; i < TN; ++i)
+                for (int i = 0; i < TN; ++i)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<v4i *>(smem + kg * (BM * PITCH) + ((wm * TM + j) * 32 + ml) * PITCH + ((wn * TN + i) * 32 + q * 8 + nh) * 4) =
-                        v4i{acc[0][i][j][4 * q], acc[0][i][j][4 * q + 1], acc[0][i][j][4 * q + 2], acc[0][i][j][4 * q + 3]};
+                    for (int q = 0; q < 4; ++q)
+                        *cell(slab, i, j, q) = v4i{acc[0][i][j][4 * q], acc[0][i][j][4 * q + 1], acc[0][i][j][4 * q + 2], acc[0][i][j][4 * q + 3]};
+        };
+        if (KS == 2 && !TWO_SLABS) {
+            if (wave < NM && kg == 1) park(0);
+            __syncthreads();
+            if (wave < NM && kg == 0) {
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+#pragma unroll
+                    for (int i = 0; i < TN; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const v4i o = *cell(0, i, j, q);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[0][i][j][4 * q + e] += o[e];
+                        }
+            }
+            __syncthreads();
+            if (wave < NM && kg == 0) park(0);
+        } else if (wave < NM) {
+            park(kg);
+        }
     }
     __syncthreads();
     MQ_STAMP_AT(6);
@@ -430,7 +437,7 @@ __global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(G
             const int row = (t * RPI + lrow < BM) ? t * RPI + lrow : BM - 1;
             q0[t] = *reinterpret_cast<const v4i *>(smem + row * PITCH + c8 * 4);
             q1[t] = *reinterpret_cast<const v4i *>(smem + row * PITCH + c8 * 4 + 16);
-            if (KS == 2) {
+            if (TWO_SLABS) {
                 q0[t] += *reinterpret_cast<const v4i *>(smem + BM * PITCH + row * PITCH + c8 * 4);
                 q1[t] += *reinterpret_cast<const v4i *>(smem + BM * PITCH + row * PITCH + c8 * 4 + 16);
             }
@@ -478,7 +485,7 @@ __global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(G
         if (row >= BM || m >= p.M || n >= p.N) continue;
         v4i q0 = *reinterpret_cast<const v4i *>(smem + row * PITCH + c8 * 4);
         v4i q1 = *reinterpret_cast<const v4i *>(smem + row * PITCH + c8 * 4 + 16);
-        if (KS == 2) {      // the two k groups' partial sums
+        if (TWO_SLABS) {    // the two k groups' partial sums
             q0 += *reinterpret_cast<const v4i *>(smem + BM * PITCH + row * PITCH + c8 * 4);
             q1 += *reinterpret_cast<const v4i *>(smem + BM * PITCH + row * PITCH + c8 * 4 + 16);
         }
@@ -598,6 +605,17 @@ int dispatch_ws(const GemmArgs &p, int tile, hipStream_t st)
         else return launch_ws<128, 128, 1, 4, 1, 4, 4, W_BITS, EPI>(p, st);
     case 45: return launch_ws<96, 128, 1, 4, 2, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI>(p, st);
     case 46: return launch_ws<64, 128, 1, 4, 2, 4, (W_BITS == 4 ? 8 : 6), W_BITS, EPI>(p, st);
+    // Wide wave tiles (two 32-channel fragments per wave, two k groups): 30-45 % fewer LDS bytes per
+    // MFMA than the 1 x 4 / 2 x 4 arrangements -- and the same time per k-step on every model shape
+    // (the k-step is set by the barrier / LDS-DMA / fragment-read pipeline, not by LDS
+    // bandwidth or MFMA issue alone).  Kept selectable for comparison, exact like the others.
+    case 47: return launch_ws<96, 128, 1, 2, 2, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI>(p, st);
+    case 48:
+        if constexpr (W_BITS == 4) return launch_ws<128, 128, 2, 2, 2, 4, 6, W_BITS, EPI>(p, st);
+        else break;
+    case 49:
+        if constexpr (W_BITS == 4) return launch_ws<192, 128, 2, 2, 2, 4, 4, W_BITS, EPI>(p, st);
+        else break;
     default: break;
     }
     return fail(MQ_EINVAL, "gemm_ws: unknown tile %d", tile);

@@ -378,6 +378,45 @@ def rotate_f64_(x: torch.Tensor, signs, K: int, had_words) -> torch.Tensor:
     return x
 
 
+FP8_E4M3_MAX = 448.0
+
+
+@_on_device
+def kv_quant_fp8(kv: torch.Tensor, scale: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """K or V [T, kv_heads, head_dim] (token stride free: a slice of the fused qkv output works in
+    place) -> e4m3fn bytes [T, kv_heads, head_dim] (torch.float8_e4m3fn) with one static scale per head
+    (``mq_kv_quant_fp8``).  scale: float32 [kv_heads] = calibrated absmax / 448."""
+    _need_cuda(kv, scale, out)
+    T, H, D = kv.shape
+    assert kv.stride(2) == 1 and kv.stride(1) == D and scale.dtype == torch.float32 and scale.numel() == H
+    if out is None:
+        out = torch.empty((T, H, D), dtype=torch.float8_e4m3fn, device=kv.device)
+    assert out.dtype == torch.float8_e4m3fn and out.stride(2) == 1 and out.stride(1) == D
+    call("mq_kv_quant_fp8", kv.data_ptr(), dtype_code(kv.dtype), T, H, D, kv.stride(0) if T > 1 else H * D,
+         scale.data_ptr(), out.data_ptr(), out.stride(0) if T > 1 else H * D, _stream())
+    return out
+
+
+@_on_device
+def kv_dequant_fp8(q: torch.Tensor, scale: torch.Tensor, dtype: torch.dtype = torch.float16,
+                   out: torch.Tensor = None) -> torch.Tensor:
+    """e4m3fn cache [T, kv_heads, head_dim] -> ``dtype`` in front of SDPA (``mq_kv_dequant_fp8``)."""
+    _need_cuda(q, scale, out)
+    T, H, D = q.shape
+    assert q.dtype == torch.float8_e4m3fn and q.stride(2) == 1 and q.stride(1) == D and scale.numel() == H
+    if out is None:
+        out = torch.empty((T, H, D), dtype=dtype, device=q.device)
+    assert out.stride(2) == 1 and out.stride(1) == D
+    call("mq_kv_dequant_fp8", q.data_ptr(), T, H, D, q.stride(0) if T > 1 else H * D, scale.data_ptr(),
+         out.data_ptr(), dtype_code(out.dtype), out.stride(0) if T > 1 else H * D, _stream())
+    return out
+
+
+def kv_scale_from_absmax(kv: torch.Tensor) -> torch.Tensor:
+    """Static per-head scale from calibration activations [T, kv_heads, head_dim]: absmax / 448."""
+    return (kv.float().abs().amax(dim=(0, 2)).clamp_min(1e-8) / FP8_E4M3_MAX).contiguous()
+
+
 @_on_device
 def prepack(q: torch.Tensor, bits: int, zero_col0: bool = False) -> torch.Tensor:
     """int levels [N, K] -> the pre-tiled image streamed by gemm_w4a8."""

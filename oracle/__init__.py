@@ -263,3 +263,46 @@ def gptq_block(W1, Hb, scale, bits):
                          _p(Hb, C.c_float), C.c_long(Hb.shape[1]), _p(scale, C.c_float), C.c_int(bits),
                          _p(Q1, C.c_float), C.c_long(cols), _p(E1, C.c_float), C.c_long(cols))
     return Q1, E1
+
+
+def fp8_e4m3fn_encode(x):
+    """float32 array -> OCP e4m3fn bytes (round to nearest even, saturating)."""
+    x = _f32(x)
+    out = np.empty(x.shape, dtype=np.uint8)
+    f = lib().orc_fp8_e4m3fn_encode
+    f.restype, f.argtypes = C.c_uint8, [C.c_float]
+    flat_in, flat_out = x.reshape(-1), out.reshape(-1)
+    for i in range(flat_in.size):
+        flat_out[i] = f(float(flat_in[i]))
+    return out
+
+
+def fp8_e4m3fn_decode(b):
+    b = np.ascontiguousarray(b, dtype=np.uint8)
+    out = np.empty(b.shape, dtype=np.float32)
+    f = lib().orc_fp8_e4m3fn_decode
+    f.restype, f.argtypes = C.c_float, [C.c_uint8]
+    flat_in, flat_out = b.reshape(-1), out.reshape(-1)
+    for i in range(flat_in.size):
+        flat_out[i] = f(int(flat_in[i]))
+    return out
+
+
+def kv_quant_fp8(x, scale):
+    """x [T, H, D] float32 (values of the source dtype), scale [H] -> uint8 e4m3fn [T, H, D]."""
+    x, scale = _f32(x), _f32(scale).reshape(-1)
+    T, H, D = x.shape
+    out = np.empty((T, H, D), dtype=np.uint8)
+    lib().orc_kv_quant_fp8(_p(x, C.c_float), C.c_long(T), C.c_long(H), C.c_long(D), _p(scale, C.c_float),
+                           _p(out, C.c_uint8))
+    return out
+
+
+def kv_dequant_fp8(q, scale, mode=0):
+    """uint8 e4m3fn [T, H, D] -> float32 of the fp32 product rounded to the output dtype (``round_to`` mode)."""
+    q, scale = np.ascontiguousarray(q, dtype=np.uint8), _f32(scale).reshape(-1)
+    T, H, D = q.shape
+    out = np.empty((T, H, D), dtype=np.float32)
+    lib().orc_kv_dequant_fp8(_p(q, C.c_uint8), C.c_long(T), C.c_long(H), C.c_long(D), _p(scale, C.c_float),
+                             _p(out, C.c_float))
+    return round_to(out, mode)

@@ -532,3 +532,58 @@ void orc_gptq_block(const float *W1, long N, long cols, long ldw,
     }
     free(w);
 }
+
+/* ---- fp8 KV cache: NO reference implementation, parity unpinned -------------------
+ * OCP e4m3fn: 1 sign, 4 exponent (bias 7), 3 mantissa bits; no infinities, 0x7F / 0xFF = NaN,
+ * largest finite 448 (0x7E), smallest subnormal 2^-9.  Round to nearest even; finite values that
+ * round beyond 448 saturate to 448 here (the callers clamp first, so this never decides anything);
+ * NaN -> 0x7F.  The codec is pinned to torch.float8_e4m3fn in tests/test_oracle_golden.py. */
+uint8_t orc_fp8_e4m3fn_encode(float x)
+{
+    if (x != x) return 0x7F;
+    const uint8_t sign = signbit(x) ? 0x80 : 0x00;
+    float a = fabsf(x);
+    if (a >= 464.0f) return (uint8_t)(sign | 0x7E);           /* 464 = midpoint of 448 and the absent 480 */
+    if (a < 0.015625f) {                                      /* below the smallest normal 2^-6: step 2^-9 */
+        const float q = rintf(a * 512.0f);                    /* exact scaling, rint = round half to even */
+        return (uint8_t)(sign | (uint8_t)q);                  /* q = 8 is the encoding of 2^-6 itself */
+    }
+    int e;
+    const float m = frexpf(a, &e);                            /* a = m * 2^e, m in [0.5, 1) */
+    float q = rintf(m * 16.0f);                               /* 4 significant bits: 8 .. 16 */
+    int be = e - 1 + 7;                                       /* biased exponent of 1.xxx * 2^(e-1) */
+    if (q == 16.0f) { q = 8.0f; be += 1; }
+    if (be > 15 || (be == 15 && q > 14.0f)) return (uint8_t)(sign | 0x7E);
+    return (uint8_t)(sign | (be << 3) | ((int)q - 8));
+}
+
+float orc_fp8_e4m3fn_decode(uint8_t b)
+{
+    const int e = (b >> 3) & 15, m = b & 7;
+    float v;
+    if (e == 15 && m == 7) return NAN;
+    if (e == 0) v = ldexpf((float)m, -9);
+    else v = ldexpf((float)(8 + m), e - 7 - 3);
+    return (b & 0x80) ? -v : v;
+}
+
+/* write side: x [T][H][D] (already rounded to the cache's source dtype), scale [H] */
+void orc_kv_quant_fp8(const float *x, long T, long H, long D, const float *scale, uint8_t *out)
+{
+    for (long t = 0; t < T; ++t)
+        for (long h = 0; h < H; ++h)
+            for (long d = 0; d < D; ++d) {
+                float q = x[(t * H + h) * D + d] / scale[h];
+                q = fminf(fmaxf(q, -448.0f), 448.0f);
+                out[(t * H + h) * D + d] = orc_fp8_e4m3fn_encode(q);
+            }
+}
+
+/* read side: fp32 product, the caller rounds to the output dtype */
+void orc_kv_dequant_fp8(const uint8_t *q, long T, long H, long D, const float *scale, float *out)
+{
+    for (long t = 0; t < T; ++t)
+        for (long h = 0; h < H; ++h)
+            for (long d = 0; d < D; ++d)
+                out[(t * H + h) * D + d] = orc_fp8_e4m3fn_decode(q[(t * H + h) * D + d]) * scale[h];
+}

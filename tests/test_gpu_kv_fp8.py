@@ -1,0 +1,95 @@
+"""fp8 KV cache kernels (mq_kv_quant_fp8 / mq_kv_dequant_fp8) against the oracle -- bytes
+bit for bit -- and the end-to-end effect on attention at BASELINE configuration 5's shapes
+(Qwen2-VL-72B: 64 heads, 8 KV heads, head_dim 128) against fp16 SDPA.  Parity unpinned: the reference
+has no KV-cache quantization."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+torch.set_grad_enabled(False)
+MODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def _kv(seed, T, H, D, dtype):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    x = torch.randn(T, H, D, generator=g, device=DEV) * torch.tensor([0.05, 1.0, 9.0, 30.0] * (H // 4 + 1), device=DEV)[:H, None]
+    x[0, 0, :8] = torch.tensor([0.0, -0.0, 1e-4, -1e-4, 500.0, -500.0, 0.3, -0.3], device=DEV)
+    return x.to(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("T,H,D", [(1, 1, 8), (77, 4, 128), (1536, 8, 128), (300, 4, 80)])
+def test_write_and_read_equal_the_oracle(dtype, T, H, D):
+    from mquant_amd import ops
+    x = _kv(T + H, T, H, D, dtype)
+    scale = ops.kv_scale_from_absmax(x)
+    if H > 1:
+        scale[1] = scale[1] * 0.25                    # a too small static scale: values saturate at +-448
+    q = ops.kv_quant_fp8(x, scale)
+    assert q.dtype == torch.float8_e4m3fn and q.shape == x.shape
+    want = oracle.kv_quant_fp8(x.float().cpu().numpy(), scale.cpu().numpy())
+    np.testing.assert_array_equal(q.view(torch.uint8).cpu().numpy(), want)
+    if H > 1:
+        assert int((want[:, 1] == 0x7E).sum() + (want[:, 1] == 0xFE).sum()) > 0
+    y = ops.kv_dequant_fp8(q, scale, dtype)
+    ref = oracle.kv_dequant_fp8(want, scale.cpu().numpy(), MODE[dtype])
+    np.testing.assert_array_equal(y.float().cpu().numpy(), ref)
+
+
+def test_slices_of_a_fused_qkv_output_are_read_in_place():
+    from mquant_amd import ops
+    T, HQ, HKV, D = 200, 28, 4, 128
+    g = torch.Generator(device=DEV).manual_seed(3)
+    qkv = torch.randn(T, (HQ + 2 * HKV) * D, generator=g, device=DEV).half()
+    k = qkv[:, HQ * D:(HQ + HKV) * D].view(T, HKV, D)                  # token stride = the fused width
+    assert not k.is_contiguous()
+    scale = ops.kv_scale_from_absmax(k)
+    cache = torch.zeros(T + 5, HKV, D, device=DEV, dtype=torch.uint8).view(torch.float8_e4m3fn)
+    ops.kv_quant_fp8(k, scale, out=cache[5:])
+    want = oracle.kv_quant_fp8(k.float().cpu().numpy(), scale.cpu().numpy())
+    np.testing.assert_array_equal(cache[5:].view(torch.uint8).cpu().numpy(), want)
+    assert int(cache[:5].view(torch.uint8).max()) == 0
+
+
+def test_bad_arguments_are_refused():
+    from mquant_amd import ops
+    from mquant_amd._lib import MQuantHipError
+    x = torch.zeros(4, 2, 12, device=DEV, dtype=torch.float16)           # head_dim % 8
+    with pytest.raises(MQuantHipError):
+        ops.kv_quant_fp8(x, torch.ones(2, device=DEV))
+    with pytest.raises(MQuantHipError):
+        ops.kv_quant_fp8(torch.zeros(4, 2, 16, dtype=torch.float16), torch.ones(2))   # CPU tensors
+
+
+#: attention output with an fp8 KV cache vs fp16 KV, relative Frobenius error.  e4m3 keeps 3 mantissa
+#: bits (<= 2^-4 = 6.25 % per element, ~2 % rms); softmax-weighted sums over hundreds of keys average
+#: the V error down and the K error perturbs the logits by ~2 % of |q.k| / sqrt(d).
+ATTN_REL_TOL = 3e-2
+
+
+@pytest.mark.parametrize("T", [512, 1536])
+def test_attention_with_fp8_kv_stays_near_fp16_sdpa(T):
+    """Configuration 5 shapes: 64 query heads, 8 KV heads, head_dim 128, causal prefill."""
+    from mquant_amd import ops
+    HQ, HKV, D = 64, 8, 128
+    g = torch.Generator(device=DEV).manual_seed(T)
+    q = torch.randn(T, HQ, D, generator=g, device=DEV).half()
+    k = (torch.randn(T, HKV, D, generator=g, device=DEV) * 1.5).half()
+    v = torch.randn(T, HKV, D, generator=g, device=DEV).half()
+    k[:, :, 5] *= 8.0                                                    # an outlier channel, as rotary K has
+    sk, sv = ops.kv_scale_from_absmax(k), ops.kv_scale_from_absmax(v)
+    k8 = ops.kv_dequant_fp8(ops.kv_quant_fp8(k, sk), sk, torch.float16)
+    v8 = ops.kv_dequant_fp8(ops.kv_quant_fp8(v, sv), sv, torch.float16)
+
+    def attn(kk, vv):
+        return F.scaled_dot_product_attention(q.transpose(0, 1)[None], kk.transpose(0, 1)[None], vv.transpose(0, 1)[None],
+                                              is_causal=True, enable_gqa=True)[0].float()
+    ref, got = attn(k, v), attn(k8, v8)
+    rel = float((got - ref).norm() / ref.norm())
+    assert rel < ATTN_REL_TOL, rel
+    assert float((got - ref).abs().max()) < 0.25

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 DTYPES = [torch.float16, torch.bfloat16, torch.float32]
 MODE = {torch.float16: 1, torch.bfloat16: 2, torch.float32: 0}
-WS_TILES = (40, 41, 42, 43, 44, 45, 46)
+WS_TILES = (40, 41, 42, 43, 44, 45, 46, 47, 48, 49)
 
 
 def ops():
@@ -128,8 +128,8 @@ def test_every_wave_specialised_tile_is_exact(w_bits, M, N, K):
     o.splitk_workspace(torch.device(DEV), 64 << 20)
     try:
         for tile in WS_TILES:
-            if w_bits == 8 and tile == 42:
-                continue                      # 192 x 128 exists for int4 weights only
+            if w_bits == 8 and tile in (42, 48, 49):
+                continue                      # these exist for int4 weights only
             for splits in (1, 3):
                 o.gemm_debug_force(tile, splits)
                 acc = o.gemm_w4a8_i32(at, img, w_bits, N)
@@ -301,7 +301,7 @@ def test_every_m_grouping_of_the_xcd_mapping_is_a_bijection(M, N, K):
     img = o.prepack(to_dev(w), 4)
     o.splitk_workspace(torch.device(DEV), 64 << 20)
     try:
-        for tile in (40, 41, 42, 43, 44, 3, 1):
+        for tile in (40, 41, 42, 43, 44, 47, 49, 3, 1):
             for xm in (1, 2, 3, 4, 6, 8):
                 for splits in (1, 2):
                     o.gemm_debug_force(tile, splits | (xm << 8))
