@@ -13,6 +13,15 @@ __device__ __forceinline__ void dma16(const void *g, void *lds_wave_base)
     __builtin_amdgcn_global_load_lds((gbl_void *)g, (lds_void *)lds_wave_base, 16, 0, 0);
 }
 
+// The same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane offset: the address needs no
+// vector-ALU instruction, so a loader wave never queues for the VALU port behind the math waves' MFMAs
+// (and consecutive DMAs do not serialise on one reused address register pair).
+__device__ __forceinline__ void dma16_s(const char *uniform_base, unsigned lane_off, unsigned lds_wave_base)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0"
+                 :: "s"(uniform_base), "v"(lane_off), "s"(lds_wave_base) : "memory");
+}
+
 enum { EPI_F16 = MQ_F16, EPI_BF16 = MQ_BF16, EPI_F32 = MQ_F32, EPI_I32 = 3 };
 
 // Experiment switch for bottleneck hunting (never set in the shipped build): 1 = no DMA inside the

@@ -107,6 +107,7 @@ __global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(G
         const int lw = wave - NM;
         __builtin_amdgcn_s_setprio(2);               // a loader's few instructions go ahead of the math waves' streams
         const long KT = p.K_pad >> 6, MT = (p.M + 15) >> 4;
+        // piece f of a stage: wave-uniform base (SGPRs) + lane * 16
         const char *src[LPW];
 #pragma unroll
         for (int i = 0; i < LPW; ++i) {
@@ -114,23 +115,25 @@ __global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(G
             if (f < A_PIECES) {
                 long mt = m0 / 16 + (f >> 1);
                 if (mt >= MT) mt = MT - 1;
-                src[i] = reinterpret_cast<const char *>(p.a) + ((mt * KT + k_begin * 2 + (f & 1)) * 64 + lane) * 16;
+                src[i] = reinterpret_cast<const char *>(p.a) + (mt * KT + k_begin * 2 + (f & 1)) * 1024;
             } else if (W_BITS == 4) {
                 const int g = f - A_PIECES;
                 long ntp = nt0 / 2 + (g >> 1);
                 if (ntp >= p.n_pairs) ntp = p.n_pairs - 1;
-                src[i] = reinterpret_cast<const char *>(p.w) + (((ntp * kps + k_begin) * 2 + (g & 1)) * 64 + lane) * 16;
+                src[i] = reinterpret_cast<const char *>(p.w) + ((ntp * kps + k_begin) * 2 + (g & 1)) * 1024;
             } else {
                 const int g = f - A_PIECES;
                 long nt = nt0 + (g >> 1);
                 if (nt >= p.n_tiles) nt = p.n_tiles - 1;
-                src[i] = reinterpret_cast<const char *>(p.w) + (((nt * kps + k_begin) * 2 + (g & 1)) * 64 + lane) * 16;
+                src[i] = reinterpret_cast<const char *>(p.w) + ((nt * kps + k_begin) * 2 + (g & 1)) * 1024;
             }
         }
+        const unsigned lane_off = lane * 16;
+        const unsigned lds0 = (unsigned)(size_t)(lds_void *)smem;
         auto issue = [&](int slot, int st) {
-            char *base = smem + slot * STAGE;
+            const unsigned base = lds0 + slot * STAGE;
 #pragma unroll
-            for (int i = 0; i < LPW; ++i) dma16(src[i] + (long)st * 2048, base + (lw + i * NL) * 1024);
+            for (int i = 0; i < LPW; ++i) dma16_s(src[i] + (long)st * 2048, lane_off, base + (lw + i * NL) * 1024);
         };
         auto wait_younger = [&](int younger) {      // at most `younger` stages may still be in flight
 #define MQ_WS_WAIT(k) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((k) * LPW < 64 ? (k) * LPW : 0) : "memory")
