@@ -66,7 +66,7 @@ __global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(G
     constexpr int PITCH = BN * 4 + 16;              // epilogue slab row pitch (bytes)
     static_assert(BM % (MW_M * 32) == 0 && BN % (MW_N * 32) == 0, "tile shape");
     static_assert(PIECES % NL == 0, "pieces must divide over the loader waves");
-    static_assert(S >= 4 && S <= 8 && (S - 3) * LPW < 64, "ring depth (vmcnt is 6 bits)");
+    static_assert(S >= 4 && S <= 8 && (S - 2) * LPW < 64, "ring depth (vmcnt is 6 bits)");
     static_assert(KS == 1 || KS == 2, "k groups");
     static_assert(BM * PITCH <= RING, "epilogue slab must fit the ring");
     constexpr bool TWO_SLABS = (KS == 2) && (2 * BM * PITCH <= RING);   // else the k groups are added through one slab
@@ -618,6 +618,13 @@ int dispatch_ws(const GemmArgs &p, int tile, hipStream_t st)
         else break;
     case 49:
         if constexpr (W_BITS == 4) return launch_ws<192, 128, 2, 2, 2, 4, 4, W_BITS, EPI>(p, st);
+        else break;
+    // the same wave tiles with one k group (four math waves)
+    case 50:
+        if constexpr (W_BITS == 4) return launch_ws<192, 128, 2, 2, 1, 4, 4, W_BITS, EPI>(p, st);
+        else break;
+    case 51:
+        if constexpr (W_BITS == 4) return launch_ws<128, 128, 2, 2, 1, 4, 6, W_BITS, EPI>(p, st);
         else break;
     default: break;
     }

@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--bits", type=int, default=4)
     ap.add_argument("--tiled", action="store_true", help="activations in the tiled layout for every config (ids >= 40 always)")
+    ap.add_argument("--cold", action="store_true",
+                    help="rotate over enough copies of the weight image (> 600 MB) that every call streams it from HBM, as in the prefill")
     args = ap.parse_args()
     cfgs = [tuple(int(v) for v in c.split(":")) for c in args.configs.split(",")]
     dev = torch.device("cuda:0")
@@ -65,7 +67,17 @@ def main():
             aa = a_t if (args.tiled or tile >= 40) else a
             acc = ops.gemm_w4a8_i32(aa, img, args.bits, N)
             ok = bool(torch.equal(acc, ref)) and bool(torch.equal(ops.gemm_w4a8(aa, img, args.bits, N, 0.02, s_w), yref))
-            us = bench(lambda: ops.gemm_w4a8(aa, img, args.bits, N, 0.02, s_w, out=out))
+            if args.cold:
+                copies = [img] + [img.clone() for _ in range(max(1, int(600e6 // max(img.numel(), 1))))]
+                state = {"i": 0}
+
+                def call_cold():
+                    state["i"] = (state["i"] + 1) % len(copies)
+                    ops.gemm_w4a8(aa, copies[state["i"]], args.bits, N, 0.02, s_w, out=out)
+                us = bench(call_cold, iters=max(20, 2 * len(copies)))
+                del copies
+            else:
+                us = bench(lambda: ops.gemm_w4a8(aa, img, args.bits, N, 0.02, s_w, out=out))
             cols.append(f"{us:8.1f} {2.0 * M * N * K / us / 1e6:7.0f}{'' if ok else ' MISMATCH'}")
         print(f"{name:14s} {M:5d} {N:6d} {K:6d} | " + " | ".join(cols))
     ops.gemm_debug_force(-1, 0)
