@@ -11,7 +11,7 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 struct Args { int n; int *sink; };
 
 // MODE bit 0: waves 0-3 run 32x32x32 MFMAs; bit 1: waves 4-7 run VALU; bit 2: waves 4-7 run ds_read_b128;
-// bit 3: the MFMA waves use the 16x16x64 form
+// bit 3: the MFMA waves use the 16x16x64 form; bit 4: they use the fp32 form V_MFMA_F32_16X16X4_F32 (the Hadamard K x K stage)
 template <int MODE>
 __global__ __launch_bounds__(512) void k(Args p)
 {
@@ -22,7 +22,21 @@ __global__ __launch_bounds__(512) void k(Args p)
     int t = 0;
     if (wave < 4) {
         if (MODE & 1) {
-            if (MODE & 8) {
+            if (MODE & 16) {
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                v4f acc[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc[j] = v4f{0.f, 0.f, 0.f, 0.f};
+                const float a = (float)lane, b = (float)(lane + 1);
+                for (int it = 0; it < p.n; ++it) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < 6; ++j) t ^= (int)acc[j][0];
+            } else if (MODE & 8) {
                 v4i acc[6];
 #pragma unroll
                 for (int j = 0; j < 6; ++j) acc[j] = v4i{0, 0, 0, 0};
@@ -105,5 +119,8 @@ int main()
     run<9>("16x16x64 MFMA waves alone (12 per iteration)");
     run<11>("16x16x64 MFMA waves + VALU waves");
     run<13>("16x16x64 MFMA waves + ds_read waves");
+    run<17>("fp32 16x16x4 MFMA waves alone (24 per iteration)");
+    run<19>("fp32 16x16x4 MFMA waves + VALU waves on the same SIMDs");
+    run<21>("fp32 16x16x4 MFMA waves + ds_read waves on the same SIMDs");
     return 0;
 }
