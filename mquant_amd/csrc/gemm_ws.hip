@@ -149,60 +149,66 @@ __global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(G
             default: MQ_WS_WAIT(0); break;
             }
         };
-        const int pre = nk < S ? nk : S;
+        // Ring fill.  The first stages of a launch come from HBM and a CU keeps only so many misses in
+        // flight: issuing the whole ring takes ~4000 cycles (tools/gemm_stamps.py), all of it in front of
+        // the first MFMA if B(0) waits for it.  Only PRE0 stages go out before B(0); the rest of the ring
+        // is filled at most two stages per k-step while the math waves already work (a stage is consumed
+        // more slowly than it arrives, so the ring fills up behind them).
+#ifndef MQ_PRE0
+#define MQ_PRE0 3
+#endif
+        constexpr int PRE0 = (MQ_PRE0 > 0 && MQ_PRE0 < S) ? MQ_PRE0 : S;
+        const int pre0 = nk < PRE0 ? nk : PRE0;
 #pragma unroll
-        for (int s = 0; s < S; ++s)
-            if (s < pre) issue(s, s);
+        for (int s = 0; s < PRE0; ++s)
+            if (s < pre0) issue(s, s);
         MQ_STAMP_AT(1);
-        wait_younger(pre - 1);                       // stage 0 landed
+        wait_younger(pre0 - 1);                      // stage 0 landed
         MQ_STAMP_AT(2);
         __builtin_amdgcn_s_barrier();                // B(0)
         MQ_STAMP_AT(3);
-        int last = pre - 1;                          // last stage issued
-        int slot = S - 1;                            // slot of stage it-1 (refilled at B(it+1)), it = 0: none
+        int last = pre0 - 1;                         // last stage issued
+        int slot = pre0 == S ? 0 : pre0;             // slot of stage last + 1
         long long tw = 0, tb = 0, ti = 0, tt = MQ_STAMP_T();
         for (int it = 0; it < nk; ++it) {
             const int need = it + 1 < nk ? it + 1 : nk - 1;
             const int younger = last - need;
             if (younger == S - 3) MQ_WS_WAIT(S - 3);   // steady state: S-3 stages stay in flight across the barrier
             else wait_younger(younger > 0 ? younger : 0);
-            __builtin_amdgcn_s_barrier();            // B(it+1)
+            __builtin_amdgcn_s_barrier();            // B(it+1): every math wave has finished step it-1
             MQ_STAMP_ACC(tb, tt);
 #ifdef MQ_STAMP
             if (it < 200) MQ_STAMP_PUT(32 + it, tt);   // barrier release times = step boundaries
 #endif
-            if (it >= 1 && last + 1 < nk) {
-                if (MQ_EXP != 6) issue(slot, last + 1);   // MQ_EXP 6: timing experiment, no LDS-DMA inside the k-loop
-                ++last;
+            // stages up to it-1+S fit the ring now
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (last + 1 < nk && last + 1 <= it - 1 + S) {
+                    if (MQ_EXP != 6) issue(slot, last + 1);   // MQ_EXP 6: timing experiment, no LDS-DMA inside the k-loop
+                    ++last;
+                    if (++slot == S) slot = 0;
+                }
             }
-            if (++slot == S) slot = 0;
         }
         MQ_STAMP_PUT(16, tw); MQ_STAMP_PUT(17, tb); MQ_STAMP_PUT(18, ti);
         __builtin_amdgcn_s_setprio(0);
     } else {
         // =========================== math waves =============================================
         const int kg = wave / NMT, wm = (wave % NMT) / MW_N, wn = wave % MW_N;
-        // epilogue parameters -> LDS while the loaders fill the first stage
-        {
-            const int t = tid;                       // 0 .. NM*64-1
-            if (t < BN && EPI != EPI_I32) {
-                const long n = n0 + t;
-                const bool ok = n < p.N;
-                par_sw[t] = ok ? p.s_w[n] : 0.0f;
-                par_bs[t] = (ok && p.bias) ? p.bias[n] : 0.0f;
-                par_wz[t] = (ok && p.w0) ? p.w0[n] : 0.0f;
-            }
-            if (t < BM && EPI != EPI_I32) {
-                const long m = m0 + t;
-                float sx = p.sx0, xz = 0.0f;
-                if (m < p.M) {
-                    if (p.sx_vec) sx = p.sx_vec[m];
-                    else if (p.row_sel && p.row_sel[m]) sx = p.sx1;
-                    if (p.x0) xz = p.x0[m];
-                }
-                par_sx[t] = sx;
-                par_xz[t] = xz;
-            }
+        // Epilogue parameters: straight-line loads at clamped indices now (no use before the k-loop ends,
+        // so B(0) does not wait for these cold misses), selected and parked in LDS after the loop.
+        float pr_sw = 0.0f, pr_bs = 0.0f, pr_wz = 0.0f, pr_sx = 0.0f, pr_xz = 0.0f;
+        unsigned pr_rs = 0;
+        if (EPI != EPI_I32) {
+            const int tn = tid < BN ? tid : BN - 1, tm = tid < BM ? tid : BM - 1;
+            const long nc = n0 + tn < p.N ? n0 + tn : p.N - 1;
+            const long mc = m0 + tm < p.M ? m0 + tm : p.M - 1;
+            pr_sw = p.s_w[nc];
+            pr_bs = (p.bias ? p.bias : p.s_w)[nc];
+            pr_wz = (p.w0 ? p.w0 : p.s_w)[nc];
+            pr_sx = (p.sx_vec ? p.sx_vec : p.s_w)[p.sx_vec ? mc : 0];
+            pr_xz = (p.x0 ? p.x0 : p.s_w)[p.x0 ? mc : 0];
+            pr_rs = (p.row_sel ? p.row_sel : reinterpret_cast<const uint8_t *>(p.s_w))[p.row_sel ? mc : 0];
         }
 #pragma unroll
         for (int a = 0; a < NACC; ++a)
@@ -364,6 +370,24 @@ __global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(G
             for (int i = 0; i < TN; ++i)
 #pragma unroll
                 for (int j = 0; j < TM; ++j) acc[0][i][j] += acc[1][i][j];
+        }
+        if (EPI != EPI_I32) {                        // the parameter block sits behind the ring
+            if (tid < BN) {
+                const bool ok = n0 + tid < p.N;
+                par_sw[tid] = ok ? pr_sw : 0.0f;
+                par_bs[tid] = (ok && p.bias) ? pr_bs : 0.0f;
+                par_wz[tid] = (ok && p.w0) ? pr_wz : 0.0f;
+            }
+            if (tid < BM) {
+                const bool ok = m0 + tid < p.M;
+                float sx = p.sx0;
+                if (ok) {
+                    if (p.sx_vec) sx = pr_sx;
+                    else if (p.row_sel && pr_rs) sx = p.sx1;
+                }
+                par_sx[tid] = sx;
+                par_xz[tid] = (ok && p.x0) ? pr_xz : 0.0f;
+            }
         }
     }
 
