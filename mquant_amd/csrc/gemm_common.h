@@ -276,11 +276,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][
             v4i q1 = *reinterpret_cast<const v4i *>(slab + row * SLAB_LD + c8 * 4 + 16);
             if (m >= p.M || n >= p.N) continue;
             int a[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
-            if (W_BITS == 4) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) a[e] >>= 4;
-            }
             if (to_partial || EPI == EPI_I32) {
+                if (W_BITS == 4) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a[e] >>= 4;
+                }
                 int *o = to_partial ? p.partial + ((long)split * p.M + m) * p.N + n
                                     : reinterpret_cast<int *>(p.out) + m * p.ldo + n;
                 if (n_full) {
@@ -292,7 +292,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][
                 }
                 continue;
             }
-            const float sx = rowpar[row * 2];
+            // int4 weights: the accumulator carries a factor 16; float(16 a) * (s_x / 16) is the same real
+            // product as float(a) * s_x (exact power-of-two rescale on both sides): same bits, no shift
+            const float sx = (W_BITS == 4) ? rowpar[row * 2] * 0.0625f : rowpar[row * 2];
             const float xz = rowpar[row * 2 + 1];
             float res[8];
             if (p.residual) {   // issued ahead of the arithmetic below
@@ -317,21 +319,29 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][
                 }
             }
             float y[8];
+            typedef float v2f __attribute__((ext_vector_type(2)));   // v_pk_mul_f32 / v_pk_add_f32: two outputs per instruction
+            const v2f sx2 = v2f{sx, sx}, xz2 = v2f{xz, xz};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float t = (float)a[e] * sx;
-                t = t * swv[e];
-                if (p.bias) t = t + bsv[e];
+            for (int e = 0; e < 8; e += 2) {
+                v2f t = v2f{(float)a[e], (float)a[e + 1]};
+                t = t * sx2;
+                t = t * v2f{swv[e], swv[e + 1]};
+                if (p.bias) t = t + v2f{bsv[e], bsv[e + 1]};
                 if (p.x0) {
-                    const float pr = xz * wzv[e];
+                    const v2f pr = xz2 * v2f{wzv[e], wzv[e + 1]};
                     t = t + pr;
                 }
-                if (p.residual) {   // torch: hidden + linear(x), the Linear's output rounded first
+                y[e] = t[0];
+                y[e + 1] = t[1];
+            }
+            if (p.residual) {   // torch: hidden + linear(x), the Linear's output rounded first
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float t = y[e];
                     if (EPI == EPI_F16) t = f16_bits_to_f32(f32_to_f16_bits(t));
                     if (EPI == EPI_BF16) t = bf16_bits_to_f32(f32_to_bf16_bits(t));
-                    t = t + res[e];
+                    y[e] = t + res[e];
                 }
-                y[e] = t;
             }
             if (EPI == EPI_F32) {
                 float *o = reinterpret_cast<float *>(p.out) + m * p.ldo + n;

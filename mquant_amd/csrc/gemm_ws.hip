@@ -471,23 +471,39 @@ __global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(G
             sxr[t] = par_sx[row];
             xzr[t] = par_xz[row];
         }
+        // Packed fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32: two outputs per instruction, each lane
+        // element rounded like the scalar form).  int4 weights: the accumulator carries a factor 16
+        // (levels sit in the high nibble); float(16 a) * (s_x / 16) is the same real product as
+        // float(a) * s_x with an exact power-of-two rescale on both sides, so one rounding, same bits,
+        // and the shift is gone.
+        typedef float v2f __attribute__((ext_vector_type(2)));
         const bool has_bias = p.bias != nullptr, has_x0 = p.x0 != nullptr;
+        v2f sw2[4], bs2[4], wz2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sw2[e] = v2f{swv[2 * e], swv[2 * e + 1]};
+            bs2[e] = v2f{bsv[2 * e], bsv[2 * e + 1]};
+            wz2[e] = v2f{wzv[2 * e], wzv[2 * e + 1]};
+        }
 #pragma unroll
         for (int t = 0; t < ITERS; ++t) {
             const long m = m0 + t * RPI + lrow;
-            int a[8] = {q0[t][0], q0[t][1], q0[t][2], q0[t][3], q1[t][0], q1[t][1], q1[t][2], q1[t][3]};
+            const int a[8] = {q0[t][0], q0[t][1], q0[t][2], q0[t][3], q1[t][0], q1[t][1], q1[t][2], q1[t][3]};
+            const float sxe = (W_BITS == 4) ? sxr[t] * 0.0625f : sxr[t];
+            const v2f sx2 = v2f{sxe, sxe}, xz2 = v2f{xzr[t], xzr[t]};
             float y[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (W_BITS == 4) a[e] >>= 4;
-                float v = (float)a[e] * sxr[t];
-                v = v * swv[e];
-                if (has_bias) v = v + bsv[e];
+            for (int e = 0; e < 4; ++e) {
+                v2f v = v2f{(float)a[2 * e], (float)a[2 * e + 1]};
+                v = v * sx2;
+                v = v * sw2[e];
+                if (has_bias) v = v + bs2[e];
                 if (has_x0) {
-                    const float pr = xzr[t] * wzv[e];
+                    const v2f pr = xz2 * wz2[e];
                     v = v + pr;
                 }
-                y[e] = v;
+                y[2 * e] = v[0];
+                y[2 * e + 1] = v[1];
             }
             if (m >= p.M || t * RPI + lrow >= BM) continue;
             if (EPI == EPI_F32) {
