@@ -68,13 +68,13 @@ __global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(G
     static_assert(PIECES % NL == 0, "pieces must divide over the loader waves");
     static_assert(S >= 4 && S <= 8 && (S - 2) * LPW < 64, "ring depth (vmcnt is 6 bits)");
     static_assert(KS == 1 || KS == 2, "k groups");
-    static_assert(BM * PITCH <= RING, "epilogue slab must fit the ring");
+    constexpr int BODY = RING > BM * PITCH ? RING : BM * PITCH;   // the epilogue slab reuses the ring (and may exceed it)
     constexpr bool TWO_SLABS = (KS == 2) && (2 * BM * PITCH <= RING);   // else the k groups are added through one slab
     static_assert(NM * 64 >= BN && NM * 64 >= BM, "parameter prefetch: one thread per channel / row");
     static_assert(KS == 1 || (W_BITS == 4 ? true : true), "k groups");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *par_sw = reinterpret_cast<float *>(smem + RING);      // [BN] weight scales
+    float *par_sw = reinterpret_cast<float *>(smem + BODY);      // [BN] weight scales
     float *par_bs = par_sw + BN;                                  // [BN] bias
     float *par_wz = par_bs + BN;                                  // [BN] w0 (split term)
     float *par_sx = par_wz + BN;                                  // [BM] activation scale of the row
@@ -619,7 +619,8 @@ template <int BM, int BN, int MW_M, int MW_N, int KS, int NL, int S, int W_BITS,
 static int launch_ws(const GemmArgs &p, hipStream_t st)
 {
     constexpr int PIECES = (BM / 16) * 2 + ((W_BITS == 4) ? (BN / 32) * 2 : (BN / 16) * 2);
-    constexpr int SMEM = S * PIECES * 1024 + (3 * BN + 2 * BM) * 4;
+    constexpr int RING = S * PIECES * 1024, SLAB = BM * (BN * 4 + 16);
+    constexpr int SMEM = (RING > SLAB ? RING : SLAB) + (3 * BN + 2 * BM) * 4;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
     auto kern = gemm_ws_kernel<BM, BN, MW_M, MW_N, KS, NL, S, W_BITS, EPI>;
     int rc = ensure_dynamic_lds((const void *)kern, SMEM);
