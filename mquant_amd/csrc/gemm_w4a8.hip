@@ -473,7 +473,10 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
         }
     }
     if (t256 >= 192) {
-        pl.tile = 3;
+        // gate|up: with tiled activations the software-pipelined 8-wave kernel (register double
+        // buffering of the fragments) is ~5 % ahead of the 16-wave one (104-107 vs 110-112 us), with
+        // row-major activations it is behind
+        pl.tile = (w4 && a_tiled) ? 13 : 3;
     } else if (a_tiled && best >= 0 && ceil_div(M, 96) * ceil_div(N, 128) >= 128) {
         // enough 96..192 x 128 tiles for most CUs: the wave-specialised kernel walks the whole reduction
         // (down_proj, K = 19968: 64 us against 60 + 14 us for split-K partials plus the reduce kernel)
