@@ -405,11 +405,13 @@ class ActQuantWrapper(torch.nn.Module):
                 and all(p == 0 for p in mod.padding) and mod.groups == 1)
 
     def _dynamic_real_ok(self) -> bool:
-        """Dynamic symmetric per-token int8 (the reference's default activation mode,
-        quant_utils.py:205-268) also has a real-integer kernel pair."""
+        """Dynamic per-token int8 (the reference's default activation mode, quant_utils.py:205-268) also
+        has real-integer kernels: symmetric, and asymmetric (``--a_asym``) when the wrapper is not split
+        (the zero point travels through the same rank-1 epilogue term as the split column)."""
         qz = self.quantizer
-        return (qz.bits <= 8 and qz.bits >= 2 and getattr(qz, "sym", False) and not qz.act_per_tensor
-                and getattr(qz, "groupsize", -1) <= 0)
+        if not (2 <= qz.bits <= 8) or qz.act_per_tensor or getattr(qz, "groupsize", -1) > 0:
+            return False
+        return bool(getattr(qz, "sym", False)) or not self.split
 
     def _build_real(self, device):
         from mquant_amd import ops
@@ -450,7 +452,7 @@ class ActQuantWrapper(torch.nn.Module):
             if qz.msq:
                 s1 = float(qz.quantizer_text.scale) if qz.quantizer_text.scale is not None else s0
         else:
-            dynamic = dict(bits=int(qz.bits), clip_ratio=float(qz.clip_ratio))
+            dynamic = dict(bits=int(qz.bits), clip_ratio=float(qz.clip_ratio), sym=bool(qz.sym))
         self._real = W4A8Linear(levels, scale, wq.bits,
                                 None if bias is None else bias.data.to(device), s0, s1,
                                 had=had, w0=w0, dynamic=dynamic)

@@ -186,6 +186,17 @@ int mq_quantize_act_dyn_i8(const void *x, int x_dtype, long M, long K, long ldx,
                            float clip_ratio, int skip_col0, float *x0_out, float *scale_out,
                            int8_t *out, long K_pad, long ldo, void *stream);
 
+/* The ASYMMETRIC variant (--a_asym without --*_static; quant_utils.py:239-268 else-branch + asym_quant
+ * :27-31), maxq = 2^bits - 1, per row m:
+ *   xmin / xmax as above (both 0 -> -1 / +1); scale = (xmax - xmin) / maxq; zero = rint(-xmin / scale)
+ *   q = clamp(rint(x / scale) + zero, 0, maxq);  out[m][k] = q - 2^(bits-1)  (int8), zero for k >= K
+ *   shift_out[m] = scale * (2^(bits-1) - zero):  x_hat[m][k] = scale * out[m][k] + shift_out[m]
+ * Pair with mq_gemm_w4a8_rowscale_ws(s_x_rows = scale_out, x0 = shift_out, w0[n] = s_w[n] * sum_k q_w[n][k]):
+ * the rank-1 epilogue term restores offset and zero point.  zero_out may be NULL. */
+int mq_quantize_act_dyn_asym_i8(const void *x, int x_dtype, long M, long K, long ldx, int bits,
+                                float clip_ratio, float *scale_out, float *zero_out, float *shift_out,
+                                int8_t *out, long K_pad, long ldo, void *stream);
+
 /* ---------------------------------------------------------------------------
  * RMSN + static quantizer in one pass.  Replaces module_util.RMSN.forward
  * (module_util.py:55-61) followed by UniformQuantizer.quant (uniform.py:20-33):

@@ -20,12 +20,14 @@ struct DqArgs {
     float clip, maxq;
     int skip_col0;
     float *x0_out, *scale_out;
+    float *zero_out, *shift_out;   // asymmetric mode: zero point and scale * (2^(bits-1) - zero) per row
+    float half;                    // asymmetric mode: 2^(bits-1), the offset of the stored levels
     int8_t *out;
     long K_pad, ldo;
     int vec_ok;
 };
 
-template <int DT>
+template <int DT, bool ASYM = false>
 __global__ __launch_bounds__(DQ_THREADS) void act_quant_dyn_kernel(DqArgs p)
 {
     typedef typename Elem<DT>::T T;
@@ -81,11 +83,26 @@ __global__ __launch_bounds__(DQ_THREADS) void act_quant_dyn_kernel(DqArgs p)
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < DQ_THREADS / 64; ++w) { mn = fminf(mn, rmin[w]); mx = fmaxf(mx, rmax[w]); }
-    const float xmin = mn * p.clip, xmax0 = mx * p.clip;
-    const float xmax = fmaxf(fabsf(xmin), xmax0);
-    const float s = (xmax == 0.0f) ? 1.0f : xmax / p.maxq;
-    if (t == 0 && p.scale_out) p.scale_out[row] = s;
-    const float lo = -(p.maxq + 1.0f), hi = p.maxq;
+    float xmin = mn * p.clip, xmax0 = mx * p.clip;
+    float s, zero = 0.0f, lo, hi;
+    if (ASYM) {                                         // quant_utils.py:255-268 + asym_quant :27-31
+        if (xmin == 0.0f && xmax0 == 0.0f) { xmin = -1.0f; xmax0 = 1.0f; }
+        s = (xmax0 - xmin) / p.maxq;
+        zero = rintf(-xmin / s);
+        lo = 0.0f;
+        hi = p.maxq;
+        if (t == 0) {
+            if (p.scale_out) p.scale_out[row] = s;
+            if (p.zero_out) p.zero_out[row] = zero;
+            if (p.shift_out) p.shift_out[row] = s * (p.half - zero);
+        }
+    } else {
+        const float xmax = fmaxf(fabsf(xmin), xmax0);
+        s = (xmax == 0.0f) ? 1.0f : xmax / p.maxq;
+        if (t == 0 && p.scale_out) p.scale_out[row] = s;
+        lo = -(p.maxq + 1.0f);
+        hi = p.maxq;
+    }
 
 #pragma unroll
     for (int c = 0; c < DQ_MAX_CHUNKS; ++c) {
@@ -93,7 +110,15 @@ __global__ __launch_bounds__(DQ_THREADS) void act_quant_dyn_kernel(DqArgs p)
         if (ch < chunks) {
             int q[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) q[i] = (ch * 16 + i < p.K) ? quant_level(v[c][i], s, lo, hi) : 0;
+            for (int i = 0; i < 16; ++i) {
+                if (ASYM) {      // clamp(rint(x / s) + zero, 0, maxq), stored minus 2^(bits-1); pad columns 0 (their weights are 0)
+                    float lv = rintf(v[c][i] / s) + zero;
+                    lv = fminf(fmaxf(lv, lo), hi);
+                    q[i] = (ch * 16 + i < p.K) ? (int)(lv - p.half) : 0;
+                } else {
+                    q[i] = (ch * 16 + i < p.K) ? quant_level(v[c][i], s, lo, hi) : 0;
+                }
+            }
             if (p.skip_col0 && ch == 0) {
                 if (p.x0_out) p.x0_out[row] = v[c][0];
                 q[0] = 0;
@@ -128,6 +153,7 @@ extern "C" int mq_quantize_act_dyn_i8(const void *x, int x_dtype, long M, long K
     DqArgs p;
     p.x = x; p.M = M; p.K = K; p.ldx = ldx; p.clip = clip_ratio; p.maxq = (float)((1 << (bits - 1)) - 1);
     p.skip_col0 = skip_col0; p.x0_out = x0_out; p.scale_out = scale_out; p.out = out; p.K_pad = K_pad; p.ldo = ldo;
+    p.zero_out = nullptr; p.shift_out = nullptr; p.half = 0.0f;
     const size_t esz = (x_dtype == MQ_F32) ? 4 : 2;
     p.vec_ok = (((uintptr_t)x) % 16 == 0) && ((ldx * esz) % 16 == 0);
     hipStream_t st = (hipStream_t)stream;
@@ -138,4 +164,39 @@ extern "C" int mq_quantize_act_dyn_i8(const void *x, int x_dtype, long M, long K
     default: return fail(MQ_EINVAL, "mq_quantize_act_dyn_i8: unknown dtype %d", x_dtype);
     }
     return check_launch("quantize_act_dyn_i8");
+}
+
+/* Dynamic ASYMMETRIC per-token quantizer (--a_asym without --*_static; quant_utils.py:239-268 else-branch):
+ *   scale = (xmax - xmin) / (2^bits - 1), zero = rint(-xmin / scale), q = clamp(rint(x / scale) + zero, 0, 2^bits - 1)
+ * The int8 GEMM gets q - 2^(bits-1); shift_out[m] = scale * (2^(bits-1) - zero) is the row factor of the
+ * rank-1 term that undoes the offset and the zero point: x_hat = scale * stored + shift, so
+ *   y[m][n] = ((acc * scale[m]) * s_w[n]) + bias[n] + shift[m] * (s_w[n] * sum_k q_w[n][k])
+ * (mq_gemm_w4a8_rowscale_ws with x0 = shift_out and w0 = s_w * column sums of the weight levels). */
+extern "C" int mq_quantize_act_dyn_asym_i8(const void *x, int x_dtype, long M, long K, long ldx, int bits,
+                                           float clip_ratio, float *scale_out, float *zero_out, float *shift_out,
+                                           int8_t *out, long K_pad, long ldo, void *stream)
+{
+    using namespace mq;
+    if (M == 0) return MQ_OK;
+    MQ_REQUIRE(x && out && scale_out && shift_out && M >= 0 && K > 0 && ldx >= K, "mq_quantize_act_dyn_asym_i8: bad shape");
+    MQ_REQUIRE(bits >= 2 && bits <= 8, "mq_quantize_act_dyn_asym_i8: bits must be 2..8");
+    MQ_REQUIRE(K <= 16L * DQ_THREADS * DQ_MAX_CHUNKS, "mq_quantize_act_dyn_asym_i8: K=%ld too large (max %d)", K, 16 * DQ_THREADS * DQ_MAX_CHUNKS);
+    MQ_REQUIRE(K_pad >= K && K_pad % 16 == 0 && ((uintptr_t)out) % 16 == 0 &&
+                   (ldo == MQ_LD_TILED ? K_pad % 64 == 0 : (ldo >= K_pad && ldo % 16 == 0)),
+               "mq_quantize_act_dyn_asym_i8: bad K_pad / ldo / alignment");
+    DqArgs p;
+    p.x = x; p.M = M; p.K = K; p.ldx = ldx; p.clip = clip_ratio; p.maxq = (float)((1 << bits) - 1);
+    p.half = (float)(1 << (bits - 1));
+    p.skip_col0 = 0; p.x0_out = nullptr; p.scale_out = scale_out; p.zero_out = zero_out; p.shift_out = shift_out;
+    p.out = out; p.K_pad = K_pad; p.ldo = ldo;
+    const size_t esz = (x_dtype == MQ_F32) ? 4 : 2;
+    p.vec_ok = (((uintptr_t)x) % 16 == 0) && ((ldx * esz) % 16 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    switch (x_dtype) {
+    case MQ_F16: hipLaunchKernelGGL((act_quant_dyn_kernel<MQ_F16, true>), dim3((unsigned)M), dim3(DQ_THREADS), 0, st, p); break;
+    case MQ_BF16: hipLaunchKernelGGL((act_quant_dyn_kernel<MQ_BF16, true>), dim3((unsigned)M), dim3(DQ_THREADS), 0, st, p); break;
+    case MQ_F32: hipLaunchKernelGGL((act_quant_dyn_kernel<MQ_F32, true>), dim3((unsigned)M), dim3(DQ_THREADS), 0, st, p); break;
+    default: return fail(MQ_EINVAL, "mq_quantize_act_dyn_asym_i8: unknown dtype %d", x_dtype);
+    }
+    return check_launch("quantize_act_dyn_asym_i8");
 }

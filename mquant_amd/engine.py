@@ -82,8 +82,14 @@ class W4A8Linear:
         self.s_x0 = float(s_x0)
         self.s_x1 = None if s_x1 is None else float(s_x1)
         self.had = had
-        #: None = static scales; dict(bits=, clip_ratio=) = dynamic symmetric per-token quantizer
+        #: None = static scales; dict(bits=, clip_ratio=, sym=) = dynamic per-token quantizer (symmetric, or
+        #: asymmetric: the zero point and the storage offset come back through the rank-1 epilogue term
+        #: shift[m] * (s_w[n] * sum_k q_w[n][k]), which is the slot the split column uses -- not both)
         self.dynamic = dynamic
+        self.w_colsum = None
+        if dynamic is not None and not dynamic.get("sym", True):
+            assert not self.split, "asymmetric activations and the split column share the rank-1 epilogue term"
+            self.w_colsum = (levels.to(torch.int32).sum(dim=1).to(torch.float32) * self.s_w).contiguous()
         self.in_features = self.K if in_features is None else in_features
         if had is not None:
             assert had.n == self.K, "Hadamard size must equal the (padded) reduction dim"
@@ -155,6 +161,10 @@ class W4A8Linear:
         if self.had is not None:
             x2 = ops.hadamard(x2, self.had.n, self.had.K, self.had.bits, self.had.fp32_had)
         a = WORKSPACE.act(x2.device, x2.shape[0], self.K_pad)
+        if self.w_colsum is not None:
+            a, s_rows, _, shift = ops.quantize_act_dyn_asym_i8(x2, self.dynamic["bits"], self.dynamic["clip_ratio"], out=a)
+            return ops.gemm_w4a8_rowscale(a, self.w_img, self.w_bits, self.N, s_rows, self.s_w, bias=self.bias,
+                                          x0=shift, w0=self.w_colsum, out_dtype=x2.dtype, out=out)
         a, s_rows, x0 = ops.quantize_act_dyn_i8(x2, self.dynamic["bits"], self.dynamic["clip_ratio"],
                                                 skip_col0=self.split, out=a)
         return ops.gemm_w4a8_rowscale(a, self.w_img, self.w_bits, self.N, s_rows, self.s_w, bias=self.bias,

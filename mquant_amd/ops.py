@@ -488,6 +488,21 @@ def quantize_act_dyn_i8(x: torch.Tensor, bits: int = 8, clip_ratio: float = 1.0,
 
 
 @_on_device
+def quantize_act_dyn_asym_i8(x: torch.Tensor, bits: int = 8, clip_ratio: float = 1.0, *, out=None, tiled: bool = False):
+    """Dynamic ASYMMETRIC per-token quantizer (``--a_asym``).  Returns (stored int8 levels q - 2^(bits-1)
+    [M, ceil128(K)], scale [M], zero [M], shift [M] = scale * (2^(bits-1) - zero)); dequantised value =
+    scale * stored + shift."""
+    x2 = _rows(x)
+    _need_cuda(x2, out)
+    M, K = x2.shape
+    out, optr, K_pad, ldo = _out_act(out, tiled, M, ceil_to(K, 128), x.device)
+    scale, zero, shift = (torch.empty((M,), dtype=torch.float32, device=x.device) for _ in range(3))
+    call("mq_quantize_act_dyn_asym_i8", x2.data_ptr(), dtype_code(x2.dtype), M, K, x2.stride(0), int(bits),
+         float(clip_ratio), scale.data_ptr(), zero.data_ptr(), shift.data_ptr(), optr, K_pad, ldo, _stream())
+    return out, scale, zero, shift
+
+
+@_on_device
 def gemm_w4a8_rowscale(a: torch.Tensor, w_img: torch.Tensor, w_bits: int, N: int, s_x_rows: torch.Tensor,
                        s_w: torch.Tensor, *, bias: Optional[torch.Tensor] = None, x0: Optional[torch.Tensor] = None,
                        w0: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.float16,

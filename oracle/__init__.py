@@ -222,6 +222,18 @@ def quant_dyn(x, bits=8, clip=1.0, skip_col0=False):
     return q, scale
 
 
+def quant_dyn_asym(x, bits=8, clip=1.0):
+    """quant_utils.py:239-268 (asymmetric branch): dynamic per-token -> (stored int8 levels q - 2^(bits-1),
+    scale, zero, shift = scale * (2^(bits-1) - zero)) per row."""
+    x = _f32(x)
+    rows, cols = x.shape
+    scale, zero, shift = (np.empty(rows, dtype=np.float32) for _ in range(3))
+    q = np.empty((rows, cols), dtype=np.int8)
+    lib().orc_quant_dyn_asym(_p(x, C.c_float), C.c_long(rows), C.c_long(cols), C.c_int(bits), C.c_float(clip),
+                             _p(scale, C.c_float), _p(zero, C.c_float), _p(shift, C.c_float), _p(q, C.c_int8))
+    return q, scale, zero, shift
+
+
 def silu_mul(g, u, mode=0):
     g, u = _f32(g), _f32(u)
     out = np.empty_like(g)

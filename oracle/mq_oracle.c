@@ -174,6 +174,37 @@ void orc_quant_dyn(const float *x, long rows, long cols, int bits, float clip, i
     }
 }
 
+/* Dynamic ASYMMETRIC per-token quantizer (--a_asym), quant_utils.py:239-268 (else-branch) +
+ * asym_quant :27-31, maxq = 2^bits - 1:
+ *   xmin = min(min_k x, 0)*clip; xmax = max(max_k x, 0)*clip; both 0 -> (-1, +1)
+ *   scale = (xmax - xmin) / maxq;  zero = round(-xmin / scale)
+ *   q = clamp(round(x / scale) + zero, 0, maxq)           dequantised: scale * (q - zero)
+ * Stored for the int8 GEMM as q - 2^(bits-1); shift[r] = scale * (2^(bits-1) - zero) is the per-row
+ * factor of the rank-1 term that restores it: x_hat = scale * q_stored + shift. */
+void orc_quant_dyn_asym(const float *x, long rows, long cols, int bits, float clip,
+                        float *scale, float *zero, float *shift, int8_t *q)
+{
+    const float maxq = (float)((1 << bits) - 1), half = (float)(1 << (bits - 1));
+    for (long r = 0; r < rows; ++r) {
+        const float *h = x + r * cols;
+        float mn = 0.0f, mx = 0.0f;
+        for (long k = 0; k < cols; ++k) { if (h[k] < mn) mn = h[k]; if (h[k] > mx) mx = h[k]; }
+        float xmin = mn * clip, xmax = mx * clip;
+        if (xmin == 0.0f && xmax == 0.0f) { xmin = -1.0f; xmax = 1.0f; }
+        const float s = (xmax - xmin) / maxq;
+        const float z = rintf(-xmin / s);
+        scale[r] = s;
+        zero[r] = z;
+        shift[r] = s * (half - z);
+        for (long k = 0; k < cols; ++k) {
+            float v = rintf(h[k] / s) + z;
+            if (v < 0.0f) v = 0.0f;
+            if (v > maxq) v = maxq;
+            q[r * cols + k] = (int8_t)(v - half);
+        }
+    }
+}
+
 /* uniform.py:35-43: x_hat = (q - zp) * s  (fp32) */
 void orc_dequant_static(const int8_t *q, long rows, long cols,
                         const float *scale0, const float *zp0,

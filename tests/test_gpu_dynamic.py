@@ -10,7 +10,7 @@ import torch
 
 import oracle
 from golden_inputs import make_w, make_x
-from test_oracle_golden import DYN_CASES
+from test_oracle_golden import ASYM_DYN_CASES, DYN_CASES
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -85,12 +85,75 @@ def test_wrapper_dynamic_mode_matches_reference_forward(golden_dir, case):
     np.testing.assert_array_equal(ops.gemm_w4a8_i32(a, real.w_img, 4, N).cpu().numpy(), g["acc"])
 
 
+@pytest.mark.parametrize("M,K,dtype,bits,clip", [(768, 3584, torch.float16, 8, 1.0), (33, 1000, torch.float16, 8, 0.9),
+                                                 (5, 19968, torch.bfloat16, 8, 1.0), (17, 260, torch.float32, 4, 1.0),
+                                                 (3, 32768, torch.float16, 6, 1.0)])
+@pytest.mark.parametrize("tiled", [False, True])
+def test_asymmetric_kernel_matches_oracle(M, K, dtype, bits, clip, tiled):
+    from mquant_amd import ops
+    x = torch.from_numpy(make_x(M * 5 + K, (M, K))).to(device=DEV, dtype=dtype)
+    x[0] = x[0].abs()                                              # one-sided row: xmin clamps to 0, zero point 0
+    if M > 2:
+        x[1] = 0                                                   # all-zero row: range (-1, +1)
+        x[2] = -x[2].abs()
+    q, s, z, sh = ops.quantize_act_dyn_asym_i8(x, bits, clip, tiled=tiled)
+    q_ref, s_ref, z_ref, sh_ref = oracle.quant_dyn_asym(x.float().cpu().numpy(), bits=bits, clip=clip)
+    np.testing.assert_array_equal(s.cpu().numpy(), s_ref)
+    np.testing.assert_array_equal(z.cpu().numpy(), z_ref)
+    np.testing.assert_array_equal(sh.cpu().numpy(), sh_ref)
+    rows = q.to_rows() if isinstance(q, ops.TiledAct) else q
+    np.testing.assert_array_equal(rows.cpu().numpy()[:, :K], q_ref)
+    assert not rows[:, K:].any() and float(z[0]) == 0.0
+    if M > 2:
+        assert float(s[1]) == np.float32(2.0) / np.float32((1 << bits) - 1)
+
+
+@pytest.mark.parametrize("case", ASYM_DYN_CASES)
+def test_wrapper_asymmetric_dynamic_mode_matches_reference_forward(golden_dir, case):
+    from fake_quant import hadamard_utils as hu, quant_utils as qu, utils
+    from fake_quant.gptq.rtn import rtn_module
+    from mquant_amd import ops
+    g = np.load(os.path.join(golden_dir, f"wrapper_dyn_{case}.npz"))
+    K_in, K_pad, N, M, seed, had, split, bias, a_bits = [int(v) for v in g["meta"]]
+    lin = torch.nn.Linear(K_pad, N, bias=bool(bias))
+    lin.weight.data = torch.from_numpy(make_w(seed, (N, K_pad)))
+    if bias:
+        lin.bias.data = torch.from_numpy(make_w(seed + 1, (N,), std=0.1))
+    wrap = qu.ActQuantWrapper(lin.to(DEV))
+    if had:
+        hadK, Kh = hu.get_hadK(K_pad)
+        wrap.online_full_had, wrap.had_K, wrap.K = True, hadK, Kh
+    if K_pad != K_in:
+        wrap.register_forward_pre_hook(functools.partial(utils.revise_down_input, new_size=K_pad))
+    rtn_module(wrap, "layer", 4, True, False, [], {})
+    wrap.quantizer.configure(bits=a_bits, sym=False, clip_ratio=float(g["clip"]))
+    x = torch.from_numpy(make_x(seed + 20, (M, K_in))).to(DEV)
+    assert wrap._real_ready(x), "the asymmetric dynamic mode must run the real kernels"
+    y = wrap(x)
+    real = wrap._real
+    assert real is not None and real.dynamic is not None and real.w_colsum is not None
+    np.testing.assert_allclose(y.cpu().numpy(), g["y"], rtol=0, atol=1e-3)
+    xr = ops.hadamard(x, real.had.n, real.had.K, real.had.bits) if had else x
+    a, s_rows, zero, _ = ops.quantize_act_dyn_asym_i8(xr, a_bits, float(g["clip"]))
+    np.testing.assert_array_equal(s_rows.cpu().numpy(), g["s_rows"])
+    np.testing.assert_array_equal(zero.cpu().numpy(), g["zero"])
+    np.testing.assert_array_equal(a.cpu().numpy()[:, :64], g["qx_head"])
+    np.testing.assert_array_equal(ops.gemm_w4a8_i32(a, real.w_img, 4, N).cpu().numpy(), g["acc"])
+    # a split wrapper keeps the simulated path in this mode (one rank-1 epilogue slot)
+    wrap2 = qu.ActQuantWrapper(torch.nn.Linear(256, 32).to(DEV))
+    wrap2.split = True
+    wrap2.split_weights()
+    rtn_module(wrap2, "layer", 4, True, False, [], {})
+    wrap2.quantizer.configure(bits=8, sym=False)
+    assert not wrap2._real_ready(torch.zeros(4, 256, device=DEV))
+
+
 def test_modes_the_kernels_do_not_cover_stay_on_the_simulated_path():
     from fake_quant import quant_utils as qu
     from fake_quant.gptq.rtn import rtn_module
     lin = torch.nn.Linear(256, 32).to(DEV).half()
     x = torch.from_numpy(make_x(1, (8, 256))).to(DEV).half()
-    for kw in (dict(bits=8, sym=False), dict(bits=8, sym=True, groupsize=128), dict(bits=16)):
+    for kw in (dict(bits=8, sym=False, act_per_tensor=True), dict(bits=8, sym=True, groupsize=128), dict(bits=16)):
         wrap = qu.ActQuantWrapper(lin)
         rtn_module(wrap, "l", 4, True, False, [], {})
         wrap.quantizer.configure(**kw)

@@ -235,3 +235,36 @@ def test_dynamic_wrapper_layer_against_reference(golden_dir, had_table, case):
     b = make_w(seed + 1, (N,), std=0.1) if bias else None
     y = oracle.epilogue(acc, s_rows, s_w, bias=b, x0=x[:, 0] if split else None, w0=W[:, 0] if split else None)
     np.testing.assert_allclose(y, g["y"], rtol=0, atol=1e-3)
+
+
+ASYM_DYN_CASES = ["asym_3584", "asym_clip_1280", "asym_down_19968", "asym_a6_2048"]
+
+
+@pytest.mark.parametrize("case", ASYM_DYN_CASES)
+def test_asymmetric_dynamic_wrapper_layer_against_reference(golden_dir, had_table, case):
+    """--a_asym: per-token scale and zero point (quant_utils.py:239-268 else-branch), levels stored minus
+    2^(bits-1) for the int8 GEMM, zero point and offset restored by the rank-1 epilogue term."""
+    from golden_inputs import make_w, make_x
+    g = np.load(os.path.join(golden_dir, f"wrapper_dyn_{case}.npz"))
+    K_in, K_pad, N, M, seed, had, split, bias, a_bits = [int(v) for v in g["meta"]]
+    assert not split and int(g["sym"]) == 0
+    x = make_x(seed + 20, (M, K_in))
+    if had:
+        K = had_table["n2k"][K_pad]
+        x = oracle.hadamard(x, K_pad, K, had_table["mats"][K], mid_round=0, out_round=0)
+    q, s_rows, zero, shift = oracle.quant_dyn_asym(x, bits=a_bits, clip=float(g["clip"]))
+    np.testing.assert_array_equal(s_rows, g["s_rows"])
+    np.testing.assert_array_equal(zero, g["zero"])
+    np.testing.assert_array_equal(q[:, :64], g["qx_head"])
+    half = 1 << (a_bits - 1)
+    assert q.min() >= -half and q.max() <= half - 1
+    np.testing.assert_array_equal(shift, s_rows * (np.float32(half) - zero))
+    W = make_w(seed, (N, K_pad))
+    s_w, levels = oracle.wquant_sym(np.ascontiguousarray(W), bits=4)
+    np.testing.assert_array_equal(s_w, g["s_w"])
+    acc = oracle.gemm_i32(q, levels)
+    np.testing.assert_array_equal(acc, g["acc"])
+    b = make_w(seed + 1, (N,), std=0.1) if bias else None
+    w0 = levels.astype(np.int32).sum(axis=1).astype(np.float32) * s_w
+    y = oracle.epilogue(acc, s_rows, s_w, bias=b, x0=shift, w0=w0)
+    np.testing.assert_allclose(y, g["y"], rtol=0, atol=1e-3)

@@ -17,8 +17,13 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import gen_golden  # noqa: E402
 from golden_inputs import make_w, make_x  # noqa: E402
 
-# tag: (K_in, K_pad, N, M, seed, had, split, bias, clip_ratio, a_bits)
+# tag: (K_in, K_pad, N, M, seed, had, split, bias, clip_ratio, a_bits[, sym])
 CASES = {
+    # asymmetric (--a_asym): levels 0..2^bits-1 with a zero point per row
+    "asym_3584": (3584, 3584, 48, 16, 1700, False, False, True, 1.0, 8, False),
+    "asym_clip_1280": (1280, 1280, 40, 24, 1710, False, False, False, 0.9, 8, False),
+    "asym_down_19968": (18944, 19968, 24, 6, 1720, True, False, True, 1.0, 8, False),
+    "asym_a6_2048": (2048, 2048, 32, 10, 1730, False, False, False, 1.0, 6, False),
     "plain_3584": (3584, 3584, 48, 16, 1600, False, False, True, 1.0, 8),
     "clip_1280": (1280, 1280, 40, 24, 1610, False, False, False, 0.9, 8),
     "had_5120_split": (5120, 5120, 32, 12, 1620, True, True, True, 1.0, 8),
@@ -33,7 +38,9 @@ def main():
     from fake_quant import quant_utils as qu
     from fake_quant import utils as ru
     assert qu.__file__.startswith(gen_golden.REF)
-    for tag, (K_in, K_pad, N, M, seed, had, split, bias, clip, a_bits) in CASES.items():
+    for tag, case in CASES.items():
+        K_in, K_pad, N, M, seed, had, split, bias, clip, a_bits = case[:10]
+        sym = case[10] if len(case) > 10 else True
         lin = torch.nn.Linear(K_pad, N, bias=bias)
         lin.weight.data = torch.from_numpy(make_w(seed, (N, K_pad)))
         if bias:
@@ -57,7 +64,7 @@ def main():
             sub.weight.data = wq.quantize(sub.weight.data)
             if name in ("module", "L2"):
                 wscale = wq.scale.float().numpy().reshape(-1)
-        wrap.quantizer.configure(bits=a_bits, sym=True, clip_ratio=clip)
+        wrap.quantizer.configure(bits=a_bits, sym=sym, clip_ratio=clip)
         x = make_x(seed + 20, (M, K_in))
         y = wrap(torch.from_numpy(x.copy()))
         # integer restatement from the reference's own dynamic quantizer
@@ -68,9 +75,14 @@ def main():
             xt = hu.matmul_hadU_cuda(xt, wrap.had_K, wrap.K)
         xq_in = xt[..., 1:] if split else xt
         aq = qu.ActQuantizer()
-        aq.configure(bits=a_bits, sym=True, clip_ratio=clip)
+        aq.configure(bits=a_bits, sym=sym, clip_ratio=clip)
         aq.find_params(xq_in)
-        qx, s_rows = aq.quantize(xq_in)
+        zero = None
+        if sym:
+            qx, s_rows = aq.quantize(xq_in)
+        else:                       # levels 0 .. 2^bits - 1; the int8 GEMM stores them minus 2^(bits-1)
+            qx, s_rows, zero = aq.quantize(xq_in)
+            qx = qx - float(1 << (a_bits - 1))
         Wq = (wrap.L2.weight.data if split else wrap.module.weight.data).float()
         qw = torch.round(Wq / torch.from_numpy(wscale).reshape(-1, 1)).to(torch.int64)
         acc = qx.to(torch.int64) @ qw.T
@@ -80,6 +92,9 @@ def main():
                    clip=np.float32(clip))
         if split:
             out["x0"] = xt[..., 0].numpy()
+        if zero is not None:
+            out["zero"] = zero[:, 0].numpy().astype(np.float32)
+            out["sym"] = np.int64(0)
         gen_golden.save(f"wrapper_dyn_{tag}", **out)
 
 
