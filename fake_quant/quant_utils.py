@@ -407,9 +407,10 @@ class ActQuantWrapper(torch.nn.Module):
     def _dynamic_real_ok(self) -> bool:
         """Dynamic per-token int8 (the reference's default activation mode, quant_utils.py:205-268) also
         has real-integer kernels: symmetric, and asymmetric (``--a_asym``) when the wrapper is not split
-        (the zero point travels through the same rank-1 epilogue term as the split column)."""
+        (the zero point travels through the same rank-1 epilogue term as the split column); per token or
+        per tensor (``act_per_tensor``).  Group-wise scales stay on the simulated path."""
         qz = self.quantizer
-        if not (2 <= qz.bits <= 8) or qz.act_per_tensor or getattr(qz, "groupsize", -1) > 0:
+        if not (2 <= qz.bits <= 8) or getattr(qz, "groupsize", -1) > 0:
             return False
         return bool(getattr(qz, "sym", False)) or not self.split
 
@@ -452,7 +453,8 @@ class ActQuantWrapper(torch.nn.Module):
             if qz.msq:
                 s1 = float(qz.quantizer_text.scale) if qz.quantizer_text.scale is not None else s0
         else:
-            dynamic = dict(bits=int(qz.bits), clip_ratio=float(qz.clip_ratio), sym=bool(qz.sym))
+            dynamic = dict(bits=int(qz.bits), clip_ratio=float(qz.clip_ratio), sym=bool(qz.sym),
+                           per_tensor=bool(qz.act_per_tensor))
         self._real = W4A8Linear(levels, scale, wq.bits,
                                 None if bias is None else bias.data.to(device), s0, s1,
                                 had=had, w0=w0, dynamic=dynamic)

@@ -197,6 +197,17 @@ int mq_quantize_act_dyn_asym_i8(const void *x, int x_dtype, long M, long K, long
                                 float clip_ratio, float *scale_out, float *zero_out, float *shift_out,
                                 int8_t *out, long K_pad, long ldo, void *stream);
 
+/* The PER-TENSOR variant (act_per_tensor = True; quant_utils.py:214-237): one range for the whole
+ * tensor, taken from `minmax` = the two device floats written by mq_minmax_tensor (col_begin = 1 under
+ * skip_col0) -- no host round trip.  asym = 0: scale = max(|xmin|, xmax) / (2^(bits-1) - 1) (1 if 0);
+ * asym = 1: a zero bound becomes -1 resp. +1 on its own, scale / zero / stored levels / shift as in
+ * mq_quantize_act_dyn_asym_i8 (no skip_col0 then).  scale_out (and zero_out / shift_out, may be NULL when
+ * asym = 0) are written per row for mq_gemm_w4a8_rowscale_ws. */
+int mq_quantize_act_range_i8(const void *x, int x_dtype, long M, long K, long ldx, int bits,
+                             float clip_ratio, int asym, int skip_col0, const float *minmax,
+                             float *x0_out, float *scale_out, float *zero_out, float *shift_out,
+                             int8_t *out, long K_pad, long ldo, void *stream);
+
 /* ---------------------------------------------------------------------------
  * RMSN + static quantizer in one pass.  Replaces module_util.RMSN.forward
  * (module_util.py:55-61) followed by UniformQuantizer.quant (uniform.py:20-33):

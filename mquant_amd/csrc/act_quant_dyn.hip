@@ -22,6 +22,7 @@ struct DqArgs {
     float *x0_out, *scale_out;
     float *zero_out, *shift_out;   // asymmetric mode: zero point and scale * (2^(bits-1) - zero) per row
     float half;                    // asymmetric mode: 2^(bits-1), the offset of the stored levels
+    const float *range_in;         // per-tensor mode: device [min, max] of the whole tensor (mq_minmax_tensor), else NULL
     int8_t *out;
     long K_pad, ldo;
     int vec_ok;
@@ -83,10 +84,17 @@ __global__ __launch_bounds__(DQ_THREADS) void act_quant_dyn_kernel(DqArgs p)
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < DQ_THREADS / 64; ++w) { mn = fminf(mn, rmin[w]); mx = fmaxf(mx, rmax[w]); }
+    if (p.range_in) {                                   // act_per_tensor (quant_utils.py:214-237): one range for all rows
+        mn = fminf(p.range_in[0], 0.0f);
+        mx = fmaxf(p.range_in[1], 0.0f);
+    }
     float xmin = mn * p.clip, xmax0 = mx * p.clip;
     float s, zero = 0.0f, lo, hi;
     if (ASYM) {                                         // quant_utils.py:255-268 + asym_quant :27-31
-        if (xmin == 0.0f && xmax0 == 0.0f) { xmin = -1.0f; xmax0 = 1.0f; }
+        if (p.range_in) {                               // the per-tensor rule fixes each bound on its own (:229-232)
+            if (xmin == 0.0f) xmin = -1.0f;
+            if (xmax0 == 0.0f) xmax0 = 1.0f;
+        } else if (xmin == 0.0f && xmax0 == 0.0f) { xmin = -1.0f; xmax0 = 1.0f; }
         s = (xmax0 - xmin) / p.maxq;
         zero = rintf(-xmin / s);
         lo = 0.0f;
@@ -153,7 +161,7 @@ extern "C" int mq_quantize_act_dyn_i8(const void *x, int x_dtype, long M, long K
     DqArgs p;
     p.x = x; p.M = M; p.K = K; p.ldx = ldx; p.clip = clip_ratio; p.maxq = (float)((1 << (bits - 1)) - 1);
     p.skip_col0 = skip_col0; p.x0_out = x0_out; p.scale_out = scale_out; p.out = out; p.K_pad = K_pad; p.ldo = ldo;
-    p.zero_out = nullptr; p.shift_out = nullptr; p.half = 0.0f;
+    p.zero_out = nullptr; p.shift_out = nullptr; p.half = 0.0f; p.range_in = nullptr;
     const size_t esz = (x_dtype == MQ_F32) ? 4 : 2;
     p.vec_ok = (((uintptr_t)x) % 16 == 0) && ((ldx * esz) % 16 == 0);
     hipStream_t st = (hipStream_t)stream;
@@ -187,7 +195,7 @@ extern "C" int mq_quantize_act_dyn_asym_i8(const void *x, int x_dtype, long M, l
     DqArgs p;
     p.x = x; p.M = M; p.K = K; p.ldx = ldx; p.clip = clip_ratio; p.maxq = (float)((1 << bits) - 1);
     p.half = (float)(1 << (bits - 1));
-    p.skip_col0 = 0; p.x0_out = nullptr; p.scale_out = scale_out; p.zero_out = zero_out; p.shift_out = shift_out;
+    p.skip_col0 = 0; p.x0_out = nullptr; p.scale_out = scale_out; p.zero_out = zero_out; p.shift_out = shift_out; p.range_in = nullptr;
     p.out = out; p.K_pad = K_pad; p.ldo = ldo;
     const size_t esz = (x_dtype == MQ_F32) ? 4 : 2;
     p.vec_ok = (((uintptr_t)x) % 16 == 0) && ((ldx * esz) % 16 == 0);
@@ -199,4 +207,47 @@ extern "C" int mq_quantize_act_dyn_asym_i8(const void *x, int x_dtype, long M, l
     default: return fail(MQ_EINVAL, "mq_quantize_act_dyn_asym_i8: unknown dtype %d", x_dtype);
     }
     return check_launch("quantize_act_dyn_asym_i8");
+}
+
+/* Dynamic PER-TENSOR quantizer (act_per_tensor = True; quant_utils.py:214-237): the range of the whole
+ * tensor comes from mq_minmax_tensor (device [min, max], col_begin = 1 under skip_col0), so nothing
+ * returns to the host.  Symmetric or asymmetric as above, except that the asymmetric rule replaces a
+ * zero bound on its own (xmin == 0 -> -1; xmax == 0 -> +1).  scale_out / zero_out / shift_out are
+ * written per row (all rows equal) for mq_gemm_w4a8_rowscale_ws. */
+extern "C" int mq_quantize_act_range_i8(const void *x, int x_dtype, long M, long K, long ldx, int bits,
+                                        float clip_ratio, int asym, int skip_col0, const float *minmax,
+                                        float *x0_out, float *scale_out, float *zero_out, float *shift_out,
+                                        int8_t *out, long K_pad, long ldo, void *stream)
+{
+    using namespace mq;
+    if (M == 0) return MQ_OK;
+    MQ_REQUIRE(x && out && scale_out && minmax && M >= 0 && K > 0 && ldx >= K, "mq_quantize_act_range_i8: bad shape");
+    MQ_REQUIRE(!asym || (shift_out && !skip_col0), "mq_quantize_act_range_i8: the asymmetric mode needs shift_out and no split column");
+    MQ_REQUIRE(bits >= 2 && bits <= 8, "mq_quantize_act_range_i8: bits must be 2..8");
+    MQ_REQUIRE(K <= 16L * DQ_THREADS * DQ_MAX_CHUNKS, "mq_quantize_act_range_i8: K=%ld too large (max %d)", K, 16 * DQ_THREADS * DQ_MAX_CHUNKS);
+    MQ_REQUIRE(K_pad >= K && K_pad % 16 == 0 && ((uintptr_t)out) % 16 == 0 &&
+                   (ldo == MQ_LD_TILED ? K_pad % 64 == 0 : (ldo >= K_pad && ldo % 16 == 0)),
+               "mq_quantize_act_range_i8: bad K_pad / ldo / alignment");
+    DqArgs p;
+    p.x = x; p.M = M; p.K = K; p.ldx = ldx; p.clip = clip_ratio;
+    p.maxq = asym ? (float)((1 << bits) - 1) : (float)((1 << (bits - 1)) - 1);
+    p.half = asym ? (float)(1 << (bits - 1)) : 0.0f;
+    p.skip_col0 = skip_col0; p.x0_out = x0_out; p.scale_out = scale_out; p.zero_out = zero_out; p.shift_out = shift_out;
+    p.range_in = minmax; p.out = out; p.K_pad = K_pad; p.ldo = ldo;
+    const size_t esz = (x_dtype == MQ_F32) ? 4 : 2;
+    p.vec_ok = (((uintptr_t)x) % 16 == 0) && ((ldx * esz) % 16 == 0);
+    hipStream_t st = (hipStream_t)stream;
+#define MQ_DQ_LAUNCH(DT)                                                                                              \
+    do {                                                                                                              \
+        if (asym) hipLaunchKernelGGL((act_quant_dyn_kernel<DT, true>), dim3((unsigned)M), dim3(DQ_THREADS), 0, st, p); \
+        else hipLaunchKernelGGL((act_quant_dyn_kernel<DT, false>), dim3((unsigned)M), dim3(DQ_THREADS), 0, st, p);    \
+    } while (0)
+    switch (x_dtype) {
+    case MQ_F16: MQ_DQ_LAUNCH(MQ_F16); break;
+    case MQ_BF16: MQ_DQ_LAUNCH(MQ_BF16); break;
+    case MQ_F32: MQ_DQ_LAUNCH(MQ_F32); break;
+    default: return fail(MQ_EINVAL, "mq_quantize_act_range_i8: unknown dtype %d", x_dtype);
+    }
+#undef MQ_DQ_LAUNCH
+    return check_launch("quantize_act_range_i8");
 }

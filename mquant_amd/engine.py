@@ -161,6 +161,13 @@ class W4A8Linear:
         if self.had is not None:
             x2 = ops.hadamard(x2, self.had.n, self.had.K, self.had.bits, self.had.fp32_had)
         a = WORKSPACE.act(x2.device, x2.shape[0], self.K_pad)
+        if self.dynamic.get("per_tensor", False):
+            asym = self.w_colsum is not None
+            a, s_rows, _, shift, x0 = ops.quantize_act_tensor_i8(x2, self.dynamic["bits"], self.dynamic["clip_ratio"],
+                                                                 asym=asym, skip_col0=self.split, out=a)
+            return ops.gemm_w4a8_rowscale(a, self.w_img, self.w_bits, self.N, s_rows, self.s_w, bias=self.bias,
+                                          x0=shift if asym else x0, w0=self.w_colsum if asym else self.w0,
+                                          out_dtype=x2.dtype, out=out)
         if self.w_colsum is not None:
             a, s_rows, _, shift = ops.quantize_act_dyn_asym_i8(x2, self.dynamic["bits"], self.dynamic["clip_ratio"], out=a)
             return ops.gemm_w4a8_rowscale(a, self.w_img, self.w_bits, self.N, s_rows, self.s_w, bias=self.bias,

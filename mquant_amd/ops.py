@@ -503,6 +503,28 @@ def quantize_act_dyn_asym_i8(x: torch.Tensor, bits: int = 8, clip_ratio: float =
 
 
 @_on_device
+def quantize_act_tensor_i8(x: torch.Tensor, bits: int = 8, clip_ratio: float = 1.0, *, asym: bool = False,
+                           skip_col0: bool = False, out=None, tiled: bool = False):
+    """Dynamic PER-TENSOR quantizer (``act_per_tensor``): min/max of the whole tensor on the device
+    (``mq_minmax_tensor``), then ``mq_quantize_act_range_i8``.  Returns (int8 levels, scale [M], zero [M] | None,
+    shift [M] | None, column 0 as fp32 [M] | None)."""
+    x2 = _rows(x)
+    _need_cuda(x2, out)
+    assert not (asym and skip_col0)
+    M, K = x2.shape
+    rng = minmax_tensor(x2, 1 if skip_col0 else 0)
+    out, optr, K_pad, ldo = _out_act(out, tiled, M, ceil_to(K, 128), x.device)
+    scale = torch.empty((M,), dtype=torch.float32, device=x.device)
+    zero = torch.empty((M,), dtype=torch.float32, device=x.device) if asym else None
+    shift = torch.empty((M,), dtype=torch.float32, device=x.device) if asym else None
+    x0 = torch.empty((M,), dtype=torch.float32, device=x.device) if skip_col0 else None
+    call("mq_quantize_act_range_i8", x2.data_ptr(), dtype_code(x2.dtype), M, K, x2.stride(0), int(bits),
+         float(clip_ratio), int(asym), int(skip_col0), rng.data_ptr(), _ptr(x0), scale.data_ptr(), _ptr(zero),
+         _ptr(shift), optr, K_pad, ldo, _stream())
+    return out, scale, zero, shift, x0
+
+
+@_on_device
 def gemm_w4a8_rowscale(a: torch.Tensor, w_img: torch.Tensor, w_bits: int, N: int, s_x_rows: torch.Tensor,
                        s_w: torch.Tensor, *, bias: Optional[torch.Tensor] = None, x0: Optional[torch.Tensor] = None,
                        w0: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.float16,

@@ -205,6 +205,47 @@ void orc_quant_dyn_asym(const float *x, long rows, long cols, int bits, float cl
     }
 }
 
+/* Dynamic PER-TENSOR quantizer (act_per_tensor = True), quant_utils.py:214-237: one range for the
+ * whole tensor (column 0 left out and passed through under skip_col0, ActQuantWrapper.split :367-372):
+ *   xmin = min(min x, 0)*clip; xmax = max(max x, 0)*clip
+ *   sym:  xmax = max(|xmin|, xmax); scale = xmax / maxq (1 if xmax == 0), maxq = 2^(bits-1)-1
+ *   asym: xmin == 0 -> -1; xmax == 0 -> +1 (each on its own, unlike the per-token rule);
+ *         scale = (xmax - xmin) / maxq, zero = round(-xmin / scale), maxq = 2^bits - 1
+ * Levels as in orc_quant_dyn / orc_quant_dyn_asym; params[0..2] = scale, zero, shift. */
+void orc_quant_tensor(const float *x, long rows, long cols, int bits, float clip, int asym, int skip_col0,
+                      float *params, int8_t *q)
+{
+    float mn = 0.0f, mx = 0.0f;
+    for (long r = 0; r < rows; ++r)
+        for (long k = skip_col0 ? 1 : 0; k < cols; ++k) {
+            const float v = x[r * cols + k];
+            if (v < mn) mn = v;
+            if (v > mx) mx = v;
+        }
+    float xmin = mn * clip, xmax = mx * clip, s, z = 0.0f, lo, hi, half = 0.0f;
+    if (asym) {
+        const float maxq = (float)((1 << bits) - 1);
+        if (xmin == 0.0f) xmin = -1.0f;
+        if (xmax == 0.0f) xmax = 1.0f;
+        s = (xmax - xmin) / maxq;
+        z = rintf(-xmin / s);
+        lo = 0.0f; hi = maxq; half = (float)(1 << (bits - 1));
+    } else {
+        const float maxq = (float)((1 << (bits - 1)) - 1);
+        xmax = fmaxf(fabsf(xmin), xmax);
+        s = (xmax == 0.0f) ? 1.0f : xmax / maxq;
+        lo = -(maxq + 1.0f); hi = maxq;
+    }
+    params[0] = s; params[1] = z; params[2] = s * (half - z);
+    for (long r = 0; r < rows; ++r)
+        for (long k = 0; k < cols; ++k) {
+            float v = rintf(x[r * cols + k] / s) + z;
+            if (v < lo) v = lo;
+            if (v > hi) v = hi;
+            q[r * cols + k] = (skip_col0 && k == 0) ? 0 : (int8_t)(v - half);
+        }
+}
+
 /* uniform.py:35-43: x_hat = (q - zp) * s  (fp32) */
 void orc_dequant_static(const int8_t *q, long rows, long cols,
                         const float *scale0, const float *zp0,

@@ -10,7 +10,7 @@ import torch
 
 import oracle
 from golden_inputs import make_w, make_x
-from test_oracle_golden import ASYM_DYN_CASES, DYN_CASES
+from test_oracle_golden import ASYM_DYN_CASES, DYN_CASES, PT_DYN_CASES
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -148,12 +148,69 @@ def test_wrapper_asymmetric_dynamic_mode_matches_reference_forward(golden_dir, c
     assert not wrap2._real_ready(torch.zeros(4, 256, device=DEV))
 
 
+@pytest.mark.parametrize("M,K,dtype,bits,clip,asym,skip", [(768, 3584, torch.float16, 8, 1.0, False, False), (33, 1000, torch.float16, 8, 0.9, True, False),
+                                                           (5, 19968, torch.bfloat16, 8, 1.0, False, True), (17, 260, torch.float32, 4, 1.0, True, False),
+                                                           (9, 512, torch.float16, 8, 1.0, True, False)])
+def test_per_tensor_kernel_matches_oracle(M, K, dtype, bits, clip, asym, skip):
+    from mquant_amd import ops
+    x = torch.from_numpy(make_x(M * 7 + K, (M, K))).to(device=DEV, dtype=dtype)
+    if M == 9:
+        x = x.abs()                                                 # xmin == 0 alone: the per-tensor rule makes it -1
+    q, s, z, sh, x0 = ops.quantize_act_tensor_i8(x, bits, clip, asym=asym, skip_col0=skip)
+    q_ref, s_ref, z_ref, sh_ref = oracle.quant_tensor(x.float().cpu().numpy(), bits=bits, clip=clip, asym=asym, skip_col0=skip)
+    np.testing.assert_array_equal(s.cpu().numpy(), np.full(M, s_ref, np.float32))
+    np.testing.assert_array_equal(q.cpu().numpy()[:, :K], q_ref)
+    if asym:
+        np.testing.assert_array_equal(z.cpu().numpy(), np.full(M, z_ref, np.float32))
+        np.testing.assert_array_equal(sh.cpu().numpy(), np.full(M, sh_ref, np.float32))
+    if skip:
+        np.testing.assert_array_equal(x0.cpu().numpy(), x[:, 0].float().cpu().numpy())
+
+
+@pytest.mark.parametrize("case", PT_DYN_CASES)
+def test_wrapper_per_tensor_dynamic_mode_matches_reference_forward(golden_dir, case):
+    from fake_quant import hadamard_utils as hu, quant_utils as qu, utils
+    from fake_quant.gptq.rtn import rtn_module
+    from mquant_amd import ops
+    g = np.load(os.path.join(golden_dir, f"wrapper_dyn_{case}.npz"))
+    K_in, K_pad, N, M, seed, had, split, bias, a_bits = [int(v) for v in g["meta"]]
+    asym = "zero" in g.files
+    lin = torch.nn.Linear(K_pad, N, bias=bool(bias))
+    lin.weight.data = torch.from_numpy(make_w(seed, (N, K_pad)))
+    if bias:
+        lin.bias.data = torch.from_numpy(make_w(seed + 1, (N,), std=0.1))
+    wrap = qu.ActQuantWrapper(lin.to(DEV))
+    if had:
+        hadK, Kh = hu.get_hadK(K_pad)
+        wrap.online_full_had, wrap.had_K, wrap.K = True, hadK, Kh
+    if split:
+        wrap.split = True
+        wrap.split_weights()
+    if K_pad != K_in:
+        wrap.register_forward_pre_hook(functools.partial(utils.revise_down_input, new_size=K_pad))
+    rtn_module(wrap, "layer", 4, True, False, [], {})
+    wrap.quantizer.configure(bits=a_bits, sym=not asym, clip_ratio=float(g["clip"]), act_per_tensor=True)
+    x = torch.from_numpy(make_x(seed + 20, (M, K_in))).to(DEV)
+    assert wrap._real_ready(x), "the per-tensor dynamic mode must run the real kernels"
+    y = wrap(x)
+    real = wrap._real
+    assert real is not None and real.dynamic["per_tensor"]
+    np.testing.assert_allclose(y.cpu().numpy(), g["y"], rtol=0, atol=1e-3)
+    xr = ops.hadamard(x, real.had.n, real.had.K, real.had.bits) if had else x
+    a, s_rows, zero, _, _ = ops.quantize_act_tensor_i8(xr, a_bits, float(g["clip"]), asym=asym, skip_col0=bool(split))
+    np.testing.assert_array_equal(s_rows.cpu().numpy(), g["s_rows"])
+    if asym:
+        np.testing.assert_array_equal(zero.cpu().numpy(), g["zero"])
+    np.testing.assert_array_equal(a.cpu().numpy()[:, 1 if split else 0:65 if split else 64], g["qx_head"])
+    np.testing.assert_array_equal(ops.gemm_w4a8_i32(a, real.w_img, 4, N).cpu().numpy(), g["acc"])
+
+
 def test_modes_the_kernels_do_not_cover_stay_on_the_simulated_path():
     from fake_quant import quant_utils as qu
     from fake_quant.gptq.rtn import rtn_module
     lin = torch.nn.Linear(256, 32).to(DEV).half()
     x = torch.from_numpy(make_x(1, (8, 256))).to(DEV).half()
-    for kw in (dict(bits=8, sym=False, act_per_tensor=True), dict(bits=8, sym=True, groupsize=128), dict(bits=16)):
+    for kw in (dict(bits=8, sym=False, groupsize=64), dict(bits=8, sym=True, groupsize=128), dict(bits=16)):
         wrap = qu.ActQuantWrapper(lin)
         rtn_module(wrap, "l", 4, True, False, [], {})
         wrap.quantizer.configure(**kw)

@@ -268,3 +268,38 @@ def test_asymmetric_dynamic_wrapper_layer_against_reference(golden_dir, had_tabl
     w0 = levels.astype(np.int32).sum(axis=1).astype(np.float32) * s_w
     y = oracle.epilogue(acc, s_rows, s_w, bias=b, x0=shift, w0=w0)
     np.testing.assert_allclose(y, g["y"], rtol=0, atol=1e-3)
+
+
+PT_DYN_CASES = ["pt_sym_3584", "pt_sym_had_5120_split", "pt_asym_1280", "pt_asym_down_19968"]
+
+
+@pytest.mark.parametrize("case", PT_DYN_CASES)
+def test_per_tensor_dynamic_wrapper_layer_against_reference(golden_dir, had_table, case):
+    """act_per_tensor: one dynamic range for the whole activation tensor (quant_utils.py:214-237)."""
+    from golden_inputs import make_w, make_x
+    g = np.load(os.path.join(golden_dir, f"wrapper_dyn_{case}.npz"))
+    K_in, K_pad, N, M, seed, had, split, bias, a_bits = [int(v) for v in g["meta"]]
+    asym = "zero" in g.files
+    x = make_x(seed + 20, (M, K_in))
+    if had:
+        K = had_table["n2k"][K_pad]
+        x = oracle.hadamard(x, K_pad, K, had_table["mats"][K], mid_round=0, out_round=0)
+    q, s, z, shift = oracle.quant_tensor(x, bits=a_bits, clip=float(g["clip"]), asym=asym, skip_col0=bool(split))
+    np.testing.assert_array_equal(np.full(M, s, np.float32), g["s_rows"])
+    if asym:
+        np.testing.assert_array_equal(np.full(M, z, np.float32), g["zero"])
+    np.testing.assert_array_equal(q[:, 1 if split else 0:65 if split else 64], g["qx_head"])
+    W = make_w(seed, (N, K_pad))
+    Wsrc = W[:, 1:] if split else W
+    s_w, levels = oracle.wquant_sym(np.ascontiguousarray(Wsrc), bits=4)
+    if split:
+        levels = np.concatenate([np.zeros((N, 1), np.int8), levels], axis=1)
+    acc = oracle.gemm_i32(q, levels)
+    np.testing.assert_array_equal(acc, g["acc"])
+    b = make_w(seed + 1, (N,), std=0.1) if bias else None
+    if asym:
+        x0, w0 = np.full(M, shift, np.float32), levels.astype(np.int32).sum(axis=1).astype(np.float32) * s_w
+    else:
+        x0, w0 = (x[:, 0], W[:, 0]) if split else (None, None)
+    y = oracle.epilogue(acc, np.full(M, s, np.float32), s_w, bias=b, x0=x0, w0=w0)
+    np.testing.assert_allclose(y, g["y"], rtol=0, atol=1e-3)

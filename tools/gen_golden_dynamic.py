@@ -17,8 +17,13 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import gen_golden  # noqa: E402
 from golden_inputs import make_w, make_x  # noqa: E402
 
-# tag: (K_in, K_pad, N, M, seed, had, split, bias, clip_ratio, a_bits[, sym])
+# tag: (K_in, K_pad, N, M, seed, had, split, bias, clip_ratio, a_bits[, sym[, per_tensor]])
 CASES = {
+    # one range for the whole tensor (act_per_tensor)
+    "pt_sym_3584": (3584, 3584, 48, 16, 1800, False, False, True, 1.0, 8, True, True),
+    "pt_sym_had_5120_split": (5120, 5120, 32, 12, 1810, True, True, True, 0.9, 8, True, True),
+    "pt_asym_1280": (1280, 1280, 40, 24, 1820, False, False, False, 1.0, 8, False, True),
+    "pt_asym_down_19968": (18944, 19968, 24, 6, 1830, True, False, True, 0.95, 8, False, True),
     # asymmetric (--a_asym): levels 0..2^bits-1 with a zero point per row
     "asym_3584": (3584, 3584, 48, 16, 1700, False, False, True, 1.0, 8, False),
     "asym_clip_1280": (1280, 1280, 40, 24, 1710, False, False, False, 0.9, 8, False),
@@ -41,6 +46,7 @@ def main():
     for tag, case in CASES.items():
         K_in, K_pad, N, M, seed, had, split, bias, clip, a_bits = case[:10]
         sym = case[10] if len(case) > 10 else True
+        per_tensor = case[11] if len(case) > 11 else False
         lin = torch.nn.Linear(K_pad, N, bias=bias)
         lin.weight.data = torch.from_numpy(make_w(seed, (N, K_pad)))
         if bias:
@@ -64,7 +70,7 @@ def main():
             sub.weight.data = wq.quantize(sub.weight.data)
             if name in ("module", "L2"):
                 wscale = wq.scale.float().numpy().reshape(-1)
-        wrap.quantizer.configure(bits=a_bits, sym=sym, clip_ratio=clip)
+        wrap.quantizer.configure(bits=a_bits, sym=sym, clip_ratio=clip, act_per_tensor=per_tensor)
         x = make_x(seed + 20, (M, K_in))
         y = wrap(torch.from_numpy(x.copy()))
         # integer restatement from the reference's own dynamic quantizer
@@ -75,7 +81,7 @@ def main():
             xt = hu.matmul_hadU_cuda(xt, wrap.had_K, wrap.K)
         xq_in = xt[..., 1:] if split else xt
         aq = qu.ActQuantizer()
-        aq.configure(bits=a_bits, sym=sym, clip_ratio=clip)
+        aq.configure(bits=a_bits, sym=sym, clip_ratio=clip, act_per_tensor=per_tensor)
         aq.find_params(xq_in)
         zero = None
         if sym:
@@ -86,6 +92,10 @@ def main():
         Wq = (wrap.L2.weight.data if split else wrap.module.weight.data).float()
         qw = torch.round(Wq / torch.from_numpy(wscale).reshape(-1, 1)).to(torch.int64)
         acc = qx.to(torch.int64) @ qw.T
+        if per_tensor:               # scalars: one value for every row
+            s_rows = torch.as_tensor(s_rows, dtype=torch.float32).reshape(1, 1).expand(xq_in.shape[0], 1)
+            if zero is not None:
+                zero = torch.as_tensor(zero, dtype=torch.float32).reshape(1, 1).expand(xq_in.shape[0], 1)
         out = dict(y=y.numpy(), s_w=wscale, s_rows=s_rows[:, 0].numpy().astype(np.float32),
                    acc=acc.numpy().astype(np.int32), qx_head=qx[:, :64].numpy().astype(np.int8),
                    meta=np.array([K_in, K_pad, N, M, seed, int(had), int(split), int(bias), a_bits], np.int64),
@@ -95,6 +105,8 @@ def main():
         if zero is not None:
             out["zero"] = zero[:, 0].numpy().astype(np.float32)
             out["sym"] = np.int64(0)
+        if per_tensor:
+            out["per_tensor"] = np.int64(1)
         gen_golden.save(f"wrapper_dyn_{tag}", **out)
 
 
