@@ -309,3 +309,46 @@ def test_every_m_grouping_of_the_xcd_mapping_is_a_bijection(M, N, K):
                     np.testing.assert_array_equal(acc.cpu().numpy(), acc_ref, err_msg=f"tile {tile} xm {xm} splits {splits}")
     finally:
         o.gemm_debug_force(-1, 0)
+
+
+def test_random_shapes_tiles_and_epilogues_against_the_oracle():
+    """Seeded sweep over ragged shapes, every kernel family, split-K, XCD m-groups and the optional
+    epilogue terms: int32 accumulators and the dequantised output bit for bit against the oracle."""
+    o = ops()
+    rng = np.random.default_rng(20261002)
+    tiles_w4 = list(WS_TILES) + [1, 3, 13, 2, 10, 26, 31, 35]
+    tiles_w8 = [t for t in WS_TILES if t not in (42, 48, 49, 50, 51)] + [3, 2, 10, 26, 31]
+    o.splitk_workspace(torch.device(DEV), 64 << 20)
+    try:
+        for case in range(48):
+            w_bits = 4 if case % 3 else 8
+            M = int(rng.integers(1, 700))
+            N = int(rng.integers(1, 90)) * 8
+            K = int(rng.integers(1, 12)) * 128
+            tile = int(rng.choice(tiles_w4 if w_bits == 4 else tiles_w8))
+            splits = int(rng.choice([1, 1, 2, 3]))
+            xm = int(rng.choice([0, 1, 2, 4]))
+            a = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+            w = _levels(case, (N, K), w_bits)
+            s_w = rng.uniform(0.001, 0.01, size=N).astype(np.float32)
+            bias = rng.normal(size=N).astype(np.float32) if case % 2 else None
+            sel = (rng.random(M) < 0.4).astype(np.uint8) if case % 4 == 1 else None
+            use_x0 = case % 5 == 2
+            x0 = rng.normal(size=M).astype(np.float32) if use_x0 else None
+            w0 = rng.normal(size=N).astype(np.float32) if use_x0 else None
+            out_dtype = (torch.float16, torch.bfloat16, torch.float32)[case % 3]
+            w_eff = w.copy()
+            acc_ref = oracle.gemm_i32(a, w_eff)
+            y_ref = oracle.round_to(oracle.epilogue(acc_ref, np.float32(0.02), s_w, bias=bias, sx1=np.float32(0.05),
+                                                    row_sel=sel, x0=x0, w0=w0), MODE[out_dtype])
+            at = o.TiledAct.from_rows(to_dev(a))
+            img = o.prepack(to_dev(w), w_bits)
+            tag = f"case {case}: M={M} N={N} K={K} w{w_bits} tile {tile} splits {splits} xm {xm} {out_dtype}"
+            o.gemm_debug_force(tile, splits | (xm << 8))
+            np.testing.assert_array_equal(o.gemm_w4a8_i32(at, img, w_bits, N).cpu().numpy(), acc_ref, err_msg=tag)
+            y = o.gemm_w4a8(at, img, w_bits, N, 0.02, to_dev(s_w), s_x1=0.05, row_sel=None if sel is None else to_dev(sel),
+                            bias=None if bias is None else to_dev(bias), x0=None if x0 is None else to_dev(x0),
+                            w0=None if w0 is None else to_dev(w0), out_dtype=out_dtype)
+            np.testing.assert_array_equal(y.float().cpu().numpy(), y_ref, err_msg=tag)
+    finally:
+        o.gemm_debug_force(-1, 0)
