@@ -44,7 +44,8 @@ class BaseObserver:
 
     def _asymmetric_params(self, min_val, max_val):
         qmin, qmax = self._bounds()
-        scale = (max_val - min_val) / float(qmax - qmin)
+        span = torch.tensor(float(qmax - qmin), dtype=max_val.dtype, device=max_val.device)   # tensor / tensor: see minmax.py
+        scale = (max_val - min_val) / span
         scale.clamp_(self.eps)
         zero_point = qmin - torch.round(min_val / scale)
         zero_point.clamp_(qmin, qmax)

@@ -49,6 +49,10 @@ class MinmaxObserver(BaseObserver):
         qmin, qmax = self._bounds()
         if not self.symmetric:
             return self._asymmetric_params(self.min_val, self.max_val)
-        scale = torch.max(torch.abs(self.min_val / qmin), torch.abs(self.max_val / qmax))
+        # tensor / tensor: torch's CUDA kernel turns "tensor / python scalar" into a multiplication by the
+        # reciprocal (one ulp off the IEEE quotient the reference's CPU run -- and the goldens -- have)
+        lo = torch.tensor(float(qmin), dtype=self.min_val.dtype, device=self.min_val.device)
+        hi = torch.tensor(float(qmax), dtype=self.max_val.dtype, device=self.max_val.device)
+        scale = torch.max(torch.abs(self.min_val / lo), torch.abs(self.max_val / hi))
         scale.clamp_(self.eps)
         return scale, torch.zeros_like(self.max_val, dtype=torch.int64)

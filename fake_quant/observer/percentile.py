@@ -39,6 +39,8 @@ class PercentileObserver(BaseObserver):
         if not self.symmetric:
             return self._asymmetric_params(self.min_val, self.max_val)
         qmin, qmax = self._bounds()
-        scale = torch.max(torch.abs(self.min_val / qmin), torch.abs(self.max_val / qmax))
+        lo = torch.tensor(float(qmin), dtype=self.min_val.dtype, device=self.min_val.device)   # tensor / tensor: see minmax.py
+        hi = torch.tensor(float(qmax), dtype=self.max_val.dtype, device=self.max_val.device)
+        scale = torch.max(torch.abs(self.min_val / lo), torch.abs(self.max_val / hi))
         scale.clamp_(self.eps)
         return scale, torch.zeros_like(self.max_val, dtype=torch.int64)

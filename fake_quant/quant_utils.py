@@ -392,8 +392,13 @@ class ActQuantWrapper(torch.nn.Module):
             return False
         name, _ = self._weight_module()
         wq = self.weight_quantizers.get(name)
-        if wq is None or not getattr(wq, "sym", False) or wq.bits not in (4, 8):
+        if wq is None or wq.bits not in (4, 8):
             return False
+        if not getattr(wq, "sym", False):
+            # asymmetric weights (--w_asym): their zero points use the rank-1 epilogue term, which the split
+            # column and asymmetric activations need for themselves; per-channel only
+            if self.split or not getattr(wq, "perchannel", False) or (not qz.static and not getattr(qz, "sym", False)):
+                return False
         if qz.static and (qz.quantizer.scale is None or qz.quantizer.scale.numel() != 1):
             return False                                   # channel_wise scales: simulated path
         mod = self.module
@@ -424,14 +429,26 @@ class ActQuantWrapper(torch.nn.Module):
         scale = wq.scale.reshape(-1).to(device=device, dtype=torch.float32)
         if scale.numel() == 1:
             scale = scale.expand(W2.shape[0]).contiguous()
-        levels = ops.weight_levels(W2, scale, wq.bits)
+        w_shift = None
+        if getattr(wq, "sym", False):
+            levels = ops.weight_levels(W2, scale, wq.bits)
+        else:
+            # W~ = s_w (q - z_w), q in 0 .. 2^b - 1: rint(W~ / s_w) = q - z_w; stored level = q - 2^(b-1)
+            half = 1 << (wq.bits - 1)
+            zero = wq.zero.reshape(-1).to(device=device, dtype=torch.float32)
+            if zero.numel() == 1:
+                zero = zero.expand(W2.shape[0]).contiguous()
+            diff = torch.round(W2.float() / scale[:, None])        # |q - z_w| <= 255: exact also for half-precision W~
+            levels = (diff + (zero - float(half))[:, None]).clamp(-half, half - 1).to(torch.int8)
+            w_shift = scale * (float(half) - zero)
         # the attached quantizer must be the one that produced these weights (one scale per output
         # channel): levels * scale has to give the stored fake-quantized weight back, else the wrapper
         # would silently run on a different integer grid (e.g. a group-wise GPTQ quantizer that only
         # remembers its last column group)
         # (any weight is within half a step of SOME level, so the test is the MEAN distance: ~0.25 steps for
         # a foreign grid, at most a few 1e-2 for half-precision roundings of scale * level, 0 in fp32)
-        dev_steps = ((levels.float() * scale[:, None] - W2.float()).abs() / scale[:, None]).mean()
+        grid_w = levels.float() * scale[:, None] if w_shift is None else levels.float() * scale[:, None] + w_shift[:, None]
+        dev_steps = ((grid_w - W2.float()).abs() / scale[:, None]).mean()
         if float(dev_steps) > 0.12:
             raise RuntimeError(f"ActQuantWrapper: weights of '{name}' are not on the attached quantizer's grid "
                                f"(mean distance {float(dev_steps):.3g} quantization steps); refusing to build the integer backend")
@@ -457,7 +474,7 @@ class ActQuantWrapper(torch.nn.Module):
                            per_tensor=bool(qz.act_per_tensor))
         self._real = W4A8Linear(levels, scale, wq.bits,
                                 None if bias is None else bias.data.to(device), s0, s1,
-                                had=had, w0=w0, dynamic=dynamic)
+                                had=had, w0=w0, dynamic=dynamic, w_shift=w_shift)
         return self._real
 
     def _forward_real(self, x):

@@ -355,6 +355,16 @@ int mq_gemm_w4a8_i32_ws(const int8_t *a, long lda, const void *w, int w_bits,
                         long M, long N, long K_pad, int32_t *acc, long ldacc,
                         void *workspace, size_t workspace_bytes, void *stream);
 
+/* Scaled row sums of the int8 activation levels, for ASYMMETRIC weights (--w_asym; WeightQuantizer with
+ * sym = False, quant_utils.py:446-509).  With the weight levels stored as q - 2^(b-1) the fake-quantized
+ * weight is s_w[n] (stored + 2^(b-1) - z_w[n]); the zero points come back through the rank-1 epilogue term
+ *   x0[m] = s_x(m) * sum_k a[m][k]   (this function; s_x(m) as in the GEMM: s_x_rows[m], or s_x1 where
+ *                                     row_sel[m], else s_x0)
+ *   w0[n] = s_w[n] * (2^(b-1) - z_w[n])
+ * of mq_gemm_w4a8 / _rowscale_ws.  a: [M, K_pad] int8 with lda bytes per row or lda = MQ_LD_TILED. */
+int mq_act_rowsum_scaled(const int8_t *a, long lda, long M, long K_pad, float s_x0, float s_x1,
+                         const uint8_t *row_sel, const float *s_x_rows, float *out, void *stream);
+
 /* Tuning / test hook (process-wide, not part of the drop-in surface): force the tile shape
  * (-1 heuristic; ids as in csrc/gemm_w4a8.hip dispatch_tile) and the split-K factor (0 heuristic;
  * bits 8..15 of a positive value force the number of m-groups of the XCD mapping, 0 = automatic). */

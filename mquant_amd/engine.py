@@ -69,7 +69,8 @@ class W4A8Linear:
     def __init__(self, levels: torch.Tensor, s_w: torch.Tensor, w_bits: int,
                  bias: Optional[torch.Tensor], s_x0: float, s_x1: Optional[float] = None,
                  had: Optional[HadamardSpec] = None, w0: Optional[torch.Tensor] = None,
-                 in_features: Optional[int] = None, dynamic: Optional[dict] = None):
+                 in_features: Optional[int] = None, dynamic: Optional[dict] = None,
+                 w_shift: Optional[torch.Tensor] = None):
         assert levels.is_cuda and levels.dtype == torch.int8 and levels.dim() == 2
         self.N, self.K = levels.shape
         self.K_pad = ops.ceil_to(self.K, 128)
@@ -79,6 +80,11 @@ class W4A8Linear:
         self.s_w = s_w.reshape(-1).to(torch.float32).contiguous()
         self.bias = None if bias is None else bias.reshape(-1).to(torch.float32).contiguous()
         self.w0 = None if w0 is None else w0.reshape(-1).to(torch.float32).contiguous()
+        #: asymmetric weights (--w_asym): levels are stored minus 2^(bits-1) and w_shift[n] = s_w[n] (2^(bits-1) -
+        #: z_w[n]); the zero points come back as the rank-1 term (s_x sum_k a[m][k]) * w_shift[n] -- the slot of
+        #: the split column, so not both
+        self.w_shift = None if w_shift is None else w_shift.reshape(-1).to(torch.float32).contiguous()
+        assert not (self.split and self.w_shift is not None), "asymmetric weights and the split column share the rank-1 epilogue term"
         self.s_x0 = float(s_x0)
         self.s_x1 = None if s_x1 is None else float(s_x1)
         self.had = had
@@ -88,7 +94,7 @@ class W4A8Linear:
         self.dynamic = dynamic
         self.w_colsum = None
         if dynamic is not None and not dynamic.get("sym", True):
-            assert not self.split, "asymmetric activations and the split column share the rank-1 epilogue term"
+            assert not self.split and self.w_shift is None, "asymmetric activations need the rank-1 epilogue term for themselves"
             self.w_colsum = (levels.to(torch.int32).sum(dim=1).to(torch.float32) * self.s_w).contiguous()
         self.in_features = self.K if in_features is None else in_features
         if had is not None:
@@ -145,15 +151,21 @@ class W4A8Linear:
 
     def gemm(self, a: torch.Tensor, x0: Optional[torch.Tensor], out_dtype: torch.dtype,
              row_sel: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+        w0 = self.w0
+        if self.w_shift is not None:
+            x0, w0 = ops.act_rowsum_scaled(a, self.s_x0, self.s_x1, row_sel), self.w_shift
         return ops.gemm_w4a8(a, self.w_img, self.w_bits, self.N, self.s_x0, self.s_w,
-                             s_x1=self.s_x1, row_sel=row_sel, bias=self.bias, x0=x0, w0=self.w0,
+                             s_x1=self.s_x1, row_sel=row_sel, bias=self.bias, x0=x0, w0=w0,
                              out_dtype=out_dtype, out=out)
 
     def gemm_residual(self, a: torch.Tensor, x0: Optional[torch.Tensor], residual: torch.Tensor,
                       row_sel: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
         """residual + Linear in one launch (same rounding as torch's `hidden + linear(x)`)."""
+        w0 = self.w0
+        if self.w_shift is not None:
+            x0, w0 = ops.act_rowsum_scaled(a, self.s_x0, self.s_x1, row_sel), self.w_shift
         return ops.gemm_w4a8_residual(a, self.w_img, self.w_bits, self.N, self.s_x0, self.s_w, residual,
-                                      s_x1=self.s_x1, row_sel=row_sel, bias=self.bias, x0=x0, w0=self.w0, out=out)
+                                      s_x1=self.s_x1, row_sel=row_sel, bias=self.bias, x0=x0, w0=w0, out=out)
 
     def forward_dynamic(self, x2: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """[Hadamard ->] dynamic per-token quantize -> GEMM with per-row scales.  The row maximum
@@ -165,17 +177,23 @@ class W4A8Linear:
             asym = self.w_colsum is not None
             a, s_rows, _, shift, x0 = ops.quantize_act_tensor_i8(x2, self.dynamic["bits"], self.dynamic["clip_ratio"],
                                                                  asym=asym, skip_col0=self.split, out=a)
+            w0 = self.w_colsum if asym else self.w0
+            x0 = shift if asym else x0
+            if self.w_shift is not None:
+                x0, w0 = ops.act_rowsum_scaled(a, s_x_rows=s_rows), self.w_shift
             return ops.gemm_w4a8_rowscale(a, self.w_img, self.w_bits, self.N, s_rows, self.s_w, bias=self.bias,
-                                          x0=shift if asym else x0, w0=self.w_colsum if asym else self.w0,
-                                          out_dtype=x2.dtype, out=out)
+                                          x0=x0, w0=w0, out_dtype=x2.dtype, out=out)
         if self.w_colsum is not None:
             a, s_rows, _, shift = ops.quantize_act_dyn_asym_i8(x2, self.dynamic["bits"], self.dynamic["clip_ratio"], out=a)
             return ops.gemm_w4a8_rowscale(a, self.w_img, self.w_bits, self.N, s_rows, self.s_w, bias=self.bias,
                                           x0=shift, w0=self.w_colsum, out_dtype=x2.dtype, out=out)
         a, s_rows, x0 = ops.quantize_act_dyn_i8(x2, self.dynamic["bits"], self.dynamic["clip_ratio"],
                                                 skip_col0=self.split, out=a)
+        w0 = self.w0
+        if self.w_shift is not None:
+            x0, w0 = ops.act_rowsum_scaled(a, s_x_rows=s_rows), self.w_shift
         return ops.gemm_w4a8_rowscale(a, self.w_img, self.w_bits, self.N, s_rows, self.s_w, bias=self.bias,
-                                      x0=x0, w0=self.w0, out_dtype=x2.dtype, out=out)
+                                      x0=x0, w0=w0, out_dtype=x2.dtype, out=out)
 
     def forward(self, x: torch.Tensor, row_sel: Optional[torch.Tensor] = None,
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -525,6 +525,20 @@ def quantize_act_tensor_i8(x: torch.Tensor, bits: int = 8, clip_ratio: float = 1
 
 
 @_on_device
+def act_rowsum_scaled(a, s_x0: float = 1.0, s_x1: Optional[float] = None, row_sel: Optional[torch.Tensor] = None,
+                      s_x_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """s_x(m) * sum_k a[m][k] per row of the int8 activations (``mq_act_rowsum_scaled``): the row factor of
+    the rank-1 epilogue term that carries the zero points of asymmetric weights."""
+    _need_cuda(a if not isinstance(a, TiledAct) else a.data, row_sel, s_x_rows)
+    aptr, lda, M, K_pad = _a_args(a)
+    dev = a.data.device if isinstance(a, TiledAct) else a.device
+    out = torch.empty((M,), dtype=torch.float32, device=dev)
+    call("mq_act_rowsum_scaled", aptr, lda, M, K_pad, float(s_x0), float(s_x0 if s_x1 is None else s_x1),
+         _ptr(row_sel), _ptr(s_x_rows), out.data_ptr(), _stream())
+    return out
+
+
+@_on_device
 def gemm_w4a8_rowscale(a: torch.Tensor, w_img: torch.Tensor, w_bits: int, N: int, s_x_rows: torch.Tensor,
                        s_w: torch.Tensor, *, bias: Optional[torch.Tensor] = None, x0: Optional[torch.Tensor] = None,
                        w0: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.float16,

@@ -275,6 +275,18 @@ def wquant_sym(w, bits=4, mse=False, norm=2.4, grid=100, maxshrink=0.8, want_lev
     return scale, levels
 
 
+def wquant_asym(w, bits=4, mse=False, norm=2.4, grid=100, maxshrink=0.8, want_levels=True):
+    """quant_utils.py:446-509 (sym = False): per-channel (scale, zero, stored levels q - 2^(bits-1))."""
+    w = _f32(w)
+    N, K = w.shape
+    scale, zero = np.empty(N, dtype=np.float32), np.empty(N, dtype=np.float32)
+    levels = np.empty((N, K), dtype=np.int8) if want_levels else None
+    lib().orc_wquant_asym(_p(w, C.c_float), C.c_long(N), C.c_long(K), C.c_int(bits), C.c_int(int(mse)),
+                          C.c_float(norm), C.c_int(grid), C.c_float(maxshrink), _p(scale, C.c_float),
+                          _p(zero, C.c_float), _p(levels, C.c_int8))
+    return scale, zero, levels
+
+
 def gptq_block(W1, Hb, scale, bits):
     """Column loop of one GPTQ block (reference gptq_utils.py:249-286, symmetric per-channel
     quantizer without groups).  W1 [N, cols], Hb = Hinv[i1:i2, i1:i2], scale [N] -> (Q1, Err1)."""

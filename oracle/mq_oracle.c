@@ -566,6 +566,56 @@ void orc_wquant_sym(const float *w, long N, long K, int bits, int mse,
     }
 }
 
+/* Asymmetric per-channel weight quantizer (--w_asym), quant_utils.py:446-509 with sym = False:
+ *   xmin = min(min_k w, 0); xmax = max(max_k w, 0); both 0 -> (-1, +1)
+ *   scale = max(xmax - xmin, 1e-5) / maxq; zero = round(-xmin / scale); maxq = 2^bits - 1
+ *   mse: for i < maxshrink*grid: p = 1 - i/grid; scale1 = (p xmax - p xmin) / maxq; zero1 = round(-p xmin / scale1);
+ *        err = sum_k |scale1 (clamp(round(w/scale1) + zero1, 0, maxq) - zero1) - w|^norm; keep the first minimum
+ * levels (optional): q - 2^(bits-1) with q = clamp(round(w / scale) + zero, 0, maxq) -- the form the int GEMM stores. */
+void orc_wquant_asym(const float *w, long N, long K, int bits, int mse, float norm, int grid, float maxshrink,
+                     float *scale, float *zero, int8_t *levels)
+{
+    const float maxq = (float)((1 << bits) - 1), half = (float)(1 << (bits - 1));
+    for (long n = 0; n < N; ++n) {
+        const float *r = w + n * K;
+        float mn = 0.0f, mx = 0.0f;
+        for (long k = 0; k < K; ++k) { if (r[k] < mn) mn = r[k]; if (r[k] > mx) mx = r[k]; }
+        if (mn == 0.0f && mx == 0.0f) { mn = -1.0f; mx = 1.0f; }
+        float d = mx - mn;
+        if (d < 1e-5f) d = 1e-5f;
+        float s = d / maxq;
+        float z = rintf(-mn / s);
+        if (mse) {
+            float best = INFINITY;
+            const int steps = (int)(maxshrink * (float)grid);
+            for (int i = 0; i < steps; ++i) {
+                const float p = (float)(1.0 - (double)i / (double)grid);
+                const float mn1 = p * mn, mx1 = p * mx;
+                const float s1 = (mx1 - mn1) / maxq;
+                const float z1 = rintf(-mn1 / s1);
+                float err = 0.0f;
+                for (long k = 0; k < K; ++k) {
+                    float q = rintf(r[k] / s1) + z1;
+                    if (q < 0.0f) q = 0.0f;
+                    if (q > maxq) q = maxq;
+                    const float dq = s1 * (q - z1);
+                    err += orc_pow_pos(fabsf(dq - r[k]), norm);
+                }
+                if (err < best) { best = err; s = s1; z = z1; }
+            }
+        }
+        scale[n] = s;
+        zero[n] = z;
+        if (levels)
+            for (long k = 0; k < K; ++k) {
+                float q = rintf(r[k] / s) + z;
+                if (q < 0.0f) q = 0.0f;
+                if (q > maxq) q = maxq;
+                levels[n * K + k] = (int8_t)(q - half);
+            }
+    }
+}
+
 /* GPTQ lazy-batch block, per-column loop -- reference fake_quant/gptq/gptq_utils.py:249-286 with
  * the symmetric per-channel quantizer without groups (quant_utils.py sym_quant_dequant: scale *
  * clamp(round(w / scale), -(maxq+1), maxq)):

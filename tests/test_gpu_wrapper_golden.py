@@ -189,3 +189,82 @@ def test_conv3d_patch_embed_runs_as_gemm():
     s_w = quantizers["pe"].scale.float().numpy().reshape(-1)
     ref = oracle.round_to(oracle.epilogue(oracle.gemm_i32(q, np.rint(W / s_w[:, None]).astype(np.int8)), s, s_w), 1)
     np.testing.assert_array_equal(y.float().cpu().numpy().reshape(32, 64), ref)
+
+
+# ---------------------------------------------------------------------------- asymmetric weights
+from test_oracle_golden import WASYM_CASES  # noqa: E402
+
+
+def test_rowsum_kernel_matches_the_integer_sum():
+    from mquant_amd import ops
+    rng = np.random.default_rng(3)
+    for M, K in ((1, 128), (37, 1280), (768, 19968)):
+        a = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+        sel = (rng.random(M) < 0.5).astype(np.uint8)
+        s_rows = rng.uniform(0.001, 0.1, size=M).astype(np.float32)
+        want_static = np.where(sel != 0, np.float32(0.05), np.float32(0.02)) * a.astype(np.int64).sum(axis=1).astype(np.float32)
+        want_rows = s_rows * a.astype(np.int64).sum(axis=1).astype(np.float32)
+        for act in (torch.from_numpy(a).to(DEV), ops.TiledAct.from_rows(torch.from_numpy(a).to(DEV))):
+            got = ops.act_rowsum_scaled(act, 0.02, 0.05, torch.from_numpy(sel).to(DEV))
+            np.testing.assert_array_equal(got.cpu().numpy(), want_static)
+            got = ops.act_rowsum_scaled(act, s_x_rows=torch.from_numpy(s_rows).to(DEV))
+            np.testing.assert_array_equal(got.cpu().numpy(), want_rows)
+
+
+@pytest.mark.parametrize("case", WASYM_CASES)
+def test_wrapper_with_asymmetric_weights_matches_reference_forward(golden_dir, case):
+    """--w_asym on the real-integer path: weights stored minus 2^(bits-1), zero points restored by the
+    rank-1 epilogue term (mq_act_rowsum_scaled x s_w (2^(bits-1) - z_w))."""
+    import functools
+    from fake_quant import hadamard_utils as hu, quant_utils as qu, utils
+    from fake_quant.gptq.rtn import rtn_module
+    from golden_inputs import make_w, make_x
+    from mquant_amd import ops
+    g = np.load(os.path.join(golden_dir, f"wrapper_wasym_{case}.npz"))
+    K_in, K_pad, N, M, seed, had, bias, w_bits, w_mse, dynamic = [int(v) for v in g["meta"]]
+    lin = torch.nn.Linear(K_pad, N, bias=bool(bias))
+    lin.weight.data = torch.from_numpy(make_w(seed, (N, K_pad)))
+    if bias:
+        lin.bias.data = torch.from_numpy(make_w(seed + 1, (N,), std=0.1))
+    wrap = qu.ActQuantWrapper(lin.to(DEV))
+    if had:
+        hadK, Kh = hu.get_hadK(K_pad)
+        wrap.online_full_had, wrap.had_K, wrap.K = True, hadK, Kh
+    if K_pad != K_in:
+        wrap.register_forward_pre_hook(functools.partial(utils.revise_down_input, new_size=K_pad))
+    quantizers = {}
+    rtn_module(wrap, "layer", w_bits, False, bool(w_mse), [], quantizers)
+    wq = wrap.weight_quantizers["module"]
+    np.testing.assert_array_equal(wq.scale.reshape(-1).cpu().numpy(), g["s_w"])
+    np.testing.assert_array_equal(wq.zero.reshape(-1).cpu().numpy(), g["z_w"])
+    if dynamic:
+        wrap.quantizer.configure(bits=8, sym=True, clip_ratio=1.0)
+    else:
+        wrap.quantizer.configure(bits=8, sym=True, static=True, observer_type="minmax")
+
+        class A:
+            skip_names = []
+        calib = [torch.from_numpy(make_x(seed + 10 + i, (M, K_in))).to(DEV) for i in range(3)]
+        qu.calib_layer(wrap, calib, A())
+        np.testing.assert_array_equal(np.float32(wrap.quantizer.quantizer.scale.cpu().numpy()), g["s_x"])
+    x = torch.from_numpy(make_x(seed + 20, (M, K_in))).to(DEV)
+    assert wrap._real_ready(x), "asymmetric weights must run the real kernels"
+    y = wrap(x)
+    real = wrap._real
+    assert real is not None and real.w_shift is not None
+    np.testing.assert_allclose(y.cpu().numpy(), g["y"], rtol=0, atol=1e-3)
+    half = 1 << (w_bits - 1)
+    np.testing.assert_array_equal(real.w_shift.cpu().numpy(), g["s_w"] * (np.float32(half) - g["z_w"]))
+    # the integers of the kernels that ran
+    xr = x if K_pad == K_in else torch.nn.functional.pad(x, (0, K_pad - K_in))
+    xr = ops.hadamard(xr, real.had.n, real.had.K, real.had.bits) if had else xr
+    if dynamic:
+        a, _, _ = ops.quantize_act_dyn_i8(xr, 8, 1.0)
+    else:
+        a, _ = ops.quantize_act_i8(xr, float(g["s_x"]))
+    np.testing.assert_array_equal(ops.gemm_w4a8_i32(a, real.w_img, w_bits, N).cpu().numpy(), g["acc"])
+    # combinations that need the rank-1 slot twice keep the simulated path
+    wrap2 = qu.ActQuantWrapper(torch.nn.Linear(256, 32).to(DEV))
+    rtn_module(wrap2, "layer", 4, False, False, [], {})
+    wrap2.quantizer.configure(bits=8, sym=False)
+    assert not wrap2._real_ready(torch.zeros(4, 256, device=DEV))

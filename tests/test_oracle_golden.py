@@ -303,3 +303,43 @@ def test_per_tensor_dynamic_wrapper_layer_against_reference(golden_dir, had_tabl
         x0, w0 = (x[:, 0], W[:, 0]) if split else (None, None)
     y = oracle.epilogue(acc, np.full(M, s, np.float32), s_w, bias=b, x0=x0, w0=w0)
     np.testing.assert_allclose(y, g["y"], rtol=0, atol=1e-3)
+
+
+WASYM_CASES = ["plain_3584", "mse_1280", "w8_2048", "down_19968", "dyn_3584"]
+
+
+@pytest.mark.parametrize("case", WASYM_CASES)
+def test_asymmetric_weight_wrapper_layer_against_reference(golden_dir, had_table, case):
+    """--w_asym: per-channel scale and zero point of the weights (quant_utils.py:446-509); the int GEMM
+    stores q - 2^(bits-1), the zero points return through the rank-1 term (s_x rowsum_a) * s_w (2^(bits-1) - z_w)."""
+    from golden_inputs import make_w, make_x
+    g = np.load(os.path.join(golden_dir, f"wrapper_wasym_{case}.npz"))
+    K_in, K_pad, N, M, seed, had, bias, w_bits, w_mse, dynamic = [int(v) for v in g["meta"]]
+    W = make_w(seed, (N, K_pad))
+    s_w, z_w, levels = oracle.wquant_asym(W, bits=w_bits, mse=bool(w_mse))
+    np.testing.assert_array_equal(s_w, g["s_w"])
+    np.testing.assert_array_equal(z_w, g["z_w"])
+    np.testing.assert_array_equal(levels[:, :64], g["qw_head"])
+    x = make_x(seed + 20, (M, K_in))
+    if K_pad != K_in and not had:
+        x = np.pad(x, ((0, 0), (0, K_pad - K_in)))
+    if had:
+        K = had_table["n2k"][K_pad]
+        x = oracle.hadamard(x, K_pad, K, had_table["mats"][K], mid_round=0, out_round=0)
+    if dynamic:
+        q, s_rows = oracle.quant_dyn(x, bits=8, clip=1.0)
+        np.testing.assert_array_equal(s_rows, g["s_rows"])
+        s_x = s_rows
+    else:
+        s_x = np.float32(g["s_x"])
+        q = oracle.quant_static(x, s_x)
+        s_x = np.full(M, s_x, np.float32)
+    acc = oracle.gemm_i32(q, levels)
+    np.testing.assert_array_equal(acc, g["acc"])
+    rowsum = q.astype(np.int64).sum(axis=1)
+    np.testing.assert_array_equal(rowsum, g["qx_sum"])
+    b = make_w(seed + 1, (N,), std=0.1) if bias else None
+    x0 = s_x * rowsum.astype(np.float32)
+    w0 = s_w * (np.float32(1 << (w_bits - 1)) - z_w)
+    y = oracle.epilogue(acc, s_x, s_w, bias=b, x0=x0, w0=w0)
+    np.testing.assert_allclose(y, g["y"], rtol=0, atol=1e-3)
