@@ -50,6 +50,9 @@ def export_wrapper(wrapper, device=None) -> Dict[str, torch.Tensor]:
     if wq is None or not getattr(qz, "static", False) or qz.quantizer.scale is None:
         raise ValueError("export needs a wrapper with a static calibrated activation quantizer and an "
                          "attached symmetric WeightQuantizer")
+    if not getattr(wq, "sym", False):
+        raise ValueError("the flat checkpoint stores symmetric weight levels only; a wrapper whose weights were "
+                         "quantized asymmetrically (--w_asym) runs from the in-memory engine, not from this format")
     device = device or wmod.weight.device
     W = wmod.weight.data.to(device)
     W2 = W.reshape(W.shape[0], -1)
