@@ -24,6 +24,7 @@ class EmaObserver(BaseObserver):
             return self._asymmetric_params(self.min_val, self.max_val)
         qmin, qmax = self._bounds()
         span = torch.max(-self.min_val, self.max_val)
-        scale = span / (float(qmax - qmin) / 2)
+        half = torch.tensor(float(qmax - qmin) / 2, dtype=span.dtype, device=span.device)   # tensor / tensor: see minmax.py
+        scale = span / half
         scale.clamp_(self.eps)
         return scale, torch.zeros_like(span, dtype=torch.int64)
