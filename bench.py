@@ -78,7 +78,7 @@ def cpu_baseline_reference(budget_s: float = 40.0):
     probe = next((sp for sp in specs if sp.name == "llm.o_proj"), specs[0])
     wrap, x = build(probe, 99)
     best, cores = None, 1
-    for t in sorted({c for c in (8, 16, 32, 64, 128, avail) if c <= avail}):
+    for t in sorted({c for c in (8, 16, 32, 64, 128) if c <= avail} | ({avail} if avail < 8 else set())):
         torch.set_num_threads(t)
         wrap(x)
         t0 = time.perf_counter()
@@ -87,6 +87,8 @@ def cpu_baseline_reference(budget_s: float = 40.0):
         dt = time.perf_counter() - t0
         if best is None or dt < best:
             best, cores = dt, t
+        elif dt > 1.5 * best:
+            break                                    # past the knee: more threads only over-subscribe
     torch.set_num_threads(cores)
     del wrap, x
 
