@@ -221,8 +221,19 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="small shapes (debug only; not a valid bench line)")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels one by one instead of replaying a hipGraph")
     ap.add_argument("--no-fuse", action="store_true", help="one GEMM per Linear (no q/k/v, gate/up fusion)")
+    ap.add_argument("--direct-engines", action="store_true",
+                    help="assemble the integer engines directly (workload.Prefill) instead of building the prefill THROUGH the "
+                         "drop-in API (module tree -> add_actquant -> RTN -> calibration protocol -> model_quant -> "
+                         "ActQuantWrapper.forward), which is the default for the Qwen2-VL-7B workload")
+    ap.add_argument("--via-wrappers", action="store_true", help="(default for qwen2vl_7b; kept for explicit command lines)")
+    ap.add_argument("--workload", default="qwen2vl_7b", choices=["qwen2vl_7b", "qwenvl_7b", "internvl2_8b", "qwen2vl_72b"],
+                    help="qwen2vl_7b is the benchmark configuration (BASELINE.json); the others are labelled secondary lines")
     ap.add_argument("--no-full-prefill", action="store_true",
                     help="skip the secondary report: whole synthetic prefill incl. attention/norms (torch glue)")
+    ap.add_argument("--no-logits", action="store_true",
+                    help="leave the per-step logits (fp16 lm_head on the last position, side stream) out of the step")
+    ap.add_argument("--had-fast", action="store_true",
+                    help="non-default Hadamard mode: K x K stage on the fp16 matrix core (not bit-identical; labelled)")
     ap.add_argument("--ttft-iters", type=int, default=100)
     ap.add_argument("--batch", type=int, default=1,
                     help="image+prompt samples per GPU and step (the benchmark configuration is 1; >1 is a scaling study)")
@@ -249,7 +260,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # under torch.distributed.run the process group exists at EVERY world size, 1 included: the RCCL
+    # initialisation and the all_gather then run on a one-GPU box too (tests/test_gpu_multi.py)
+    distributed = "WORLD_SIZE" in os.environ
     if args.cpu_selftest:
         from mquant_amd import shard
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -267,50 +280,100 @@ def main():
         sys.exit(0 if ok else 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    torch.set_grad_enabled(False)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
-    from mquant_amd import workload
+    from mquant_amd import ops, workload
 
-    specs = workload.tiny_specs() if args.tiny else workload.qwen2vl_7b_specs(msq=True, batch=args.batch)
-    pf = workload.Prefill(specs, device=dev, dtype=torch.float16, share_groups=not args.no_fuse)
+    if args.had_fast:
+        ops.hadamard_fast_mode(True)     # process-wide switch of the K x K stage (include/mquant_hip.h)
+    headline = args.workload == "qwen2vl_7b" and not args.tiny
+    build_specs, workload_desc = workload.WORKLOADS[args.workload]
+    specs = workload.tiny_specs() if args.tiny else build_specs(args.batch)
+    via_wrappers = (headline or args.via_wrappers) and not args.direct_engines
+    pf, via_error = None, None
+    if via_wrappers:
+        try:
+            pf = workload.WrapperPrefill(specs, device=dev, dtype=torch.float16, fuse_siblings=not args.no_fuse)
+        except Exception as exc:          # never lose the bench line: fall back to the directly assembled engines, and say so
+            via_error, via_wrappers = repr(exc), False
+            torch.cuda.empty_cache()
+    if pf is None:
+        pf = workload.Prefill(specs, device=dev, dtype=torch.float16, share_groups=not args.no_fuse)
     tokens_per_step = workload.M_LLM * args.batch if not args.tiny else specs[-1].M
+    hidden = specs[-1].n
+    vocab = VOCAB if not args.tiny else 1024
 
-    # N > 1: sample i runs on rank i (one sample per rank and step); the exchanged tensor is the REAL
-    # last-token logits of this rank's sample from the whole synthetic prefill.  Static scales are
-    # replicated constants: every rank calibrates on sample 0 with the same seeds.
-    logits_local, logits_all, fp_logits = None, None, None
-    if distributed and not args.tiny:
-        from mquant_amd import shard
+    # Per-step logits: the rank's sample ends in logits = lm_head(rms_norm(last position)) -- fp16, lm_head is
+    # not wrapped (reference quant_utils.py:560-564) -- computed from the step's final Linear output on a SIDE
+    # stream, so that it and (N > 1) the RCCL all_gather of the ranks' logits overlap the next sample's
+    # hot path; buffers alternate by step parity.  The real-logits parity check stays outside the timing.
+    with_logits = not args.no_logits
+    side = torch.cuda.Stream(device=dev)
+    lm_head, last_rows, logits_step, logits_all = None, None, None, None
+    if with_logits:
+        g = torch.Generator(device=dev).manual_seed(7)
+        lm_head = (torch.randn((vocab, hidden), generator=g, device=dev) * 0.02).to(torch.float16)
+        last_rows = [torch.zeros((1, hidden), dtype=torch.float16, device=dev) for _ in range(2)]
+        logits_step = [torch.zeros((1, vocab), dtype=torch.float16, device=dev) for _ in range(2)]
+        if distributed:
+            logits_all = [torch.zeros((world, vocab), dtype=torch.float16, device=dev) for _ in range(2)]
+
+    # N > 1: sample i runs on rank i; static scales are replicated constants (every rank calibrates on
+    # sample 0 with the same seeds).  The whole-prefill logits of this rank's sample, for the parity check:
+    fp_logits, logits_local = None, None
+    if distributed and headline and args.batch == 1 and not args.no_fuse:
         from mquant_amd.full_prefill import FullPrefill
         fp_logits = FullPrefill(pf, fused_glue=True)
         fp_logits.calibrate()
         fp_logits.set_sample(rank)
         logits_local = fp_logits.step().to(torch.float16).clone()
+        fp_logits.restore_hot_path_scales()      # the timed step runs on the hot path's own calibration
         torch.cuda.synchronize(dev)
-    elif distributed:
-        logits_local = torch.full((1, VOCAB), float(rank), dtype=torch.float16, device=dev)
-    if distributed:
-        logits_all = torch.zeros((world, VOCAB), dtype=torch.float16, device=dev)
 
-    def capture(fn):
-        """Launch-bound inner loop -> one hipGraph (the kernels themselves are unchanged)."""
+    def capture(fn, keep=None):
+        """Launch-bound inner loop -> one hipGraph (the kernels themselves are unchanged).  ``keep`` receives
+        the function's return value (the output tensor of the step's last Linear)."""
+        keep = keep if keep is not None else [None]
         if args.no_graph:
-            return fn
+            def eager():
+                keep[0] = fn()
+            eager()
+            return eager
         fn()                      # first-call allocations / attribute setup happen outside capture
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            fn()
+            keep[0] = fn()
         return g.replay
 
-    run_prefill = capture(pf.step)
+    final_out = [None]                   # [M, hidden]: output of the last Linear of the step (down_proj)
+    run_prefill = capture(pf.step, final_out)
+    counter = [0]
+    side_done = [None, None]
 
     def step():
         run_prefill()
-        if distributed:
-            dist.all_gather_into_tensor(logits_all, logits_local)
+        if not with_logits:
+            return
+        par = counter[0] & 1
+        counter[0] += 1
+        main = torch.cuda.current_stream(dev)
+        if side_done[par] is not None:
+            main.wait_event(side_done[par])          # the side stream has finished with this parity's buffers
+        last_rows[par].copy_(final_out[0][-1:])
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            h = torch.nn.functional.rms_norm(last_rows[par], (hidden,), eps=1e-6)
+            torch.matmul(h, lm_head.t(), out=logits_step[par])
+            if distributed:
+                dist.all_gather_into_tensor(logits_all[par], logits_step[par])
+            side_done[par] = torch.cuda.Event()
+            side_done[par].record(side)
 
     def fence():
         if distributed:
@@ -333,42 +396,56 @@ def main():
     value = world * tokens_per_step * args.steps / elapsed
 
     logits_check = None
-    if distributed:
-        gathered = shard.gather_logits(logits_local, world) if not args.tiny else logits_all
+    if distributed and with_logits:
+        # what the timed steps exchanged: row r of the gathered tensor is rank r's logits of that step
+        par = (counter[0] - 1) & 1
+        mine = logits_all[par][rank]
+        logits_check = {"step_exchange": {"all_gather_bytes": int(world * vocab * 2), "own_row_intact":
+                                          bool(torch.equal(mine, logits_step[par][0])),
+                                          "finite": bool(torch.isfinite(logits_all[par].float()).all().item())}}
+    if fp_logits is not None:
+        from mquant_amd import shard
+        gathered = shard.gather_logits(logits_local, world)
         torch.cuda.synchronize(dev)
-        if rank == 0 and fp_logits is not None:
+        if rank == 0:
             # rank r's result for sample r must equal the single-GPU result for the same sample
+            fp_logits.apply_full_prefill_scales()
             same = []
             for i in range(world):
                 fp_logits.set_sample(i)
                 ref = fp_logits.step().to(torch.float16)
                 same.append(bool(torch.equal(ref[0], gathered[i])))
-            logits_check = {"samples": world, "equal_to_single_gpu": all(same), "per_sample": same,
-                            "all_gather_bytes": int(world * VOCAB * 2)}
+            fp_logits.restore_hot_path_scales()
+            logits_check = dict(logits_check or {}, samples=world, equal_to_single_gpu=all(same), per_sample=same)
 
     # ---- kernel attribution: the GEMM launches of a step alone, HIP events on the launch stream
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = max(3, min(args.steps, 10))
-    run_gemms = capture(pf.step_gemm_only)
-    run_quants = capture(pf.step_quant_only)
-    run_gemms()
-    torch.cuda.synchronize(dev)
-    e0.record()
-    for _ in range(reps):
-        run_gemms()
-    e1.record()
-    torch.cuda.synchronize(dev)
-    gemm_ms = e0.elapsed_time(e1) / reps
-    e0.record()
-    for _ in range(reps):
-        run_quants()
-    e1.record()
-    torch.cuda.synchronize(dev)
-    quant_ms = e0.elapsed_time(e1) / reps
+
+    def timed(run):
+        run()
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / reps
+
+    hot_ms = timed(run_prefill)                      # the hot path alone (no logits, no exchange), stream-timed
+    gemm_ms = timed(capture(pf.step_gemm_only))
+    quant_ms = timed(capture(pf.step_quant_only))
+    lm_ms = None
+    if with_logits:
+        def lm_only():
+            h = torch.nn.functional.rms_norm(last_rows[0], (hidden,), eps=1e-6)
+            torch.matmul(h, lm_head.t(), out=logits_step[0])
+        lm_ms = timed(lm_only)
     launches = pf.gemm_launches()
-    traffic, traffic_note, traffic_source = None, "no profiles/r2_traffic.json", None
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_traffic.json")
-    if os.path.exists(tpath) and not args.tiny and args.batch == 1:
+    traffic, traffic_note, traffic_source = None, "no PMC traffic file for this workload", None
+    tpath = next((pth for pth in (os.path.join(ROOT, "profiles", nm) for nm in ("r3_traffic.json", "r2_traffic.json"))
+                  if os.path.exists(pth)), None)
+    if tpath and headline and args.batch == 1 and not args.no_fuse:
         # HBM bytes per GEMM launch from the PMC passes (tools/pmc_traffic.py); counters cannot be
         # read inside the timed run, so this is the committed measurement of the same command -- with
         # the commit and command it was taken at, so that a stale file is detectable
@@ -376,12 +453,17 @@ def main():
             tj = json.load(fh)
         traffic = tj["kernels"].get("gemm", {}).get("hbm_bytes_per_launch")
         traffic_note = tj["corrections"]
-        traffic_source = {"file": "profiles/r2_traffic.json", "measured_at_commit": tj.get("commit"),
+        traffic_source = {"file": os.path.relpath(tpath, ROOT), "measured_at_commit": tj.get("commit"),
                           "command": tj.get("command")}
     achieved = pf.gemm_ops() / (gemm_ms * 1e-3) / 1e12
+    step_tops = pf.gemm_ops() / (ms_per_step * 1e-3) / 1e12
     roofline = {"bound": "mfma", "kernel": "gemm_ws_kernel (V_MFMA_I32_32X32X32_I8) / gemm_w4a8_pipe_kernel 256x256 (V_MFMA_I32_16X16X64_I8)",
                 "achieved": round(achieved, 2), "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
-                "frac": round(achieved / PEAK_INT8_TOPS, 4), "traffic": traffic,
+                "frac": round(achieved / PEAK_INT8_TOPS, 4),
+                "step_frac": round(step_tops / PEAK_INT8_TOPS, 4),
+                "step_frac_note": "GEMM ops / ms_per_step / peak: the whole timed step (quantize and Hadamard launches included), "
+                                  "where frac covers the GEMM launches alone",
+                "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_note": traffic_note,
                 "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": round(pf.gemm_bytes() / launches),
@@ -390,30 +472,47 @@ def main():
                 "algorithmic_ops_per_launch": round(pf.gemm_ops() / launches),
                 "gemm_ms_per_step": round(gemm_ms, 4),
                 "quant_hadamard_ms_per_step": round(quant_ms, 4),
-                "quant_hadamard_GBps": round(pf.quant_bytes() / (quant_ms * 1e-3) / 1e9, 1)}
+                "quant_hadamard_GBps": round(pf.quant_bytes() / (quant_ms * 1e-3) / 1e9, 1),
+                "hot_path_ms_per_step_stream_timed": round(hot_ms, 4)}
 
+    n_lin = sum(sp.count for sp in specs)
+    desc = workload_desc + f", M_llm={workload.M_LLM}"
+    if args.batch != 1:
+        desc += f", x{args.batch} samples per step" + (" (scaling study, not the benchmark configuration)" if headline else "")
+    if not args.no_fuse:
+        desc += " (Linears fed the same tensor -- q/k/v, gate/up -- share one quantization and one GEMM)"
+    if not headline and not args.tiny:
+        desc = "SECONDARY LINE, not the benchmark configuration: " + desc
+    if args.had_fast:
+        desc = "NON-DEFAULT fast Hadamard mode (fp16 matrix-core K x K stage, not bit-identical to the reference): " + desc
     line = {"metric": "W4A8 prefill tokens/sec (hot path: Hadamard + static quant + W4A8 Linear), "
-                      "Qwen2-VL-7B 448px+512tok",
+                      + {"qwen2vl_7b": "Qwen2-VL-7B 448px+512tok", "qwenvl_7b": "Qwen-VL-7B 448px+512tok",
+                         "internvl2_8b": "InternVL2-8B 448px+512tok", "qwen2vl_72b": "Qwen2-VL-72B 448px+512tok"}[args.workload],
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int8",
-            "data": "synthetic (random weights with the real shapes, all 327 weight images distinct = 3.65 GB streamed per step; "
-                    "random activations with outlier channels; layers of equal (M, k_in) read the SAME synthetic input tensor and "
-                    "share one output buffer, which flatters the caches slightly on the activation side)",
-            "config": {"workload": "Qwen2-VL-7B W4A8 MSQ prefill, 1x448^2 image (1024 vision tokens) + "
-                                   "512 text tokens, 327 wrapped Linears, M_llm=768" + ("" if args.batch == 1 else f", x{args.batch} samples per step (scaling study, not the benchmark configuration)") + ("" if args.no_fuse else " (q/k/v and gate/up share one quantization and one GEMM)") if not args.tiny
-                       else "tiny debug shapes",
+            "data": f"synthetic (random weights with the real shapes, all {n_lin} weight images distinct = "
+                    f"{pf.weight_bytes() / 1e9:.2f} GB streamed per step; random activations with outlier channels; layers of equal "
+                    "(M, k_in) read the SAME synthetic input tensor, which flatters the caches slightly on the activation side)",
+            "config": {"workload": desc if not args.tiny else "tiny debug shapes",
+                       "path": ("fake_quant drop-in API: add_actquant -> RTN -> calibration protocol -> model_quant -> "
+                                "ActQuantWrapper.forward" if via_wrappers else "integer engines assembled directly (workload.Prefill)")
+                               + (f"; the wrapper build FAILED and was replaced: {via_error}" if via_error else ""),
+                       "step": "every wrapped Linear of one image+prompt prefill (quantize / Hadamard+quantize launch + GEMM launch each), one hipGraph"
+                               + ("; the sample's logits (fp16 lm_head on the last position)" + (" and the RCCL all_gather of the ranks' logits" if distributed else "")
+                                  + " follow on a side stream and overlap the next sample's hot path" if with_logits else ""),
                        "tokens_per_step_per_gpu": tokens_per_step, "parallelism": f"batch-shard x{world}",
-                       "ttft_hot_path_ms": round(ms_per_step, 4),
+                       "ttft_hot_path_ms": round(hot_ms, 4),
+                       "lm_head_ms": None if lm_ms is None else round(lm_ms, 4),
                        "gemm_TOP_per_step": round(pf.gemm_ops() / 1e12, 3),
                        "hip_graph": not args.no_graph,
                        "weights_GB": round(pf.weight_bytes() / 1e9, 3)},
             "roofline": roofline}
-    if not (args.tiny or args.no_full_prefill or args.no_fuse or args.batch != 1):
+    if headline and not (args.no_full_prefill or args.no_fuse or args.batch != 1):
         line["full_prefill"] = full_prefill_report(pf, dev, args)
     if logits_check is not None:
         line["logits_check"] = logits_check
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and headline:
         try:
             line["cpu_baseline"] = cpu_baseline_reference()
         except Exception as exc:  # the baseline is a report, never a reason to lose the line

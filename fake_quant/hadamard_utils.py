@@ -21,6 +21,8 @@ from functools import lru_cache
 import numpy as np
 import torch
 
+from fake_quant import utils
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 # order in which special factors are tried (reference :28-71; note 40 sits between 28 and 20)
@@ -146,6 +148,7 @@ def random_hadamard_matrix(size: int, device):
     signs = torch.randint(low=0, high=2, size=(size,)).to(torch.float64) * 2 - 1
     Q = matmul_hadU(torch.diag(signs)).to(device)
     Q._mq_signs = signs            # structure tag: rotation_utils.mul_q runs sign flip + fast Hadamard on the GPU
+    Q._mq_tag_version = utils.tensor_version(Q)  # any later in-place edit of Q moves the counter and voids the tag
     return Q
 
 

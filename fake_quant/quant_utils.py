@@ -103,6 +103,7 @@ def unpack_i4(x: torch.Tensor):
 
 # =============================================================================== MSQ mask
 _MSQ_STATE = {"mask": None}
+_ALL_TEXT_MASKS = {}
 
 
 @contextlib.contextmanager
@@ -127,7 +128,13 @@ def _row_mask(rows: int, device) -> torch.Tensor:
     m = _MSQ_STATE["mask"]
     if m is not None and m.numel() == rows:
         return m.to(device)
-    return torch.ones(rows, dtype=torch.uint8, device=device)
+    key = (rows, str(device))
+    ones = _ALL_TEXT_MASKS.get(key)
+    if ones is None:                 # one tensor per (rows, device): sibling wrappers see the SAME mask object
+        if len(_ALL_TEXT_MASKS) > 64:
+            _ALL_TEXT_MASKS.clear()
+        ones = _ALL_TEXT_MASKS[key] = torch.ones(rows, dtype=torch.uint8, device=device)
+    return ones
 
 
 # =============================================================================== ActQuantizer
@@ -321,12 +328,14 @@ class ActQuantWrapper(torch.nn.Module):
         self.pad_to = None              # folded revise_down_input hook
         self._real = None
         self._real_frozen = False       # engine installed from a flat checkpoint (no float weights)
+        self._group = None              # SiblingGroup: q/k/v, gate/up ... sharing one quantize + one GEMM
 
     # pickled checkpoints must not drag device handles along
     def __getstate__(self):
         state = self.__dict__.copy()
         state["_real"] = None
         state["_real_frozen"] = False
+        state["_group"] = None
         return state
 
     def extra_repr(self) -> str:
@@ -366,6 +375,9 @@ class ActQuantWrapper(torch.nn.Module):
     def invalidate_real(self):
         if not getattr(self, "_real_frozen", False):
             self._real = None
+        grp = self.__dict__.get("_group")
+        if grp is not None:
+            grp.reset()
 
     def install_real(self, engine) -> None:
         """Adopt an engine rebuilt from a flat checkpoint (mquant_amd.checkpoint.load_quantized):
@@ -386,7 +398,7 @@ class ActQuantWrapper(torch.nn.Module):
         if qz.static:
             if not (qz.quant and not qz.calibrate) or qz.bits != 8:
                 return False
-        elif not self._dynamic_real_ok():
+        elif not self._dynamic_real_ok(x.dtype):
             return False
         if x.dtype not in (torch.float16, torch.bfloat16, torch.float32):
             return False
@@ -409,7 +421,7 @@ class ActQuantWrapper(torch.nn.Module):
                 and tuple(x.shape[2:]) == tuple(mod.kernel_size)
                 and all(p == 0 for p in mod.padding) and mod.groups == 1)
 
-    def _dynamic_real_ok(self) -> bool:
+    def _dynamic_real_ok(self, x_dtype=torch.float32) -> bool:
         """Dynamic per-token int8 (the reference's default activation mode, quant_utils.py:205-268) also
         has real-integer kernels: symmetric, and asymmetric (``--a_asym``) when the wrapper is not split
         (the zero point travels through the same rank-1 epilogue term as the split column); per token or
@@ -417,11 +429,20 @@ class ActQuantWrapper(torch.nn.Module):
         qz = self.quantizer
         if not (2 <= qz.bits <= 8) or getattr(qz, "groupsize", -1) > 0:
             return False
+        if getattr(qz, "act_per_tensor", False) and x_dtype != torch.float32:
+            # the reference keeps the per-tensor range, scale, zero point AND x / scale in x's dtype
+            # (quant_utils.py:214-231: ``torch.tensor(0).to(x)``, ``xmax / self.maxq``): on half / bf16
+            # activations its grid differs from an fp32 evaluation by up to 2^-9 relative, so those stay on the
+            # bit-faithful simulated path; the integer kernels compute the range in fp32 = the fp32 case
+            return False
         return bool(getattr(qz, "sym", False)) or not self.split
 
-    def _build_real(self, device):
+    def _real_parts(self, device) -> dict:
+        """Everything the integer backend needs from this wrapper, on ``device``: weight levels and
+        scales recovered from the fake-quantized weight and its attached ``WeightQuantizer``, bias, the
+        split column, the Hadamard descriptor and the activation-quantizer parameters."""
         from mquant_amd import ops
-        from mquant_amd.engine import HadamardSpec, W4A8Linear
+        from mquant_amd.engine import HadamardSpec
         name, wmod = self._weight_module()
         wq = self.weight_quantizers[name]
         W = wmod.weight.data.to(device)
@@ -472,9 +493,15 @@ class ActQuantWrapper(torch.nn.Module):
         else:
             dynamic = dict(bits=int(qz.bits), clip_ratio=float(qz.clip_ratio), sym=bool(qz.sym),
                            per_tensor=bool(qz.act_per_tensor))
-        self._real = W4A8Linear(levels, scale, wq.bits,
-                                None if bias is None else bias.data.to(device), s0, s1,
-                                had=had, w0=w0, dynamic=dynamic, w_shift=w_shift)
+        return dict(levels=levels, scale=scale, bits=wq.bits,
+                    bias=None if bias is None else bias.data.to(device), s0=s0, s1=s1,
+                    had=had, w0=w0, dynamic=dynamic, w_shift=w_shift)
+
+    def _build_real(self, device):
+        from mquant_amd.engine import W4A8Linear
+        p = self._real_parts(device)
+        self._real = W4A8Linear(p["levels"], p["scale"], p["bits"], p["bias"], p["s0"], p["s1"],
+                                had=p["had"], w0=p["w0"], dynamic=p["dynamic"], w_shift=p["w_shift"])
         return self._real
 
     def _forward_real(self, x):
@@ -482,6 +509,13 @@ class ActQuantWrapper(torch.nn.Module):
             from mquant_amd._lib import MQuantHipError
             raise MQuantHipError("ActQuantWrapper: the quantized W4A8 path runs on the GPU only; "
                                  "there is no CPU fallback (got a CPU tensor)")
+        grp = self.__dict__.get("_group")
+        if grp is not None and grp.enabled:
+            rows = x.reshape(-1, x.shape[-1])
+            sel = _row_mask(rows.shape[0], x.device) if getattr(self.quantizer, "msq", False) else None
+            y = grp.forward(self, rows, sel)
+            if y is not None:
+                return y.reshape(*x.shape[:-1], y.shape[-1])
         real = self._real if self._real is not None else self._build_real(x.device)
         if isinstance(self.module, torch.nn.Linear):
             rows = x.reshape(-1, x.shape[-1])
@@ -551,6 +585,171 @@ class ActQuantWrapper(torch.nn.Module):
             x = oq(x).to(x_dtype)
             oq.free()
         return x
+
+
+# =============================================================================== sibling fusion
+#: leaf names of Linears that their parent module feeds the SAME tensor: the attention projections and
+#: the two input projections of a gated MLP (Qwen2 / Llama / SigLIP naming, InternLM2 ``w1``/``w3``, Qwen-VL
+#: v1 ``w1``/``w2``).  The names only nominate candidates; what is fused is decided by the checks below.
+SIBLING_LEAVES = {"q_proj": "attn", "k_proj": "attn", "v_proj": "attn",
+                  "gate_proj": "mlp", "up_proj": "mlp", "w1": "mlp", "w2": "mlp", "w3": "mlp"}
+
+
+class _GroupResult:
+    __slots__ = ("key", "rows", "sel", "y", "consumed")
+
+    def __init__(self, key, rows, sel, y, first):
+        self.key, self.rows, self.sel, self.y, self.consumed = key, rows, sel, y, {first}
+
+
+class SiblingGroup:
+    """Wrappers under one parent that quantize the same input with the same static scale set run as ONE
+    quantize + ONE GEMM over their concatenated output channels; each member's ``forward`` returns its
+    column slice (a view) of that product.  The reference wraps -- and evaluates -- every Linear on its
+    own (quant_utils.py:626-662); the result here is the same bit for bit because every output channel's
+    int32 accumulator, weight scale and bias are its own and the activation levels are shared by
+    construction (same input, same scale).
+
+    Correctness does not rest on the name lists: a member takes the shared product only when the tensor
+    it is handed IS the one the product was computed from (same storage, shape, strides, dtype and
+    version counter -- the group keeps that tensor alive meanwhile, so the address cannot be recycled)
+    and each member takes a product at most once.  Anything else recomputes; a group whose products
+    keep going unused dissolves itself and its members fall back to their own engines."""
+
+    def __init__(self, parent: str, members):
+        self.parent = parent
+        self.members = list(members)                       # [(leaf name, wrapper)]
+        self.index = {id(w): i for i, (_, w) in enumerate(self.members)}
+        self.enabled = True
+        self.engine = None
+        self.offsets = None
+        self._result = None
+        self._unused = 0
+        self.launches = 0                                  # fused GEMMs issued (tests, bench accounting)
+
+    def reset(self):
+        self.engine, self.offsets, self._result = None, None, None
+
+    def dissolve(self):
+        self.enabled = False
+        self.reset()
+        for _, w in self.members:
+            if w.__dict__.get("_group") is self:
+                w._group = None
+
+    def _build(self, rows) -> bool:
+        from mquant_amd.engine import W4A8Linear
+        parts = []
+        for _, w in self.members:
+            if not (w._real_ready(rows) and _fusable(w)):
+                return False
+            parts.append(w._real_parts(rows.device))
+        p0 = parts[0]
+        if any(p["s0"] != p0["s0"] or p["s1"] != p0["s1"] or p["bits"] != p0["bits"] or p["dynamic"] is not None
+               or p["w_shift"] is not None or p["levels"].shape[1] != p0["levels"].shape[1] for p in parts):
+            return False
+        bias = None
+        if any(p["bias"] is not None for p in parts):
+            bias = torch.cat([p["bias"].float() if p["bias"] is not None
+                              else torch.zeros(p["levels"].shape[0], device=rows.device) for p in parts])
+        ends, n = [], 0
+        for p in parts:
+            ends.append((n, n + p["levels"].shape[0]))
+            n += p["levels"].shape[0]
+        self.engine = W4A8Linear(torch.cat([p["levels"] for p in parts], dim=0),
+                                 torch.cat([p["scale"] for p in parts], dim=0), p0["bits"], bias, p0["s0"], p0["s1"])
+        self.offsets = ends
+        return True
+
+    def forward(self, wrapper, rows, sel):
+        """The column slice of ``wrapper`` in the shared product for ``rows``, or None (caller runs alone)."""
+        i = self.index[id(wrapper)]
+        key = (rows.data_ptr(), utils.tensor_version(rows), tuple(rows.shape), rows.stride(), rows.dtype,
+               None if sel is None else (sel.data_ptr(), utils.tensor_version(sel)))
+        res = self._result
+        if res is not None and res.key == key and i not in res.consumed:
+            res.consumed.add(i)
+            lo, hi = self.offsets[i]
+            y = res.y[:, lo:hi]
+            if len(res.consumed) == len(self.members):
+                self._result = None                        # everybody served: let the buffers go
+            return y
+        if res is not None:
+            # a product that only its producer used: siblings are being fed different tensors
+            self._unused = self._unused + 1 if len(res.consumed) == 1 else 0
+            if self._unused >= 3:
+                self.dissolve()
+                return None
+        if self.engine is None and not self._build(rows):
+            self.dissolve()
+            return None
+        y = self.engine.forward(rows, sel)
+        self.launches += 1
+        self._result = _GroupResult(key, rows, sel, y, i)
+        lo, hi = self.offsets[i]
+        return y[:, lo:hi]
+
+
+def real_engine(wrapper):
+    """The integer engine ``wrapper``'s quantized forward runs on -- its own, or its sibling group's -- or
+    None while it still simulates."""
+    grp = wrapper.__dict__.get("_group")
+    if grp is not None and grp.enabled and grp.engine is not None:
+        return grp.engine
+    return wrapper._real
+
+
+def _fusable(w) -> bool:
+    """Static per-tensor int8 activations, a plain nn.Linear, nothing that changes the input on the way
+    (pad, online Hadamard, split column) and nothing that claims the rank-1 epilogue term."""
+    qz = w.quantizer
+    return (isinstance(w.module, torch.nn.Linear) and bool(getattr(qz, "static", False)) and not w.split
+            and not w.online_full_had and not w.online_partial_had and w.pad_to is None
+            and not getattr(w, "_real_frozen", False) and w.real_quant and len(w._forward_pre_hooks) == 0
+            and getattr(getattr(qz, "quantizer", None), "scale", None) is not None
+            and qz.quantizer.scale.numel() == 1)
+
+
+def _scale_signature(w):
+    qz = w.quantizer
+    s0 = float(qz.quantizer.scale)
+    s1 = None
+    if qz.msq:
+        s1 = float(qz.quantizer_text.scale) if qz.quantizer_text.scale is not None else s0
+    wq = w.weight_quantizers.get("module")
+    return (w.module.in_features, s0, s1, None if wq is None else int(wq.bits), w.module.weight.dtype,
+            w.module.weight.device)
+
+
+def group_siblings(model, args=None) -> list:
+    """Form ``SiblingGroup``s under ``model`` (called by ``model_quant``): wrappers with the same parent,
+    a leaf name of the same ``SIBLING_LEAVES`` family, the same in_features and IDENTICAL calibrated
+    activation scale sets.  Module names, ``module`` / ``L1`` / ``L2`` sub-modules and pickles are
+    untouched; ``args.no_sibling_fusion`` switches it off.  Returns the groups formed."""
+    wrappers = find_qlayers(model, layers=[ActQuantWrapper])
+    for w in wrappers.values():
+        g = w.__dict__.get("_group")
+        if g is not None:
+            g.dissolve()
+    if args is not None and getattr(args, "no_sibling_fusion", False):
+        return []
+    skip = list(getattr(args, "skip_names", [])) if args is not None else []
+    cand = {}
+    for name, w in wrappers.items():
+        parent, _, leaf = name.rpartition(".")
+        fam = SIBLING_LEAVES.get(leaf)
+        if fam is None or not parent or any(p in name for p in skip) or not _fusable(w) or not w.quantizer.quant:
+            continue
+        cand.setdefault((parent, fam) + _scale_signature(w), []).append((leaf, w))
+    groups = []
+    for key, members in cand.items():
+        if len(members) < 2:
+            continue
+        grp = SiblingGroup(key[0], members)
+        for _, w in members:
+            w._group = grp
+        groups.append(grp)
+    return groups
 
 
 class ActRotateWrapper(torch.nn.Module):
@@ -816,7 +1015,9 @@ def model_close_calibrate(model, args):
 
 
 def model_quant(model, args):
-    return _set_flag(model, args, "quant", True)
+    _set_flag(model, args, "quant", True)
+    group_siblings(model, args)          # q/k/v, gate/up ...: one quantize + one GEMM per shared input
+    return model
 
 
 def model_no_quant(model, args):

@@ -7,6 +7,8 @@ launches; the arithmetic is identical (IEEE division, round-half-even, fp32 dequ
 """
 import torch
 
+from fake_quant.utils import tensor_version
+
 from .base import BaseQuantizer
 
 
@@ -23,9 +25,15 @@ class UniformQuantizer(BaseQuantizer):
     def _cache_host_params(self):
         """Host copies of what the fused kernel needs, taken ONCE per parameter update: reading them on
         every forward would be a device->host sync per call (and breaks hipGraph capture)."""
-        self._cached_for = (self.scale, self.zero_point)
+        self._cached_for = (self._stamp(self.scale), self._stamp(self.zero_point))
         self._zp_is_zero = self.zero_point is None or not bool(torch.any(self.zero_point != 0))
         self._scale_host = float(self.scale) if (self.scale is not None and self.scale.numel() == 1) else None
+
+    @staticmethod
+    def _stamp(t):
+        """Identity of a parameter tensor AND of its contents: in-place writes (``.data =``, ``copy_``, a checkpoint
+        loader filling the existing tensor) move the version counter or the data pointer."""
+        return None if t is None else ((id(t), tensor_version(t), t.data_ptr()) if isinstance(t, torch.Tensor) else (id(t),))
 
     def _params(self, inputs, scale, zero_point):
         scale = self.scale if scale is None else scale
@@ -47,9 +55,8 @@ class UniformQuantizer(BaseQuantizer):
                 and x.dtype in (torch.float16, torch.bfloat16, torch.float32)
                 and self.bit_type.bits == 8 and self.bit_type.signed and self.scale is not None):
             return False
-        if getattr(self, "_cached_for", None) is None or self._cached_for[0] is not self.scale \
-                or self._cached_for[1] is not self.zero_point:
-            self._cache_host_params()          # parameters assigned directly (checkpoints, tests)
+        if getattr(self, "_cached_for", None) != (self._stamp(self.scale), self._stamp(self.zero_point)):
+            self._cache_host_params()          # parameters assigned or rewritten directly (checkpoints, tests)
         return self._zp_is_zero
 
     def forward(self, inputs):

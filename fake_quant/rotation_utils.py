@@ -29,15 +29,54 @@ def _as64(t: torch.Tensor, like: torch.Tensor = None) -> torch.Tensor:
 def q_to(Q: torch.Tensor, device) -> torch.Tensor:
     """``Q.to(device)`` that keeps the structure tag of a random Hadamard rotation."""
     Qd = Q.to(device)
-    if Qd is not Q and getattr(Q, "_mq_signs", None) is not None:
+    if Qd is not Q and getattr(Q, "_mq_signs", None) is not None and _structured_tag_alive(Q):
         Qd._mq_signs = Q._mq_signs
+        Qd._mq_tag_version = utils.tensor_version(Qd)
     return Qd
 
 
 def _structured(Q: torch.Tensor) -> bool:
     """Q = diag(s) H_n / sqrt(n) from ``random_hadamard_matrix`` and a GPU to run on: the product
     is a sign flip plus a fast Hadamard per row (``mq_rotate_f64``) instead of a dense fp64 GEMM."""
-    return getattr(Q, "_mq_signs", None) is not None and torch.cuda.is_available()
+    if getattr(Q, "_mq_signs", None) is None or not torch.cuda.is_available():
+        return False
+    return _tag_verified(Q)
+
+
+def _structured_tag_alive(Q: torch.Tensor) -> bool:
+    """False once Q was written in place after ``random_hadamard_matrix`` tagged it."""
+    ver = utils.tensor_version(Q)
+    if Q.__dict__.get("_mq_tag_version", ver) != ver:
+        Q._mq_signs = None
+        return False
+    return True
+
+
+def _tag_verified(Q: torch.Tensor) -> bool:
+    """The structure tag is an attribute of the tensor OBJECT, not of its contents: an in-place edit of Q
+    (or a reused tagged tensor) would make the fast path apply diag(s) H / sqrt(n) instead of the matrix
+    actually passed.  Per (object, version counter): compare a few rows of the dense Q with the structured
+    transform of the matching unit vectors; on any mismatch the tag is dropped and the dense product runs."""
+    if not _structured_tag_alive(Q):
+        return False
+    stamp = (utils.tensor_version(Q), Q.data_ptr())
+    seen = Q.__dict__.get("_mq_tag_ok")
+    if seen is not None and seen[0] == stamp:
+        return seen[1]
+    from fake_quant import hadamard_utils as hu
+    n = Q.shape[0]
+    ok = Q.dim() == 2 and Q.shape[1] == n and Q._mq_signs.numel() == n
+    if ok:
+        rows = sorted({0, 1, n // 3, n // 2, n - 2, n - 1} & set(range(n)))
+        eye = torch.zeros((len(rows), n), dtype=torch.float64)
+        eye[torch.arange(len(rows)), torch.tensor(rows)] = 1.0
+        want = hu.matmul_hadU(eye * Q._mq_signs.to(dtype=torch.float64, device="cpu")[None, :])   # e_r diag(s) H / sqrt(n)
+        got = Q[rows].to(device="cpu", dtype=torch.float64)
+        ok = bool(torch.allclose(got, want, rtol=0, atol=1e-9))
+    if not ok:
+        Q._mq_signs = None
+    Q.__dict__["_mq_tag_ok"] = (stamp, ok)
+    return ok
 
 
 def _signs_on(Q: torch.Tensor, device) -> torch.Tensor:

@@ -59,3 +59,12 @@ def revise_down_input(m, i, new_size):
     x = i[0]
     pad = new_size - x.shape[-1]
     return (torch.nn.functional.pad(x, (0, pad)),) + tuple(i[1:])
+
+
+def tensor_version(t) -> int:
+    """``t._version`` (the in-place write counter); inference tensors keep none -- they cannot be written in
+    place outside inference mode either -- and count as version 0."""
+    try:
+        return t._version
+    except RuntimeError:
+        return 0

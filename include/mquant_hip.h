@@ -12,7 +12,11 @@
  *   - extern "C", plain pointers and sizes, no torch types.
  *   - every pointer is a DEVICE pointer unless its name ends in _host.
  *   - stream is a hipStream_t passed as void* (NULL = default stream); all work is
- *     stream-ordered, nothing synchronises, nothing allocates; re-entrant.
+ *     stream-ordered, nothing synchronises, nothing allocates.  Re-entrant: the entry points
+ *     keep no mutable process state except (i) a per-device cache of kernel attributes behind
+ *     a mutex and (ii) the TEST-ONLY override mq_gemm_debug_force, which is thread-local.
+ *     mq_hadamard_set_mode is a process-wide SETTING (like an environment variable): choose it
+ *     once before the first launch, not concurrently with launches.
  *   - return value: 0 on success; >0 a hipError_t; <0 an argument error
  *     (MQ_EINVAL...).  mq_last_error() returns a thread-local message.
  *   - dtype codes: MQ_F16 / MQ_BF16 / MQ_F32 for activations and outputs.
@@ -365,9 +369,10 @@ int mq_gemm_w4a8_i32_ws(const int8_t *a, long lda, const void *w, int w_bits,
 int mq_act_rowsum_scaled(const int8_t *a, long lda, long M, long K_pad, float s_x0, float s_x1,
                          const uint8_t *row_sel, const float *s_x_rows, float *out, void *stream);
 
-/* Tuning / test hook (process-wide, not part of the drop-in surface): force the tile shape
- * (-1 heuristic; ids as in csrc/gemm_w4a8.hip dispatch_tile) and the split-K factor (0 heuristic;
- * bits 8..15 of a positive value force the number of m-groups of the XCD mapping, 0 = automatic). */
+/* TEST-ONLY hook, not part of the drop-in surface: force the tile shape (-1 heuristic; ids as in
+ * csrc/gemm_w4a8.hip dispatch_tile) and the split-K factor (0 heuristic; bits 8..15 of a positive value
+ * force the number of m-groups of the XCD mapping, 0 = automatic) for the GEMM calls the CALLING THREAD
+ * makes afterwards (thread-local state; other threads keep the heuristic). */
 int mq_gemm_debug_force(int tile, int splits);
 
 /* ---------------------------------------------------------------------------

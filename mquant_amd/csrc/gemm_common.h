@@ -77,7 +77,7 @@ inline unsigned pick_m_groups(unsigned m_blocks, double w_bytes, double a_bytes)
     return best;
 }
 
-extern int g_gemm_force_xm;   // debug (mq_gemm_debug_force, bits 8.. of `splits`); 0 = automatic
+extern thread_local int g_gemm_force_xm;   // test hook (mq_gemm_debug_force, bits 8.. of `splits`); 0 = automatic
 
 inline void set_geometry(GemmArgs &p, int BM, int BN, int k_unit, int w_bits)
 {
@@ -93,6 +93,16 @@ inline void set_geometry(GemmArgs &p, int BM, int BN, int k_unit, int w_bits)
     const long units = p.K_pad / k_unit;
     p.kq = (int)(units / p.splits);
     p.kr = (int)(units % p.splits);
+}
+
+// tile_of_block divides by multiplying with ceil(2^32 / d): exact while n * d < 2^32 for every (n, d) pair it
+// forms (n < total work ids, d in {mg, n_blocks, xm}).  A grid beyond that would map workgroups to wrong tiles.
+inline bool geometry_in_range(const GemmArgs &p)
+{
+    const unsigned long long total = (unsigned long long)p.m_blocks * p.n_blocks * (unsigned)p.splits;
+    unsigned long long d = p.mg > p.n_blocks ? p.mg : p.n_blocks;
+    if (p.xm > d) d = p.xm;
+    return total * d < (1ULL << 32) && total < (1ULL << 31);
 }
 
 // workgroup -> (bm, bn, split): XCD-aware and bijective.  Block b runs on XCD b % 8; the remap gives

@@ -401,6 +401,7 @@ static int launch_gemm_pipe(const GemmArgs &p, hipStream_t st)
     }
     GemmArgs g = p;
     set_geometry(g, 256, 256, 64, 4);
+    if (!geometry_in_range(g)) return fail(MQ_EINVAL, "mq_gemm_w4a8: %u x %u x %d workgroups exceed the range of the launch-geometry arithmetic", g.m_blocks, g.n_blocks, g.splits);
     hipLaunchKernelGGL(kern, dim3(g.m_blocks * g.n_blocks * (unsigned)g.splits), dim3(512), SMEM, st, g);
     int rc = check_launch("gemm_w4a8_pipe");
     if (rc != MQ_OK || p.splits == 1) return rc;
@@ -422,6 +423,7 @@ static int launch_gemm(const GemmArgs &p, hipStream_t st)
     }
     GemmArgs g = p;
     set_geometry(g, BM, BN, 128, W_BITS);
+    if (!geometry_in_range(g)) return fail(MQ_EINVAL, "mq_gemm_w4a8: %u x %u x %d workgroups exceed the range of the launch-geometry arithmetic", g.m_blocks, g.n_blocks, g.splits);
     hipLaunchKernelGGL(kern, dim3(g.m_blocks * g.n_blocks * (unsigned)g.splits),
                        dim3(WARPS_M * WARPS_N * 64), SMEM, st, g);
     int rc = check_launch("gemm_w4a8");
@@ -529,8 +531,10 @@ static int dispatch_tile(const GemmArgs &p, int tile, hipStream_t st)
     return launch_gemm<128, 128, 2, 2, 3, W_BITS, EPI>(p, st);
 }
 
-static int g_force_tile = -1, g_force_splits = 0;
-int g_gemm_force_xm = 0;
+// test / tuning overrides of the plan (mq_gemm_debug_force): thread-local, so they change the dispatch of the
+// calling thread only and the library stays re-entrant for everybody else
+static thread_local int g_force_tile = -1, g_force_splits = 0;
+thread_local int g_gemm_force_xm = 0;
 
 static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, long M, long N,
                        long K_pad, float s_x0, float s_x1, const uint8_t *row_sel,
@@ -662,8 +666,9 @@ extern "C" int mq_gemm_w4a8_i32_ws(const int8_t *a, long lda, const void *w, int
                            stream);
 }
 
-// Tuning / test hook: force a tile shape (-1 = heuristic; the ids are the cases of dispatch_tile /
-// dispatch_ws) and a split-K factor (0 = heuristic).  Process-wide; not part of the drop-in surface.
+// TEST-ONLY hook: force a tile shape (-1 = heuristic; the ids are the cases of dispatch_tile /
+// dispatch_ws) and a split-K factor (0 = heuristic) for the CALLING THREAD's later GEMM calls.
+// Not part of the drop-in surface.
 extern "C" int mq_gemm_debug_force(int tile, int splits)
 {
     mq::g_force_tile = tile;

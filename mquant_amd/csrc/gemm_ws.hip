@@ -627,6 +627,7 @@ static int launch_ws(const GemmArgs &p, hipStream_t st)
     if (rc != MQ_OK) return rc;
     GemmArgs g = p;
     set_geometry(g, BM, BN, 128, W_BITS);
+    if (!geometry_in_range(g)) return fail(MQ_EINVAL, "mq_gemm_w4a8: %u x %u x %d workgroups exceed the range of the launch-geometry arithmetic", g.m_blocks, g.n_blocks, g.splits);
     hipLaunchKernelGGL(kern, dim3(g.m_blocks * g.n_blocks * (unsigned)g.splits), dim3((MW_M * MW_N * KS + NL) * 64), SMEM, st, g);
     return check_launch("gemm_ws");
 }

@@ -106,10 +106,22 @@ class FullPrefill:
         return L.lin.gemm_residual(a, x0, residual, L.row_sel)
 
     def calibrate(self):
+        """One calibration pass over the CHAINED activations; the hot path's own scales (calibrated on its
+        synthetic per-layer inputs) are remembered so that the two sets can be swapped."""
+        self._hot_scales = [(L.lin.s_x0, L.lin.s_x1) for L in self.pf.layers]
         self.calibrating = True
         self.step()
         self.calibrating = False
+        self._full_scales = [(L.lin.s_x0, L.lin.s_x1) for L in self.pf.layers]
         torch.cuda.synchronize(self.dev)
+
+    def restore_hot_path_scales(self):
+        for L, (s0, s1) in zip(self.pf.layers, self._hot_scales):
+            L.lin.s_x0, L.lin.s_x1 = s0, s1
+
+    def apply_full_prefill_scales(self):
+        for L, (s0, s1) in zip(self.pf.layers, self._full_scales):
+            L.lin.s_x0, L.lin.s_x1 = s0, s1
 
     # -- the prefill -----------------------------------------------------------------------
     def step(self) -> torch.Tensor:

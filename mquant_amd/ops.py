@@ -75,6 +75,8 @@ def _a_args(a):
     if isinstance(a, TiledAct):
         return a.data_ptr(), LD_TILED, a.M, a.K_pad
     assert a.dtype == torch.int8 and a.dim() == 2 and a.stride(1) == 1
+    # a row stride of 0 (an expanded row) would alias the MQ_LD_TILED sentinel of the C ABI
+    assert a.stride(0) >= a.shape[1], "row-major int8 activations need a row stride >= K_pad (no expanded operands)"
     return a.data_ptr(), a.stride(0), a.shape[0], a.shape[1]
 
 

@@ -60,3 +60,29 @@ def test_kernels_follow_the_tensor_device_not_the_current_one(had_table):
             ops.gemm_w4a8_i32(torch.from_numpy(a).to("cuda:0"), ops.prepack(torch.from_numpy(w).to("cuda:1"), 4), 4, N)
     finally:
         ops.gemm_debug_force(-1, 0)
+
+
+def test_bench_as_a_single_torchrun_rank_initialises_rccl_and_exchanges_logits_on_this_gpu():
+    """The multi-GPU code path on a one-GPU box: bench.py started the way the driver starts its ranks
+    (torch.distributed.run, here with one process).  The rank initialises the RCCL process group on its
+    device, every timed step ends in the fp16 lm_head + all_gather on the side stream, the whole-prefill
+    logits are gathered with shard.gather_logits and compared with the single-GPU computation."""
+    import socket
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--no-full-prefill"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    assert "ActQuantWrapper.forward" in line["config"]["path"] and "FAILED" not in line["config"]["path"]
+    chk = line["logits_check"]
+    assert chk["step_exchange"]["own_row_intact"] is True and chk["step_exchange"]["finite"] is True
+    assert chk["samples"] == 1 and chk["equal_to_single_gpu"] is True
+    assert line["roofline"]["launches_per_step"] == 243

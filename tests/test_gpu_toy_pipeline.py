@@ -104,7 +104,7 @@ def test_quantized_toy_model_real_kernels_equal_simulation(inter, llm_split, vis
     calibrate(model, pixels, ids, mask)
     with qu.token_type_mask(mask):
         real = model(pixels, ids)
-        used = [n for n, w in wrappers.items() if w._real is not None]
+        used = [n for n, w in wrappers.items() if qu.real_engine(w) is not None]
         assert len(used) == len(wrappers), sorted(set(wrappers) - set(used))   # every wrapped layer ran the kernels
         for w in wrappers.values():
             w.real_quant = False
@@ -188,10 +188,74 @@ def test_other_model_families_run_the_real_kernels(kind, split):
     qu.model_close_calibrate(model, Args())
     qu.model_quant(model, Args())
     real = model(pixels, ids)
-    missing = [n for n, w in wrappers.items() if w._real is None]
+    missing = [n for n, w in wrappers.items() if qu.real_engine(w) is None]
     assert not missing, missing
     for w in wrappers.values():
         w.real_quant = False
     sim = model(pixels, ids)
     torch.testing.assert_close(real, sim, rtol=0, atol=2e-3 * float(sim.abs().max()))
     assert float((real.double().cpu() - want).norm() / want.norm()) < 0.08
+
+
+# ------------------------------------------------------------------ sibling fusion (q|k|v, gate|up)
+def _groups(wrappers):
+    return {id(w.__dict__["_group"]): w.__dict__["_group"] for w in wrappers.values() if w.__dict__.get("_group") is not None}
+
+
+def test_sibling_fusion_through_model_quant_is_bit_identical_to_per_linear_evaluation():
+    """model_quant() groups the q/k/v and gate/up wrappers of every decoder layer (same parent, same input,
+    identical static scale sets): one quantize + one GEMM per group, members return views.  The model output
+    must not move by a bit against the per-Linear evaluation the reference performs (quant_utils.py:626-662)."""
+    from fake_quant import quant_utils as qu
+    model, wrappers, pixels, ids, _ = build(96, False, True, 4, True)
+    mask = torch.tensor([0, 0, 1, 1, 1, 1, 1], device=DEV)
+    calibrate(model, pixels, ids, mask)
+    groups = _groups(wrappers)
+    names = sorted(tuple(sorted(n for n, _ in g.members)) for g in groups.values())
+    assert names == [("gate_proj", "up_proj"), ("gate_proj", "up_proj"), ("k_proj", "q_proj", "v_proj"),
+                     ("k_proj", "q_proj", "v_proj")], names
+    with qu.token_type_mask(mask):
+        fused = model(pixels, ids)
+        assert all(g.enabled and g.launches == 1 and g.engine is not None for g in groups.values())
+        assert all(g._result is None for g in groups.values())            # every product fully consumed and released
+        grouped = [w for w in wrappers.values() if w.__dict__.get("_group") is not None]
+        assert grouped and all(w._real is None for w in grouped)          # members never built engines of their own
+        fused2 = model(pixels * 1.03, ids)                                  # a second pass: fresh products
+        assert all(g.launches == 2 for g in groups.values())
+        qu.model_quant(model, types.SimpleNamespace(skip_names=[], no_sibling_fusion=True))
+        assert not _groups(wrappers)
+        plain = model(pixels, ids)
+        plain2 = model(pixels * 1.03, ids)
+    assert torch.equal(fused, plain) and torch.equal(fused2, plain2)
+    assert not torch.equal(fused, fused2)
+
+
+def test_sibling_group_never_serves_a_stale_or_foreign_product():
+    from fake_quant import quant_utils as qu
+    model, wrappers, pixels, ids, _ = build(96, False, False, 8, False)
+    calibrate(model, pixels, ids, None)
+    attn = model.model.layers[0].self_attn
+    q, k, v = attn.q_proj, attn.k_proj, attn.v_proj
+    grp = q.__dict__["_group"]
+    assert grp is not None and grp is k.__dict__["_group"] is v.__dict__["_group"]
+    x = torch.randn(7, q.module.in_features, device=DEV)
+    y_q = q(x).clone()
+    assert grp.launches == 1
+    y_k = k(x).clone()                       # served from the product q computed
+    assert grp.launches == 1
+    y_q2 = q(x)                              # q took this product already: recomputed, not re-served
+    assert grp.launches == 2 and torch.equal(y_q, y_q2)
+    x.mul_(1.5)                              # same storage, new contents: the version counter moves
+    y_k2 = k(x)
+    assert grp.launches == 3 and not torch.equal(y_k, y_k2)
+    # reference values from the members' own engines
+    qu.model_quant(model, types.SimpleNamespace(skip_names=[], no_sibling_fusion=True))
+    assert torch.equal(k(x), y_k2) and q._real is not None
+    # siblings fed DIFFERENT tensors: every product goes unused, the group dissolves itself
+    qu.model_quant(model, Args())
+    grp = q.__dict__["_group"]
+    for i in range(4):
+        for m in (q, k, v):
+            m(torch.randn(7, q.module.in_features, device=DEV))
+    assert not grp.enabled and q.__dict__.get("_group") is None
+    assert torch.equal(k(x), y_k2)

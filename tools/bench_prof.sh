@@ -1,6 +1,8 @@
 #!/bin/bash
 # usage: tools/bench_prof.sh <out-prefix> [bench flags] -> rocprofv3 --kernel-trace --stats of bench.py, our kernels per (name, grid)
-cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+set -euo pipefail
+GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"; export GRAFT_REPO_ROOT
+cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=$1; shift
 rm -rf gpurun_out/bp; mkdir -p gpurun_out/bp $(dirname $OUT)
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/bp -o b -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-full-prefill "$@" > ${OUT}_bench.json 2> gpurun_out/bp/err

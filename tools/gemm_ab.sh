@@ -1,12 +1,14 @@
 #!/bin/bash
 # usage: tools/gemm_ab.sh "<variants>" "<shapes>" [configs] [extra gemm_bench flags, e.g. --cold] -> same-box A/B of library variants (mquant_amd/libmquant_hip_<v>.so; "main" = the regular build)
-cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+set -euo pipefail
+GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"; export GRAFT_REPO_ROOT
+cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/gp
 for s in $2; do
   for v in $1; do
     lib=$GRAFT_REPO_ROOT/mquant_amd/libmquant_hip_$v.so; [ "$v" = main ] && lib=$GRAFT_REPO_ROOT/mquant_amd/libmquant_hip.so
     rm -f gpurun_out/gp/t_kernel_trace.csv
-    MQUANT_HIP_LIB=$lib rocprofv3 --kernel-trace --output-format csv -d gpurun_out/gp -o t -- python3 tools/gemm_bench.py --only "$s" --configs="${3:--1:0}" --tiled $4 > gpurun_out/gp/log 2>&1
+    MQUANT_HIP_LIB=$lib rocprofv3 --kernel-trace --output-format csv -d gpurun_out/gp -o t -- python3 tools/gemm_bench.py --only "$s" --configs="${3:--1:0}" --tiled ${4:-} > gpurun_out/gp/log 2>&1
     python3 - "$s" "$v" <<'PY'
 import collections, csv, sys
 rows = list(csv.DictReader(open("gpurun_out/gp/t_kernel_trace.csv")))

@@ -1,6 +1,8 @@
 #!/bin/bash
 # usage: tools/gemm_pmc.sh <shape> <configs> -> SQ counter summary (rocprofv3 --pmc, kernels serialised) for one shape
-cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+set -euo pipefail
+GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"; export GRAFT_REPO_ROOT
+cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/pmc; mkdir -p gpurun_out/pmc
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d gpurun_out/pmc -o t -- python3 tools/gemm_bench.py --only "$1" --configs="$2" > gpurun_out/pmc/log 2>&1
 python3 tools/pmc_sq_summary.py gpurun_out/pmc/t_counter_collection.csv | python3 -c "

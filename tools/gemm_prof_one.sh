@@ -1,8 +1,10 @@
 #!/bin/bash
 # usage: tools/gemm_prof_one.sh <shape> <configs> -> median kernel durations (rocprofv3) for ONE shape filter
-cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+set -euo pipefail
+GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"; export GRAFT_REPO_ROOT
+cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/gp; rm -f gpurun_out/gp/t_kernel_trace.csv
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/gp -o t -- python3 tools/gemm_bench.py --only "$1" --configs="$2" $3 > gpurun_out/gp/log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/gp -o t -- python3 tools/gemm_bench.py --only "$1" --configs="$2" ${3:-} > gpurun_out/gp/log 2>&1
 python3 - <<'PY'
 import collections, csv
 rows = list(csv.DictReader(open("gpurun_out/gp/t_kernel_trace.csv")))

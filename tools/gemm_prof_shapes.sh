@@ -1,10 +1,12 @@
 #!/bin/bash
 # usage: tools/gemm_prof_shapes.sh <configs> [bits] [extra gemm_bench flags] -> kernel durations (rocprofv3) per model shape
-cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+set -euo pipefail
+GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"; export GRAFT_REPO_ROOT
+cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/gp
 for s in vis.qkv vis.proj vis.fc1 vis.fc2 llm.q/o llm.kv "llm.qkv" "llm.gate_up" llm.down; do
   rm -f gpurun_out/gp/t_kernel_trace.csv
-  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/gp -o t -- python3 tools/gemm_bench.py --only "$s" --configs="$1" --bits ${2:-4} $3 > gpurun_out/gp/log 2>&1
+  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/gp -o t -- python3 tools/gemm_bench.py --only "$s" --configs="$1" --bits ${2:-4} ${3:-} > gpurun_out/gp/log 2>&1
   echo "== $s"
   python3 - <<'PY'
 import collections, csv

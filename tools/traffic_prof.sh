@@ -1,7 +1,9 @@
 #!/bin/bash
 # usage: tools/traffic_prof.sh <out.json> <commit>  -> HBM bytes per launch of our kernels from two
 # rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counters only, kernels serialised) over bench.py
-cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+set -euo pipefail
+GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"; export GRAFT_REPO_ROOT
+cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=$1; COMMIT=$2
 CMD="python3 bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-full-prefill"
 rm -rf gpurun_out/tr; mkdir -p gpurun_out/tr $(dirname $OUT)
