@@ -306,19 +306,20 @@ def main():
     hidden = specs[-1].n
     vocab = VOCAB if not args.tiny else 1024
 
-    # Per-step logits: the rank's sample ends in logits = lm_head(rms_norm(last position)) -- fp16, lm_head is
-    # not wrapped (reference quant_utils.py:560-564) -- computed from the step's final Linear output on a SIDE
-    # stream, so that it and (N > 1) the RCCL all_gather of the ranks' logits overlap the next sample's
-    # hot path; buffers alternate by step parity.  The real-logits parity check stays outside the timing.
+    # Per-step logits: the rank's sample ends in logits = lm_head(rms_norm(last position)) -- fp16, lm_head is not
+    # wrapped (reference quant_utils.py:560-564) -- computed from the step's final Linear output INSIDE the step
+    # (same hipGraph, same stream).  Under torch.distributed the ranks' logits then go through one RCCL all_gather
+    # per step on a SIDE stream, overlapping the next sample's hot path (buffers alternate by step parity).  The
+    # real-logits parity check (whole prefill, rank vs single GPU) stays outside the timing.
     with_logits = not args.no_logits
     side = torch.cuda.Stream(device=dev)
-    lm_head, last_rows, logits_step, logits_all = None, None, None, None
+    lm_head, logits_step, logits_send, logits_all = None, None, None, None
     if with_logits:
         g = torch.Generator(device=dev).manual_seed(7)
         lm_head = (torch.randn((vocab, hidden), generator=g, device=dev) * 0.02).to(torch.float16)
-        last_rows = [torch.zeros((1, hidden), dtype=torch.float16, device=dev) for _ in range(2)]
-        logits_step = [torch.zeros((1, vocab), dtype=torch.float16, device=dev) for _ in range(2)]
+        logits_step = torch.zeros((1, vocab), dtype=torch.float16, device=dev)
         if distributed:
+            logits_send = [torch.zeros((1, vocab), dtype=torch.float16, device=dev) for _ in range(2)]
             logits_all = [torch.zeros((world, vocab), dtype=torch.float16, device=dev) for _ in range(2)]
 
     # N > 1: sample i runs on rank i; static scales are replicated constants (every rank calibrates on
@@ -349,29 +350,32 @@ def main():
             keep[0] = fn()
         return g.replay
 
-    final_out = [None]                   # [M, hidden]: output of the last Linear of the step (down_proj)
-    run_prefill = capture(pf.step, final_out)
+    def hot_path_and_logits():
+        y = pf.step()                    # [M, hidden]: output of the last Linear of the step (down_proj)
+        if with_logits:
+            h = torch.nn.functional.rms_norm(y[-1:], (hidden,), eps=1e-6)
+            torch.matmul(h, lm_head.t(), out=logits_step)
+        return y
+
+    run_step = capture(hot_path_and_logits)
     counter = [0]
     side_done = [None, None]
 
     def step():
-        run_prefill()
-        if not with_logits:
+        run_step()
+        if not (with_logits and distributed):
             return
         par = counter[0] & 1
         counter[0] += 1
         main = torch.cuda.current_stream(dev)
         if side_done[par] is not None:
             main.wait_event(side_done[par])          # the side stream has finished with this parity's buffers
-        last_rows[par].copy_(final_out[0][-1:])
+        logits_send[par].copy_(logits_step)
         ev = torch.cuda.Event()
         ev.record(main)
         with torch.cuda.stream(side):
             side.wait_event(ev)
-            h = torch.nn.functional.rms_norm(last_rows[par], (hidden,), eps=1e-6)
-            torch.matmul(h, lm_head.t(), out=logits_step[par])
-            if distributed:
-                dist.all_gather_into_tensor(logits_all[par], logits_step[par])
+            dist.all_gather_into_tensor(logits_all[par], logits_send[par])
             side_done[par] = torch.cuda.Event()
             side_done[par].record(side)
 
@@ -401,7 +405,7 @@ def main():
         par = (counter[0] - 1) & 1
         mine = logits_all[par][rank]
         logits_check = {"step_exchange": {"all_gather_bytes": int(world * vocab * 2), "own_row_intact":
-                                          bool(torch.equal(mine, logits_step[par][0])),
+                                          bool(torch.equal(mine, logits_step[0])),
                                           "finite": bool(torch.isfinite(logits_all[par].float()).all().item())}}
     if fp_logits is not None:
         from mquant_amd import shard
@@ -432,14 +436,16 @@ def main():
         torch.cuda.synchronize(dev)
         return e0.elapsed_time(e1) / reps
 
-    hot_ms = timed(run_prefill)                      # the hot path alone (no logits, no exchange), stream-timed
+    hot_ms = timed(capture(pf.step))                 # the hot path alone (no logits, no exchange), stream-timed
     gemm_ms = timed(capture(pf.step_gemm_only))
     quant_ms = timed(capture(pf.step_quant_only))
     lm_ms = None
     if with_logits:
+        last_row = torch.zeros((1, hidden), dtype=torch.float16, device=dev)
+
         def lm_only():
-            h = torch.nn.functional.rms_norm(last_rows[0], (hidden,), eps=1e-6)
-            torch.matmul(h, lm_head.t(), out=logits_step[0])
+            h = torch.nn.functional.rms_norm(last_row, (hidden,), eps=1e-6)
+            torch.matmul(h, lm_head.t(), out=logits_step)
         lm_ms = timed(lm_only)
     launches = pf.gemm_launches()
     traffic, traffic_note, traffic_source = None, "no PMC traffic file for this workload", None
@@ -499,8 +505,9 @@ def main():
                                 "ActQuantWrapper.forward" if via_wrappers else "integer engines assembled directly (workload.Prefill)")
                                + (f"; the wrapper build FAILED and was replaced: {via_error}" if via_error else ""),
                        "step": "every wrapped Linear of one image+prompt prefill (quantize / Hadamard+quantize launch + GEMM launch each), one hipGraph"
-                               + ("; the sample's logits (fp16 lm_head on the last position)" + (" and the RCCL all_gather of the ranks' logits" if distributed else "")
-                                  + " follow on a side stream and overlap the next sample's hot path" if with_logits else ""),
+                               + ("; then the sample's logits (fp16 lm_head on the last position, same graph)"
+                                  + ("; the RCCL all_gather of the ranks' logits runs on a side stream and overlaps the next sample's hot path" if distributed else "")
+                                  if with_logits else ""),
                        "tokens_per_step_per_gpu": tokens_per_step, "parallelism": f"batch-shard x{world}",
                        "ttft_hot_path_ms": round(hot_ms, 4),
                        "lm_head_ms": None if lm_ms is None else round(lm_ms, 4),

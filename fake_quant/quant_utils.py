@@ -524,6 +524,7 @@ class ActQuantWrapper(torch.nn.Module):
             rows = x.reshape(x.shape[0], -1)
             out_shape = (x.shape[0], real.N) + (1,) * (x.dim() - 2)
         sel = _row_mask(rows.shape[0], x.device) if getattr(self.quantizer, "msq", False) else None
+        real.in_features = rows.shape[1]           # bookkeeping (bytes read by the quantizer): the un-padded width
         return real.forward(rows, sel).reshape(out_shape)
 
     # ------------------------------------------------------------------ forward

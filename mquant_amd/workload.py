@@ -172,12 +172,15 @@ def rtn_levels(w: torch.Tensor, bits: int = 4):
     return levels, scale
 
 
-def minmax_scale(mn: float, mx: float) -> float:
-    """observer/minmax.py:40-46, symmetric int8, including the zero-inclusion rule."""
-    mn = min(float(mn), 0.0)
-    mx = max(float(mx), 0.0)
-    s = max(abs(np.float32(mn) / np.float32(-128.0)), abs(np.float32(mx) / np.float32(127.0)))
-    return float(max(np.float32(s), np.float32(np.finfo(np.float32).eps)))
+def minmax_scale(mn: float, mx: float, dtype: torch.dtype = torch.float32) -> float:
+    """observer/minmax.py:40-46, symmetric int8, including the zero-inclusion rule -- evaluated in the
+    ACTIVATION's dtype like the reference's observer (min / max, their quotients by qmin / qmax and the
+    maximum are tensors of x's dtype there, so an fp16 model gets an fp16-rounded scale)."""
+    lo = torch.tensor(min(float(mn), 0.0), dtype=dtype)
+    hi = torch.tensor(max(float(mx), 0.0), dtype=dtype)
+    s = torch.max(torch.abs(lo / torch.tensor(-128.0, dtype=dtype)), torch.abs(hi / torch.tensor(127.0, dtype=dtype)))
+    s.clamp_(float(np.finfo(np.float32).eps))
+    return float(s)
 
 
 def synth_inputs(specs: List[LinearSpec], device, dtype) -> Dict[tuple, torch.Tensor]:
@@ -202,7 +205,8 @@ def synth_weight(spec: LinearSpec, li: int, seed: int, device, dtype):
     gen = torch.Generator(device=device)
     gen.manual_seed(seed + li)
     w = (torch.randn((spec.n, spec.k), generator=gen, device=device, dtype=torch.float32) * 0.02).to(dtype)
-    bias = (torch.randn((spec.n,), generator=gen, device=device) * 0.1).float() if spec.bias else None
+    # a bias of the model's dtype (what an fp16 checkpoint holds), handed on as fp32
+    bias = (torch.randn((spec.n,), generator=gen, device=device) * 0.1).to(dtype).float() if spec.bias else None
     return w, bias
 
 
@@ -247,11 +251,11 @@ class _HotPath:
         cb = 1 if spec.split else 0
         if row_sel is None:
             mm = ops.minmax_tensor(src, cb).cpu()
-            return minmax_scale(mm[0], mm[1]), None
+            return minmax_scale(mm[0], mm[1], src.dtype), None
         nv = int((row_sel == 0).sum().item())
         mv = ops.minmax_tensor(src[:nv], cb).cpu()
         mt = ops.minmax_tensor(src[nv:], cb).cpu()
-        return minmax_scale(mv[0], mv[1]), minmax_scale(mt[0], mt[1])
+        return minmax_scale(mv[0], mv[1], src.dtype), minmax_scale(mt[0], mt[1], src.dtype)
     def step(self):
         """One pass of the hot path over the whole prefill; returns the last Linear's output."""
         y = None

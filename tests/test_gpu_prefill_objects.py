@@ -39,7 +39,11 @@ def oracle_layer(spec, li, x, had_table, rows=None, seed=1234, w_bits=4):
     cb = 1 if spec.split else 0
 
     def scale(part):
-        return oracle.minmax_scale_sym(min(float(part[:, cb:].min()), 0.0), max(float(part[:, cb:].max()), 0.0))
+        # observer/minmax.py:30-46 on fp16 activations: every intermediate is an fp16 tensor
+        r16 = lambda v: oracle.round_to(np.float32(v).reshape(1), 1)[0]
+        mn, mx = min(float(part[:, cb:].min()), 0.0), max(float(part[:, cb:].max()), 0.0)
+        s = max(abs(r16(np.float32(mn) / np.float32(-128.0))), abs(r16(np.float32(mx) / np.float32(127.0))))
+        return np.float32(max(s, r16(np.finfo(np.float32).eps)))
     sel, s1 = None, None
     if spec.msq:
         sel = _np(workload.vision_text_mask(spec.M, DEV)).astype(np.uint8)

@@ -250,7 +250,7 @@ def test_sibling_group_never_serves_a_stale_or_foreign_product():
     assert grp.launches == 3 and not torch.equal(y_k, y_k2)
     # reference values from the members' own engines
     qu.model_quant(model, types.SimpleNamespace(skip_names=[], no_sibling_fusion=True))
-    assert torch.equal(k(x), y_k2) and q._real is not None
+    assert torch.equal(k(x), y_k2) and torch.equal(q(x), q(x)) and q._real is not None and k._real is not None
     # siblings fed DIFFERENT tensors: every product goes unused, the group dissolves itself
     qu.model_quant(model, Args())
     grp = q.__dict__["_group"]
