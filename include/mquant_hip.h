@@ -152,7 +152,18 @@ int mq_act_hadamard_quant_i8(const void *x, const void *x2, int act, int x_dtype
                              int skip_col0, float *x0_out, int8_t *out, long K_pad, long ldo,
                              void *stream);
 
-/* Tuning hook (process-wide, not part of the drop-in surface): 256 or 512 threads per row. */
+/* NON-DEFAULT accuracy / speed setting of the three entry points above (process-wide, like an environment
+ * variable: choose it once, before launching).  fast = 0 (default): the K x K stage is the sequential fp32
+ * add chain of the reference's CPU run, bit-identical to the goldens.  fast = 1: half-precision activations
+ * (x_dtype MQ_F16 / MQ_BF16, fp32_had off, 64 <= n/K <= 512) run that stage on the fp16 / bf16 matrix core
+ * (V_MFMA_F32_32X32X16): the products +-1 * y are exact, only the ORDER of the fp32 accumulation differs --
+ * what the reference's own GPU run does with a half-precision cuBLAS GEMM (hadamard_utils.py:127).  Not
+ * bit-identical to the exact mode: DESIGN.md 4.2 gives the measured int8 level flip rate.  Shapes / dtypes
+ * outside the fast mode silently take the exact kernel. */
+int mq_hadamard_set_mode(int fast);
+int mq_hadamard_get_mode(void);
+
+/* TEST-ONLY hook (thread-local, not part of the drop-in surface): 256 or 512 threads per row. */
 int mq_hadamard_debug_threads(int threads);
 
 /* ---------------------------------------------------------------------------

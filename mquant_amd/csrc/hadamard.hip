@@ -22,39 +22,9 @@
 //   C. cast to x's dtype, then either store or quantize (IEEE divide, rint, clamp) to int8.
 #include <math.h>
 
-#include "mq_common.h"
+#include "hadamard_common.h"
 
 namespace mq {
-
-struct HadArgs {
-    const void *x;
-    const void *x2 = nullptr;   // second operand of a fused activation (up of silu(gate)*up), same ldx
-    int act = MQ_ACT_NONE;      // activation applied to the loaded row before the transform
-    long M, n_in, ldx, n;
-    int K, m;
-    const uint8_t *had_bits;
-    const unsigned long long *masks = nullptr;   // prepared descriptor (mq_hadamard_prepare): lane masks of the sign operand
-    int unit_j = 1, unit_g = 4;                  // K x K stage: a wave owns unit_j 16-row tiles x unit_g 16-column tiles
-    int stagger = 0;                             // cycles by which the 2nd, 3rd ... workgroup of a CU starts late
-    int fp32_had;
-    void *out;
-    long ldo;
-    float s0, s1;
-    const uint8_t *row_sel;
-    int skip_col0;
-    float *x0_out;
-    int8_t *qout;
-    long K_pad, ldq;
-    int vec_ok;
-    int vec_ok2;       // same for x2
-    float inv_sqrt_n;  // 1.0f / sqrtf((float)n), computed on the host in IEEE fp32
-    int row_bytes;     // LDS bytes per k-row of the staged copy
-    int swz;           // XOR-swizzle odd k-rows by 128 B (row_bytes % 256 == 0)
-    int y_bytes;       // LDS bytes of the staged row
-};
-
-
-static int g_had_stagger = 0;   // tuning hook (measured slower in every setting): 0 = off, -1 = one K x K stage, > 0 = cycles
 
 // storage of the staged row in LDS: 16-bit when the values are exactly half-precision
 template <int DT, bool HALF_LDS> struct Stage;
@@ -96,48 +66,44 @@ __device__ __forceinline__ void had_emit1(const HadArgs &p, long row, long col, 
     }
 }
 
-// four adjacent columns col..col+3 of one row
-template <int DT, bool QUANT>
-__device__ __forceinline__ void had_emit4(const HadArgs &p, long row, long col, const float v[4],
-                                          float s, bool aligned)
+// N = 4 / 2 adjacent columns col..col+N-1 of one row (col a multiple of N); q.s = scale of the row, q.inv = 1 / s
+struct RowScale {
+    float s, inv;
+    bool rcp;
+};
+
+__device__ __forceinline__ RowScale row_scale(float s)
 {
-    float r[4];
-    int q[4];
+    return RowScale{s, 1.0f / s, quant_rcp_ok(s)};
+}
+
+template <int DT, bool QUANT, int N>
+__device__ __forceinline__ void had_emit_n(const HadArgs &p, long row, long col, const float (&v)[N], const RowScale &rs, bool aligned)
+{
+    float r[N];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) q[e] = had_finish<DT, QUANT>(p, row, col + e, v[e], s, &r[e]);
+    for (int e = 0; e < N; ++e) r[e] = Elem<DT>::rnd(v[e]);
     if (QUANT) {
+        int q[N];
+        quant_levels<N>(r, rs.s, rs.inv, rs.rcp, -128.0f, 127.0f, q);
+        if (p.skip_col0 && col == 0) {
+            if (p.x0_out) p.x0_out[row] = r[0];
+            q[0] = 0;
+        }
         int8_t *o = p.qout + act_offset(row, col, p.K_pad, p.ldq);
-        if (aligned) {
-            *reinterpret_cast<unsigned *>(o) = (q[0] & 0xff) | ((q[1] & 0xff) << 8) |
-                                               ((q[2] & 0xff) << 16) | ((unsigned)(q[3] & 0xff) << 24);
+        if (N == 4 && aligned) {
+            *reinterpret_cast<unsigned *>(o) = (q[0] & 0xff) | ((q[1] & 0xff) << 8) | ((q[2] & 0xff) << 16) | ((unsigned)(q[3] & 0xff) << 24);
+        } else if (N == 2) {
+            *reinterpret_cast<unsigned short *>(o) = (unsigned short)((q[0] & 0xff) | ((q[1] & 0xff) << 8));
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (int8_t)q[e];
+            for (int e = 0; e < N; ++e) o[e] = (int8_t)q[e];
         }
     } else {
         typedef typename Elem<DT>::T T;
         T *o = reinterpret_cast<T *>(p.out) + row * p.ldo + col;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = Elem<DT>::st(r[e]);
-    }
-}
-
-// two adjacent columns col, col+1 of one row (col even)
-template <int DT, bool QUANT>
-__device__ __forceinline__ void had_emit2(const HadArgs &p, long row, long col, const float v[2], float s)
-{
-    float r[2];
-    int q[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) q[e] = had_finish<DT, QUANT>(p, row, col + e, v[e], s, &r[e]);
-    if (QUANT) {
-        *reinterpret_cast<unsigned short *>(p.qout + act_offset(row, col, p.K_pad, p.ldq)) =
-            (unsigned short)((q[0] & 0xff) | ((q[1] & 0xff) << 8));
-    } else {
-        typedef typename Elem<DT>::T T;
-        T *o = reinterpret_cast<T *>(p.out) + row * p.ldo + col;
-        o[0] = Elem<DT>::st(r[0]);
-        o[1] = Elem<DT>::st(r[1]);
+        for (int e = 0; e < N; ++e) o[e] = Elem<DT>::st(r[e]);
     }
 }
 
@@ -148,7 +114,7 @@ __device__ __forceinline__ void had_emit2(const HadArgs &p, long row, long col, 
 // beside it is lost matrix time: the round-1 form (one tile x four column tiles, three VALU ops per
 // sign operand) spent 8 VALU per 4 MFMAs, a 5 x 2 unit spends 7 per 10.
 template <int DT, bool QUANT, bool HALF_LDS, int UJ, int UG>
-__device__ __forceinline__ void had_kxk_unit(const HadArgs &p, long row, float s, const char *ybase, int row_bytes, int swz,
+__device__ __forceinline__ void had_kxk_unit(const HadArgs &p, long row, const RowScale &rs, const char *ybase, int row_bytes, int swz,
                                              int jg, int cg, int lane)
 {
     typedef Stage<DT, HALF_LDS> S;
@@ -215,10 +181,10 @@ __device__ __forceinline__ void had_kxk_unit(const HadArgs &p, long row, float s
             if (j < K) {
                 if (UG == 4) {
                     const float v4[4] = {acc[jj][0][r], acc[jj][1][r], acc[jj][2][r], acc[jj][3][r]};
-                    had_emit4<DT, QUANT>(p, row, (long)j * m + col0, v4, s, (p.ldq & 3) == 0);
+                    had_emit_n<DT, QUANT, 4>(p, row, (long)j * m + col0, v4, rs, (p.ldq & 3) == 0);
                 } else {
                     const float v2[2] = {acc[jj][0][r], acc[jj][1][r]};
-                    had_emit2<DT, QUANT>(p, row, (long)j * m + col0, v2, s);
+                    had_emit_n<DT, QUANT, 2>(p, row, (long)j * m + col0, v2, rs, true);
                 }
             }
         }
@@ -241,6 +207,7 @@ __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
     const int wave = tid >> 6;
     const long n = p.n;
     const int K = p.K, m = p.m;
+    const int mshift = __builtin_ctz((unsigned)m);      // n / K is a power of two (checked on the host)
     const int WPR = (K + 31) / 32;
     const float scale = p.inv_sqrt_n;
     const bool mid_round = (DT != MQ_F32) && !p.fp32_had;
@@ -261,15 +228,6 @@ __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
         for (int t = tid; t < K * WPR; t += THREADS) hw[t] = gw[t];
     }
 
-    // The workgroups that share a CU would otherwise march through load -> K x K stage -> store in
-    // lockstep (all waiting for HBM, then all queueing for the fp32 MFMA, then all storing): the 2nd and
-    // 3rd resident workgroup of a CU start one K x K stage later each, so that one workgroup's matrix
-    // phase covers its neighbours' memory phases.  Block b is expected in slot b / 256 of its CU (the
-    // dispatcher fills the 256 CUs round-robin); a different placement only changes the timing.
-    if (p.stagger > 0 && blockIdx.x >= 256) {
-        const long long until = clock64() + (long long)(blockIdx.x >> 8) * p.stagger;
-        while (clock64() < until) __builtin_amdgcn_s_sleep(32);
-    }
     // tiled int8 output: the 16 rows of a piece row are handled on one XCD (tiled_row_of, mq_common.h)
     const bool remap = QUANT && p.ldq == MQ_LD_TILED && (gridDim.x & 7) == 0;
     const long v_end = remap ? ceil_div(p.M, 128) * 128 : p.M;
@@ -278,6 +236,7 @@ __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
         if (row >= p.M) continue;                  // uniform over the workgroup
         const T *xr = reinterpret_cast<const T *>(p.x) + row * p.ldx;
         const float s = (p.row_sel && p.row_sel[row]) ? p.s1 : p.s0;
+        const RowScale rs = row_scale(s);
 
         // ---------------- A: butterflies ------------------------------------------------
         if (m >= 8) {
@@ -288,51 +247,8 @@ __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
             for (long cb = wave; cb < nchunks; cb += HAD_WAVES * NB) {
               float vb[NB][8];
 #pragma unroll
-              for (int u = 0; u < NB; ++u) {
-                const long idx = (cb + (long)u * HAD_WAVES) * 512 + lane * 8;
-                if (idx + 8 <= p.n_in && p.vec_ok) {
-                    if (sizeof(T) == 2) {
-                        const v8us a = *reinterpret_cast<const v8us *>(xr + idx);
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) vb[u][i] = Elem<DT>::ld((T)a[i]);
-                    } else {
-                        const v4f a = *reinterpret_cast<const v4f *>((const float *)xr + idx);
-                        const v4f b = *reinterpret_cast<const v4f *>((const float *)xr + idx + 4);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) { vb[u][i] = a[i]; vb[u][4 + i] = b[i]; }
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) vb[u][i] = (idx + i < p.n_in) ? Elem<DT>::ld(xr[idx + i]) : 0.0f;
-                }
-                if (ACT && idx < p.n_in) {                            // fused activation prologue (own instantiation)
-                    float ub[8];
-                    if (p.act == MQ_ACT_SILU_MUL) {
-                        const T *ur = reinterpret_cast<const T *>(p.x2) + row * p.ldx;
-                        if (idx + 8 <= p.n_in && p.vec_ok2) {
-                            if (sizeof(T) == 2) {
-                                const v8us a = *reinterpret_cast<const v8us *>(ur + idx);
-#pragma unroll
-                                for (int i = 0; i < 8; ++i) ub[i] = Elem<DT>::ld((T)a[i]);
-                            } else {
-                                const v4f a = *reinterpret_cast<const v4f *>((const float *)ur + idx);
-                                const v4f b = *reinterpret_cast<const v4f *>((const float *)ur + idx + 4);
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) { ub[i] = a[i]; ub[4 + i] = b[i]; }
-                            }
-                        } else {
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) ub[i] = (idx + i < p.n_in) ? Elem<DT>::ld(ur[idx + i]) : 0.0f;
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        if (idx + i >= p.n_in) continue;
-                        vb[u][i] = (p.act == MQ_ACT_SILU_MUL) ? act_silu_mul<DT>(vb[u][i], ub[i])
-                                                               : act_quick_gelu<DT>(vb[u][i]);
-                    }
-                }
-              }
+              for (int u = 0; u < NB; ++u)
+                had_load_chunk<DT, ACT>(p, row, (cb + (long)u * HAD_WAVES) * 512 + lane * 8, vb[u]);
 #pragma unroll
               for (int u = 0; u < NB; ++u) {
                 const long c = cb + (long)u * HAD_WAVES;
@@ -341,36 +257,10 @@ __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
                 float v[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = vb[u][i];
-#pragma unroll
-                for (int h = 1; h < 8; h <<= 1) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        if ((i & h) == 0) {
-                            const float a0 = v[i], a1 = v[i + h];
-                            v[i] = a0 + a1;
-                            v[i + h] = a0 - a1;
-                        }
-                    }
-                }
-                for (int h = 8; h < m && h < 512; h <<= 1) {
-                    const int lm = h >> 3;
-                    const bool upper = (lane & lm) != 0;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const float o = __shfl_xor(v[i], lm);
-                        v[i] = upper ? (o - v[i]) : (v[i] + o);
-                    }
-                }
-                if (m <= 512) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        float t = v[i] * scale;
-                        if (mid_round) t = Elem<DT>::rnd(t);
-                        v[i] = t;
-                    }
-                }
+                // 16-bit staging rounds on the store: st(rnd(t)) == st(t), the explicit round trip would be wasted work
+                had_butterfly_chunk<DT>(v, lane, m, scale, mid_round && !HALF_LDS);
                 if (idx < n) {   // n is a multiple of 8 here (m >= 8)
-                    const int k = (int)(idx / m), i0 = (int)(idx - (long)k * m);
+                    const int k = (int)(idx >> mshift), i0 = (int)idx & (m - 1);   // m = 2^mshift
                     char *dst = ybase + yoff(k, i0);
                     if (HALF_LDS) {
                         v8us h;
@@ -386,7 +276,7 @@ __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
             }
         } else {
             for (long i = tid; i < n; i += HAD_THREADS) {
-                const int k = (int)(i / m), i0 = (int)(i - (long)k * m);
+                const int k = (int)(i >> mshift), i0 = (int)i & (m - 1);
                 *reinterpret_cast<YT *>(ybase + yoff(k, i0)) =
                     S::st((i < p.n_in) ? Elem<DT>::ld(xr[i]) : 0.0f);
             }
@@ -396,7 +286,7 @@ __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
             for (long h = (m < 8) ? 1 : 512; h < m; h <<= 1) {
                 for (long b = tid; b < n / 2; b += HAD_THREADS) {
                     const long i = (b / h) * 2 * h + (b % h);
-                    const int k = (int)(i / m), i0 = (int)(i - (long)k * m);
+                    const int k = (int)(i >> mshift), i0 = (int)i & (m - 1);
                     YT *pa = reinterpret_cast<YT *>(ybase + yoff(k, i0));
                     YT *pb = reinterpret_cast<YT *>(ybase + yoff(k, i0 + (int)h));
                     const float a0 = S::ld(*pa), a1 = S::ld(*pb);
@@ -406,7 +296,7 @@ __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
                 __syncthreads();
             }
             for (long i = tid; i < n; i += HAD_THREADS) {
-                const int k = (int)(i / m), i0 = (int)(i - (long)k * m);
+                const int k = (int)(i >> mshift), i0 = (int)i & (m - 1);
                 YT *py = reinterpret_cast<YT *>(ybase + yoff(k, i0));
                 float t = S::ld(*py) * scale;
                 if (mid_round) t = Elem<DT>::rnd(t);
@@ -431,7 +321,7 @@ __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
             const int JT = (K + 15) / 16;
             const int JG = (JT + 4) / 5, CG = m / 32;
             for (int u = wave; u < JG * CG; u += HAD_WAVES)
-                had_kxk_unit<DT, QUANT, HALF_LDS, 5, 2>(p, row, s, ybase, row_bytes, swz, u / CG, u % CG, lane);
+                had_kxk_unit<DT, QUANT, HALF_LDS, 5, 2>(p, row, rs, ybase, row_bytes, swz, u / CG, u % CG, lane);
         } else if (m >= 64) {
             const int JT = (K + 15) / 16;
             const int CG = m / 64;
@@ -486,14 +376,14 @@ __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
                     const int j = jt * 16 + lk * 4 + r;
                     if (j < K) {
                         const float v4[4] = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-                        had_emit4<DT, QUANT>(p, row, (long)j * m + col0, v4, s, (p.ldq & 3) == 0);
+                        had_emit_n<DT, QUANT, 4>(p, row, (long)j * m + col0, v4, rs, (p.ldq & 3) == 0);
                     }
                 }
             }
         } else {
             // narrow co-factor (m < 64): scalar chain per output element
             for (long o = tid; o < n; o += HAD_THREADS) {
-                const int j = (int)(o / m), i = (int)(o - (long)j * m);
+                const int j = (int)(o >> mshift), i = (int)o & (m - 1);
                 float acc = 0.0f;
                 for (int k = 0; k < K; ++k) {
                     const float v = S::ld(*reinterpret_cast<const YT *>(ybase + yoff(k, i)));
@@ -531,13 +421,6 @@ static int launch_hadamard_t(HadArgs p, hipStream_t st)
     long blocks = 256L * per_cu;
     if (blocks > p.M) blocks = p.M;
     if (QUANT && p.ldq == MQ_LD_TILED) blocks = ceil_div(blocks, 8) * 8;   // XCD-consistent row map (tiled_row_of)
-    p.stagger = 0;
-    if (p.K > 1 && p.m >= 64 && blocks > 256 && blocks <= 256 * per_cu && g_had_stagger != 0) {
-        // K x K stage of one row with the CU's matrix cores to itself: MFMAs per SIMD x 32 cycles
-        const long mfmas = (long)(p.K / 4) * ((p.K + 15) / 16) * (p.m / 16);
-        const long cyc = mfmas / 4 * 32;
-        p.stagger = (int)(g_had_stagger > 0 ? g_had_stagger : cyc);
-    }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), lds, st, p);
     return check_launch("hadamard");
 }
@@ -561,7 +444,8 @@ __global__ __launch_bounds__(64) void hadamard_prepare_kernel(const unsigned *wo
     }
 }
 
-static int g_had_threads = 0;   // 0: choose by shape
+static int g_had_fast = 0;        // process-wide SETTING (mq_hadamard_set_mode), read by every launch
+static thread_local int g_had_threads = 0;   // test hook (mq_hadamard_debug_threads); 0: choose by shape
 
 template <int DT, bool QUANT, bool HALF_LDS>
 static int launch_hadamard(const HadArgs &p, hipStream_t st)
@@ -633,6 +517,15 @@ static int hadamard_common(HadArgs p, int x_dtype, bool quant, void *stream)
         MQ_REQUIRE(p.qout && p.K_pad >= p.n && (p.ldq == MQ_LD_TILED ? p.K_pad % 64 == 0 : p.ldq >= p.K_pad),
                    "mq_hadamard_quant_i8: bad output geometry");
         MQ_REQUIRE(((uintptr_t)p.qout) % 4 == 0, "mq_hadamard_quant_i8: out must be 4-byte aligned");
+        p.vec_ok_q = (((uintptr_t)p.qout) % 16 == 0) && (p.ldq == MQ_LD_TILED || p.ldq % 16 == 0);
+    } else {
+        MQ_REQUIRE(p.out && p.ldo >= p.n, "mq_hadamard: bad output geometry");
+    }
+    if (g_had_fast) {        // non-default mode (mq_hadamard_set_mode): K x K stage on the half-precision matrix core
+        const int rc = hadamard_fast_dispatch(p, x_dtype, quant, st);
+        if (rc != MQ_EUNSUPPORTED) return rc;
+    }
+    if (quant) {
         switch (x_dtype) {
         case MQ_F16: return launch_hadamard_dt<MQ_F16, true>(p, st);
         case MQ_BF16: return launch_hadamard_dt<MQ_BF16, true>(p, st);
@@ -670,14 +563,21 @@ extern "C" int mq_hadamard_prepare(const uint32_t *had_words, int K, void *descr
     return check_launch("hadamard_prepare");
 }
 
+extern "C" int mq_hadamard_set_mode(int fast)
+{
+    mq::g_had_fast = fast ? 1 : 0;
+    return MQ_OK;
+}
+
+extern "C" int mq_hadamard_get_mode(void)
+{
+    return mq::g_had_fast;
+}
+
 extern "C" int mq_hadamard_debug_threads(int threads)
 {
-    // 256 / 512: threads per row; 0: by shape; negative values tune the workgroup stagger:
-    // -1 = default (one K x K stage), -2 = off, -(1000 + c) = c cycles
-    if (threads <= -1000) mq::g_had_stagger = -threads - 1000;
-    else if (threads == -2) mq::g_had_stagger = 0;
-    else if (threads == -1) mq::g_had_stagger = -1;
-    else mq::g_had_threads = (threads == 512 || threads == 256) ? threads : 0;
+    // TEST-ONLY: 256 / 512 threads per row for the calling thread's later launches; 0: by shape
+    mq::g_had_threads = (threads == 512 || threads == 256) ? threads : 0;
     return MQ_OK;
 }
 

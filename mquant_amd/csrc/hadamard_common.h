@@ -1,0 +1,127 @@
+// hadamard_common.h -- argument block and the row-chunk helpers shared by the online-Hadamard kernels
+// (hadamard.hip: the exact kernel; hadamard_fast.hip: the non-default fp16-matrix-core K x K stage).
+#pragma once
+#include "mq_common.h"
+
+namespace mq {
+
+struct HadArgs {
+    const void *x;
+    const void *x2 = nullptr;   // second operand of a fused activation (up of silu(gate)*up), same ldx
+    int act = MQ_ACT_NONE;      // activation applied to the loaded row before the transform
+    long M, n_in, ldx, n;
+    int K, m;
+    const uint8_t *had_bits;
+    const unsigned long long *masks = nullptr;   // prepared descriptor (mq_hadamard_prepare): lane masks of the sign operand
+    int unit_j = 1, unit_g = 4;                  // K x K stage: a wave owns unit_j 16-row tiles x unit_g 16-column tiles
+    int fp32_had;
+    void *out;
+    long ldo;
+    float s0, s1;
+    const uint8_t *row_sel;
+    int skip_col0;
+    float *x0_out;
+    int8_t *qout;
+    long K_pad, ldq;
+    int vec_ok;
+    int vec_ok2;       // same for x2
+    int vec_ok_q;      // 16-byte stores into the int8 output are aligned
+    float inv_sqrt_n;  // 1.0f / sqrtf((float)n), computed on the host in IEEE fp32
+    int row_bytes;     // LDS bytes per k-row of the staged copy
+    int swz;           // XOR-swizzle odd k-rows by 128 B (row_bytes % 256 == 0)
+    int y_bytes;       // LDS bytes of the staged row
+};
+
+// One 512-element chunk of a row, 8 consecutive elements per lane starting at ``idx``: the global loads
+// (zero beyond n_in: the pad of fake_quant/utils.py:465-471) and, with ACT, the fused activation
+// silu(x) * x2 / quick_gelu(x) evaluated like the torch ops (mq_common.h).
+template <int DT, bool ACT>
+__device__ __forceinline__ void had_load_chunk(const HadArgs &p, long row, long idx, float (&vb)[8])
+{
+    typedef typename Elem<DT>::T T;
+    const T *xr = reinterpret_cast<const T *>(p.x) + row * p.ldx;
+    if (idx + 8 <= p.n_in && p.vec_ok) {
+        if (sizeof(T) == 2) {
+            const v8us a = *reinterpret_cast<const v8us *>(xr + idx);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) vb[i] = Elem<DT>::ld((T)a[i]);
+        } else {
+            const v4f a = *reinterpret_cast<const v4f *>((const float *)xr + idx);
+            const v4f b = *reinterpret_cast<const v4f *>((const float *)xr + idx + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { vb[i] = a[i]; vb[4 + i] = b[i]; }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vb[i] = (idx + i < p.n_in) ? Elem<DT>::ld(xr[idx + i]) : 0.0f;
+    }
+    if (ACT && idx < p.n_in) {                            // fused activation prologue (own instantiation)
+        float ub[8];
+        if (p.act == MQ_ACT_SILU_MUL) {
+            const T *ur = reinterpret_cast<const T *>(p.x2) + row * p.ldx;
+            if (idx + 8 <= p.n_in && p.vec_ok2) {
+                if (sizeof(T) == 2) {
+                    const v8us a = *reinterpret_cast<const v8us *>(ur + idx);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) ub[i] = Elem<DT>::ld((T)a[i]);
+                } else {
+                    const v4f a = *reinterpret_cast<const v4f *>((const float *)ur + idx);
+                    const v4f b = *reinterpret_cast<const v4f *>((const float *)ur + idx + 4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { ub[i] = a[i]; ub[4 + i] = b[i]; }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ub[i] = (idx + i < p.n_in) ? Elem<DT>::ld(ur[idx + i]) : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (idx + i >= p.n_in) continue;
+            vb[i] = (p.act == MQ_ACT_SILU_MUL) ? act_silu_mul<DT>(vb[i], ub[i]) : act_quick_gelu<DT>(vb[i]);
+        }
+    }
+}
+
+// Butterflies of one chunk in the reference's ascending-stride (a + b, a - b) order: strides 1, 2, 4 inside
+// the lane's 8 registers, strides 8 .. min(m, 512) / 2 by wavefront shuffles (lane ^ stride / 8); when the
+// whole co-factor fits the chunk (m <= 512) also * 1 / sqrt(n) and the cast the FHT extension performs.
+template <int DT>
+__device__ __forceinline__ void had_butterfly_chunk(float (&v)[8], int lane, int m, float scale, bool mid_round)
+{
+#pragma unroll
+    for (int h = 1; h < 8; h <<= 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if ((i & h) == 0) {
+                const float a0 = v[i], a1 = v[i + h];
+                v[i] = a0 + a1;
+                v[i + h] = a0 - a1;
+            }
+        }
+    }
+    for (int h = 8; h < m && h < 512; h <<= 1) {
+        const int lm = h >> 3;
+        // lower lane of a pair: a + b, upper lane: a - b.  fma(own, +-1, other) is that sum / difference with its one
+        // rounding (own * +-1 is exact) in ONE instruction per element instead of a subtract, an add and a select
+        const float sgn = (lane & lm) ? -1.0f : 1.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float o = __shfl_xor(v[i], lm);
+            v[i] = __builtin_fmaf(v[i], sgn, o);
+        }
+    }
+    if (m <= 512) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float t = v[i] * scale;
+            if (mid_round) t = Elem<DT>::rnd(t);
+            v[i] = t;
+        }
+    }
+}
+
+// hadamard_fast.hip: MQ_EUNSUPPORTED (no message) = shape / dtype outside the fast mode, run the exact kernel
+int hadamard_fast_dispatch(const HadArgs &p, int x_dtype, bool quant, hipStream_t st);
+
+}  // namespace mq

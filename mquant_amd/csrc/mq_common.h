@@ -86,6 +86,47 @@ __device__ __forceinline__ int quant_level(float x, float s, float lo, float hi)
     return (int)v;
 }
 
+// The same levels without the ~10-instruction IEEE division on (almost) every element.  t = x * fl(1/s) is
+// within 2^-23 |x/s| of the quotient and fl(x/s) within 2^-24 |x/s|: for |x/s| <= 256 the two lie less than
+// 4.6e-5 apart, so rint() of either is the same integer unless t sits within that distance of a half-integer
+// -- then, and only then (about 2 elements in 10^4), the exact quotient is computed; beyond 256 both saturate
+// (|lo|, |hi| <= 255).  Bit-identical to quant_level by construction; the caller passes inv_s = 1.0f / s
+// (IEEE) and uses this form only when s and inv_s are normal numbers (quant_rcp_ok).
+__host__ __device__ inline bool quant_rcp_ok(float s)
+{
+    const float r = 1.0f / s;
+    return s >= 1.17549435e-38f && r >= 1.17549435e-38f && r <= 3.0e38f;
+}
+
+// N levels at once: ONE (rarely taken) branch instead of N.  rcp = false: plain quant_level.
+template <int N>
+__device__ __forceinline__ void quant_levels(const float (&x)[N], float s, float inv_s, bool rcp, float lo, float hi, int (&q)[N])
+{
+    float t[N];
+    if (rcp) {
+        bool risky = false;
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            t[e] = x[e] * inv_s;
+            risky |= fabsf(__builtin_amdgcn_fractf(t[e]) - 0.5f) < 1.0e-4f;
+        }
+        if (risky) {
+#pragma unroll
+            for (int e = 0; e < N; ++e) t[e] = x[e] / s;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < N; ++e) t[e] = x[e] / s;
+    }
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        float v = rintf(t[e]);
+        v = fmaxf(v, lo);
+        v = fminf(v, hi);
+        q[e] = (int)v;
+    }
+}
+
 // ---- library-free transcendental pieces --------------------------------------------------------
 // log2 / exp2 in double from ordered +,*,/ only (no libm, no contraction): every caller rounds the
 // result once to fp32, which makes device results reproducible bit for bit by the C oracle

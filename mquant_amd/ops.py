@@ -447,6 +447,16 @@ def splitk_workspace(device, nbytes: int = 64 << 20) -> torch.Tensor:
     return ws
 
 
+def hadamard_fast_mode(on: bool = True) -> bool:
+    """NON-DEFAULT setting of the online Hadamard kernels (``mq_hadamard_set_mode``): K x K stage on the
+    half-precision matrix core -- same exact products, another fp32 accumulation order, NOT bit-identical to
+    the reference's CPU run.  Returns the previous setting.  Process-wide; the default is the exact mode."""
+    from ._lib import load
+    prev = bool(load().mq_hadamard_get_mode())
+    call("mq_hadamard_set_mode", 1 if on else 0)
+    return prev
+
+
 def gemm_debug_force(tile: int = -1, splits: int = 0) -> None:
     """Tuning hook: force the tile shape (ids: csrc/gemm_w4a8.hip dispatch_tile) / split-K."""
     call("mq_gemm_debug_force", tile, splits)

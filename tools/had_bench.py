@@ -28,18 +28,22 @@ from mquant_amd._lib import call
 dev = torch.device("cuda:0")
 threads = int(os.environ.get("HAD_THREADS", "0"))
 call("mq_hadamard_debug_threads", threads)
-stagger = int(os.environ.get("HAD_STAGGER", "-1"))      # -1 default, -2 off, >= 0 cycles
-call("mq_hadamard_debug_threads", stagger if stagger < 0 else -(1000 + stagger))
-print("threads per row:", threads, "stagger:", stagger)
+fast = int(os.environ.get("HAD_FAST", "0"))
+ops.hadamard_fast_mode(bool(fast))
+print("threads per row:", threads, "fast mode:", fast)
 rows = [int(v) for v in os.environ.get("HAD_ROWS", "0").split(",")]
 shapes = [("vis.fc2", 1024, 5120, 5120), ("llm.down", 768, 18944, 19968),
-          ("qwenvl.c_proj", 768, 11008, 11008), ("pow2.8192", 1024, 8192, 8192)]
+          ("qwenvl.c_proj", 768, 11008, 11008), ("internvl.w2", 768, 14336, 14336), ("72b.down", 768, 29568, 30720),
+          ("pow2.8192", 1024, 8192, 8192)]
+only = os.environ.get("HAD_SHAPES", "")
+if only:
+    shapes = [sh for sh in shapes if sh[0] in only.split(",")]
 if rows != [0]:
     shapes = [(nm, r, a, b) for (nm, _, a, b) in shapes[:2] for r in rows]
 for name, M, n_in, n in shapes:
     _, K = hu.get_hadK(n)
     bits = hu.had_sign_bits(K, dev) if K > 1 else None
-    for dt in (torch.float16, torch.float32):
+    for dt in ((torch.float16,) if only else (torch.float16, torch.float32)):
         x = torch.randn((M, n_in), device=dev, dtype=torch.float32).to(dt)
         out = torch.empty((M, (n + 127) // 128 * 128), dtype=torch.int8, device=dev)
         us = bench(lambda: ops.hadamard_quant_i8(x, n, K, bits, 0.05, out=out))
