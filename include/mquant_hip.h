@@ -119,9 +119,11 @@ int mq_fakequant_act(const void *x, int x_dtype, long M, long K, long ldx,
  *           reach HBM.
  * ------------------------------------------------------------------------- */
 /* fp32_had is a flag word: MQ_HAD_FP32 = --fp32_had; MQ_HAD_PREPARED = had_words points at a
- * descriptor written by mq_hadamard_prepare (the sign words followed by the 64-lane masks of the MFMA
- * sign operand: one VALU instruction per operand instead of three -- the fp32 MFMA shares the vector
- * ALU's datapath, every VALU instruction beside it is lost matrix time).  Results are identical. */
+ * descriptor written by mq_hadamard_prepare (16-byte aligned, mq_hadamard_prepared_bytes(K) bytes): the sign
+ * words, followed by the 64-lane masks of the fp32 MFMA sign operand (one VALU instruction per operand instead
+ * of three -- the fp32 MFMA shares the vector ALU's datapath, every VALU instruction beside it is lost matrix
+ * time) and by the +-1 half-precision operand images of the fast mode (mq_hadamard_set_mode).  Results are
+ * identical with and without the descriptor. */
 #define MQ_HAD_FP32 1
 #define MQ_HAD_PREPARED 2
 size_t mq_hadamard_prepared_bytes(int K);

@@ -68,10 +68,16 @@ __global__ __launch_bounds__(256) void act_quant_kernel(
         }
 
         int q[16];
+        if (sv) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float s = sv ? ((col + i < K) ? sv[col + i] : 1.0f) : s_t;
-            q[i] = quant_level(v[i], s, -128.0f, 127.0f);
+            for (int i = 0; i < 16; ++i) {
+                const float s = (col + i < K) ? sv[col + i] : 1.0f;
+                q[i] = quant_level(v[i], s, -128.0f, 127.0f);
+            }
+        } else {
+            // one scale per row: x * (1 / s) with the exact quotient only next to a half-integer (mq_common.h) -- the
+            // same levels as the IEEE division for a third of its instructions
+            quant_levels<16>(v, s_t, 1.0f / s_t, quant_rcp_ok(s_t), -128.0f, 127.0f, q);
         }
         if (skip_col0 && col == 0) {
             if (x0_out) x0_out[row] = v[0];

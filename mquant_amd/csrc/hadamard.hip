@@ -26,6 +26,11 @@
 
 namespace mq {
 
+// byte offsets inside a prepared descriptor: sign words | lane masks of the fp32 sign operand | half operand images
+static size_t prepared_masks_offset(int K) { return ((size_t)K * ((K + 31) / 32) * 4 + 7) / 8 * 8; }
+static size_t prepared_half_offset(int K) { return (prepared_masks_offset(K) + (size_t)((K + 15) / 16) * (K / 4) * 8 + 15) / 16 * 16; }
+static size_t prepared_half_bytes(int K) { return (size_t)((K + 31) / 32) * ((K + 15) / 16) * 1024; }   // per dtype
+
 // storage of the staged row in LDS: 16-bit when the values are exactly half-precision
 template <int DT, bool HALF_LDS> struct Stage;
 template <int DT> struct Stage<DT, true> {
@@ -77,8 +82,11 @@ __device__ __forceinline__ RowScale row_scale(float s)
     return RowScale{s, 1.0f / s, quant_rcp_ok(s)};
 }
 
+// ``o``: the int8 output address (QUANT), computed by the caller: the K x K units walk their output rows j with a
+// constant byte stride, had_out_stride: no 64-bit layout arithmetic per group of levels)
 template <int DT, bool QUANT, int N>
-__device__ __forceinline__ void had_emit_n(const HadArgs &p, long row, long col, const float (&v)[N], const RowScale &rs, bool aligned)
+__device__ __forceinline__ void had_emit_n(const HadArgs &p, long row, long col, const float (&v)[N], const RowScale &rs, bool aligned,
+                                           int8_t *o)
 {
     float r[N];
 #pragma unroll
@@ -90,7 +98,6 @@ __device__ __forceinline__ void had_emit_n(const HadArgs &p, long row, long col,
             if (p.x0_out) p.x0_out[row] = r[0];
             q[0] = 0;
         }
-        int8_t *o = p.qout + act_offset(row, col, p.K_pad, p.ldq);
         if (N == 4 && aligned) {
             *reinterpret_cast<unsigned *>(o) = (q[0] & 0xff) | ((q[1] & 0xff) << 8) | ((q[2] & 0xff) << 16) | ((unsigned)(q[3] & 0xff) << 24);
         } else if (N == 2) {
@@ -105,6 +112,13 @@ __device__ __forceinline__ void had_emit_n(const HadArgs &p, long row, long col,
 #pragma unroll
         for (int e = 0; e < N; ++e) o[e] = Elem<DT>::st(r[e]);
     }
+}
+
+// Byte distance between the int8 outputs (row, j * m + c) and (row, (j + 1) * m + c) for a co-factor m >= 64:
+// m in a row-major matrix; m / 64 pieces of 1 KiB in the tiled layout (act_offset, mq_common.h).
+__device__ __forceinline__ long had_out_stride(const HadArgs &p)
+{
+    return p.ldq == MQ_LD_TILED ? 16L * p.m : (long)p.m;
 }
 
 // K x K stage for one unit of UJ 16-row tiles x UG 16-column tiles, sign operands from the prepared
@@ -173,18 +187,22 @@ __device__ __forceinline__ void had_kxk_unit(const HadArgs &p, long row, const R
             for (int g = 0; g < UG; ++g) acc[jj][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[g], acc[jj][g], 0, 0, 0);
         }
     }
+    const int j0 = jg * UJ * 16 + lk * 4;                       // first output row j of this lane
+    const long ostride = had_out_stride(p);
+    int8_t *obase = p.qout + act_offset(row, (long)j0 * m + col0, p.K_pad, p.ldq);     // unused without QUANT
 #pragma unroll
     for (int jj = 0; jj < UJ; ++jj)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int j = (jg * UJ + jj) * 16 + lk * 4 + r;
+            const int j = j0 + jj * 16 + r;
             if (j < K) {
+                int8_t *o = obase + (jj * 16 + r) * ostride;
                 if (UG == 4) {
                     const float v4[4] = {acc[jj][0][r], acc[jj][1][r], acc[jj][2][r], acc[jj][3][r]};
-                    had_emit_n<DT, QUANT, 4>(p, row, (long)j * m + col0, v4, rs, (p.ldq & 3) == 0);
+                    had_emit_n<DT, QUANT, 4>(p, row, (long)j * m + col0, v4, rs, (p.ldq & 3) == 0, o);
                 } else {
                     const float v2[2] = {acc[jj][0][r], acc[jj][1][r]};
-                    had_emit_n<DT, QUANT, 2>(p, row, (long)j * m + col0, v2, rs, true);
+                    had_emit_n<DT, QUANT, 2>(p, row, (long)j * m + col0, v2, rs, true, o);
                 }
             }
         }
@@ -371,12 +389,15 @@ __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
                     for (int q = 0; q < 7; ++q)
                         if (q < tail) kstep(word, q, yp + (full_words * 8 + q) * kstride);
                 }
+                const int j0 = jt * 16 + lk * 4;
+                int8_t *obase = p.qout + act_offset(row, (long)j0 * m + col0, p.K_pad, p.ldq);     // unused without QUANT
+                const long ostride = had_out_stride(p);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int j = jt * 16 + lk * 4 + r;
+                    const int j = j0 + r;
                     if (j < K) {
                         const float v4[4] = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-                        had_emit_n<DT, QUANT, 4>(p, row, (long)j * m + col0, v4, rs, (p.ldq & 3) == 0);
+                        had_emit_n<DT, QUANT, 4>(p, row, (long)j * m + col0, v4, rs, (p.ldq & 3) == 0, obase + r * ostride);
                     }
                 }
             }
@@ -429,7 +450,7 @@ static int launch_hadamard_t(HadArgs p, hipStream_t st)
 // the lane masks of the MFMA sign operand: masks[t][jt] for t < K/4, jt < ceil(K/16), bit l set when
 // hadK[16 jt + (l & 15)][4 t + (l >> 4)] == -1 (rows >= K: 0).
 __global__ __launch_bounds__(64) void hadamard_prepare_kernel(const unsigned *words, int K, unsigned *out_words,
-                                                                unsigned long long *out_masks)
+                                                                unsigned long long *out_masks, v4i *out_half)
 {
     const int WPR = (K + 31) / 32, ksteps = K / 4;
     const int lane = threadIdx.x;
@@ -441,6 +462,27 @@ __global__ __launch_bounds__(64) void hadamard_prepare_kernel(const unsigned *wo
         const bool neg = j < K && ((words[j * WPR + (k >> 5)] >> (k & 31)) & 1u) == 0;   // bit set = +1
         const unsigned long long mask = __ballot(neg);
         if (lane == 0) out_masks[u] = mask;
+    }
+    // operand images of the fast mode (hadamard_fast.hip): [fp16 | bf16][ceil(K/32) tiles][ceil(K/16) k-steps][64 lanes],
+    // lane l = the 8 signs H[32 jt + (l & 31)][16 ks + 8 (l >> 5) + e] as +-1.0 half numbers (0 outside the matrix)
+    const int JT32 = (K + 31) / 32, KS16 = (K + 15) / 16;
+    for (int u = blockIdx.x; u < 2 * JT32 * KS16; u += gridDim.x) {
+        const int dt = u / (JT32 * KS16), r = u - dt * JT32 * KS16, jt = r / KS16, ks = r - jt * KS16;
+        const unsigned one = dt == 0 ? 0x3C00u : 0x3F80u;
+        const int j = jt * 32 + (lane & 31), k0 = ks * 16 + 8 * (lane >> 5);
+        v4i f;
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+            unsigned h[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int k = k0 + 2 * e2 + b;
+                h[b] = 0;
+                if (j < K && k < K) h[b] = ((words[j * WPR + (k >> 5)] >> (k & 31)) & 1u) ? one : (one | 0x8000u);
+            }
+            f[e2] = (int)(h[0] | (h[1] << 16));
+        }
+        out_half[(long)u * 64 + lane] = f;
     }
 }
 
@@ -493,11 +535,13 @@ static int hadamard_common(HadArgs p, int x_dtype, bool quant, void *stream)
     const bool prepared = (p.fp32_had & MQ_HAD_PREPARED) != 0;
     p.fp32_had &= MQ_HAD_FP32;
     p.masks = nullptr;
+    p.hfrag = nullptr;
     p.unit_j = 1; p.unit_g = 4;
     if (prepared && p.K > 1) {
-        MQ_REQUIRE(((uintptr_t)p.had_bits) % 8 == 0, "mq_hadamard: a prepared descriptor is 8-byte aligned");
-        const size_t words_bytes = ((size_t)p.K * ((p.K + 31) / 32) * 4 + 7) / 8 * 8;
-        p.masks = reinterpret_cast<const unsigned long long *>(p.had_bits + words_bytes);
+        MQ_REQUIRE(((uintptr_t)p.had_bits) % 16 == 0, "mq_hadamard: a prepared descriptor is 16-byte aligned");
+        p.masks = reinterpret_cast<const unsigned long long *>(p.had_bits + prepared_masks_offset(p.K));
+        if (x_dtype != MQ_F32)
+            p.hfrag = reinterpret_cast<const v4i *>(p.had_bits + prepared_half_offset(p.K) + (x_dtype == MQ_BF16 ? prepared_half_bytes(p.K) : 0));
         const int JT = (p.K + 15) / 16;
         // measured (profiles/r2_hadamard.txt): the 5 x 2 units pay off for the large factors (K = 140 / 156 /
         // 172, down_proj 76 -> 72 us); for small K the round-1 form (one tile x four column tiles) is faster
@@ -547,19 +591,18 @@ static int hadamard_common(HadArgs p, int x_dtype, bool quant, void *stream)
 extern "C" size_t mq_hadamard_prepared_bytes(int K)
 {
     if (K <= 1 || K % 4 != 0) return 0;
-    const size_t words_bytes = ((size_t)K * ((K + 31) / 32) * 4 + 7) / 8 * 8;
-    return words_bytes + (size_t)((K + 15) / 16) * (K / 4) * 8;
+    return mq::prepared_half_offset(K) + 2 * mq::prepared_half_bytes(K);
 }
 
 extern "C" int mq_hadamard_prepare(const uint32_t *had_words, int K, void *descriptor, void *stream)
 {
     using namespace mq;
     MQ_REQUIRE(K > 1 && K % 4 == 0 && had_words && descriptor, "mq_hadamard_prepare: K=%d must be a multiple of 4 (> 1), buffers non-null", K);
-    MQ_REQUIRE(((uintptr_t)descriptor) % 8 == 0 && ((uintptr_t)had_words) % 4 == 0, "mq_hadamard_prepare: alignment");
-    const size_t words_bytes = ((size_t)K * ((K + 31) / 32) * 4 + 7) / 8 * 8;
+    MQ_REQUIRE(((uintptr_t)descriptor) % 16 == 0 && ((uintptr_t)had_words) % 4 == 0, "mq_hadamard_prepare: alignment (descriptor: 16 bytes)");
+    char *d = reinterpret_cast<char *>(descriptor);
     hipLaunchKernelGGL(hadamard_prepare_kernel, dim3(64), dim3(64), 0, (hipStream_t)stream, had_words, K,
-                       reinterpret_cast<unsigned *>(descriptor),
-                       reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(descriptor) + words_bytes));
+                       reinterpret_cast<unsigned *>(d), reinterpret_cast<unsigned long long *>(d + prepared_masks_offset(K)),
+                       reinterpret_cast<v4i *>(d + prepared_half_offset(K)));
     return check_launch("hadamard_prepare");
 }
 

@@ -85,7 +85,12 @@ __global__ __launch_bounds__(256, 3) void hadamard_fast_kernel(HadArgs p)
         if (NH == 2) own_jt[1] = 4 + (wave % EXTRA);
     }
     v4i Hf[NH][KS];
-    {
+    if (p.hfrag) {           // prepared descriptor: one 16-byte load per operand (a workgroup owns ONE row: nothing amortises a rebuild)
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) Hf[h][ks] = p.hfrag[((long)own_jt[h] * KS + ks) * 64 + lane];
+    } else {
         const unsigned *gw = reinterpret_cast<const unsigned *>(p.had_bits);
         const int WPR = (K + 31) / 32;
 #pragma unroll
