@@ -298,6 +298,13 @@ int mq_kv_quant_fp8(const void *kv, int dtype, long T, int heads, int head_dim, 
                     const float *scale, uint8_t *out, long ldo, void *stream);
 int mq_kv_dequant_fp8(const uint8_t *q, long T, int heads, int head_dim, long ld,
                       const float *scale, void *out, int out_dtype, long ldo, void *stream);
+/* The write with the READ-BACK fused in: besides the e4m3 bytes it stores readback[t][h][d] = cast(float(q) * s[h])
+ * (what mq_kv_dequant_fp8 would return later) in the source dtype, row stride ldr elements -- the K / V the
+ * attention of the SAME prefill step consumes, so prefill and decode attend over identical values and the
+ * separate dequantise-on-read launch is gone.  readback == NULL: mq_kv_quant_fp8. */
+int mq_kv_quant_fp8_readback(const void *kv, int dtype, long T, int heads, int head_dim, long ld,
+                             const float *scale, uint8_t *out, long ldo, void *readback, long ldr, void *stream);
+
 
 /* ---------------------------------------------------------------------------
  * GPTQ: the column loop of one lazy-batch block, gptq/gptq_utils.py:258-279 (symmetric

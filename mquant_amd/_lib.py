@@ -48,6 +48,7 @@ SIGNATURES = {
     "mq_wquant_sym": (_i, [_vp, _i, _l, _l, _l, _i, _i, _f, _i, _f, _vp, _vp, _vp, _vp, _l, _vp]),
     "mq_rotate_f64": (_i, [_vp, _i, _l, _l, _l, _vp, _i, _vp, _vp]),
     "mq_kv_quant_fp8": (_i, [_vp, _i, _l, _i, _i, _l, _vp, _vp, _l, _vp]),
+    "mq_kv_quant_fp8_readback": (_i, [_vp, _i, _l, _i, _i, _l, _vp, _vp, _l, _vp, _l, _vp]),
     "mq_kv_dequant_fp8": (_i, [_vp, _l, _i, _i, _l, _vp, _vp, _i, _l, _vp]),
     "mq_gptq_block": (_i, [_vp, _l, _i, _l, _vp, _l, _vp, _i, _vp, _l, _vp, _l, _vp]),
     "mq_prepack_w4": (_i, [_vp, _l, _l, _i, _vp, _vp]),

@@ -18,6 +18,8 @@ struct KvArgs {
     long T, lds, ldd;      // tokens, source / destination token strides (elements)
     int heads, d;
     const float *scale;    // [heads]
+    void *hat = nullptr;   // optional second output of the write kernel: the cache contents read back, cast(float(q) * s)
+    long ldh = 0;
 };
 
 template <int DT>
@@ -52,6 +54,32 @@ __global__ __launch_bounds__(256) void kv_quant_fp8_kernel(KvArgs p)
         w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], w1, false);
         w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], w1, true);
         *reinterpret_cast<v2i *>(reinterpret_cast<uint8_t *>(p.dst) + t * p.ldd + c) = v2i{w0, w1};
+        if (p.hat) {
+            // what a later read of the cache returns (kv_dequant_fp8_kernel), handed to the attention of THIS step
+            // in the same launch: prefill and decode then attend over identical K / V, and the dequantise-on-read
+            // pass (one more launch, one more read of the cache) disappears from the prefill
+            float y[8];
+            y[0] = __builtin_amdgcn_cvt_f32_fp8(w0, 0);
+            y[1] = __builtin_amdgcn_cvt_f32_fp8(w0, 1);
+            y[2] = __builtin_amdgcn_cvt_f32_fp8(w0, 2);
+            y[3] = __builtin_amdgcn_cvt_f32_fp8(w0, 3);
+            y[4] = __builtin_amdgcn_cvt_f32_fp8(w1, 0);
+            y[5] = __builtin_amdgcn_cvt_f32_fp8(w1, 1);
+            y[6] = __builtin_amdgcn_cvt_f32_fp8(w1, 2);
+            y[7] = __builtin_amdgcn_cvt_f32_fp8(w1, 3);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = y[e] * s;
+            if constexpr (DT == MQ_F32) {
+                float *o = reinterpret_cast<float *>(p.hat) + t * p.ldh + c;
+                *reinterpret_cast<v4f *>(o) = v4f{y[0], y[1], y[2], y[3]};
+                *reinterpret_cast<v4f *>(o + 4) = v4f{y[4], y[5], y[6], y[7]};
+            } else {
+                v8us h;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) h[e] = Elem<DT>::st(y[e]);
+                *reinterpret_cast<v8us *>(reinterpret_cast<unsigned short *>(p.hat) + t * p.ldh + c) = h;
+            }
+        }
     }
 }
 
@@ -112,15 +140,29 @@ static unsigned kv_grid(long T, int heads, int d)
 
 }  // namespace mq
 
+extern "C" int mq_kv_quant_fp8_readback(const void *kv, int dtype, long T, int heads, int head_dim, long ld,
+                                        const float *scale, uint8_t *out, long ldo, void *readback, long ldr, void *stream);
+
 extern "C" int mq_kv_quant_fp8(const void *kv, int dtype, long T, int heads, int head_dim, long ld,
                                const float *scale, uint8_t *out, long ldo, void *stream)
+{
+    return mq_kv_quant_fp8_readback(kv, dtype, T, heads, head_dim, ld, scale, out, ldo, nullptr, 0, stream);
+}
+
+extern "C" int mq_kv_quant_fp8_readback(const void *kv, int dtype, long T, int heads, int head_dim, long ld,
+                                        const float *scale, uint8_t *out, long ldo, void *readback, long ldr, void *stream)
 {
     using namespace mq;
     MQ_REQUIRE(dtype == MQ_F16 || dtype == MQ_BF16 || dtype == MQ_F32, "mq_kv_quant_fp8: dtype %d", dtype);
     const int rc = kv_check("mq_kv_quant_fp8", kv, out, T, heads, head_dim, ld, ldo, scale, dtype == MQ_F32 ? 4 : 2, 1);
     if (rc != MQ_OK) return rc;
+    if (readback) {
+        const int eb = dtype == MQ_F32 ? 4 : 2;
+        MQ_REQUIRE(ldr >= (long)heads * head_dim && (uintptr_t)readback % 16 == 0 && (ldr * eb) % 16 == 0,
+                   "mq_kv_quant_fp8_readback: read-back rows must be 16-byte aligned with a stride >= heads * head_dim");
+    }
     if (T == 0) return MQ_OK;
-    KvArgs a{kv, out, T, ld, ldo, heads, head_dim, scale};
+    KvArgs a{kv, out, T, ld, ldo, heads, head_dim, scale, readback, ldr};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid(kv_grid(T, heads, head_dim));
     switch (dtype) {

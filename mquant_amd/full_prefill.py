@@ -11,7 +11,8 @@ one calibration pass) so that the int8 grids are the ones this dataflow would ge
 """
 from __future__ import annotations
 
-from typing import Dict, List
+from dataclasses import dataclass
+from typing import Dict, List, Optional
 
 import torch
 import torch.nn.functional as F
@@ -22,6 +23,22 @@ from .workload import M_MERGED, M_TXT, M_VIS, Layer, Prefill
 VOCAB = 152064
 VIS_DIM, VIS_HEADS = 1280, 16
 LLM_DIM, LLM_HEADS, LLM_KV_HEADS, HEAD_DIM = 3584, 28, 4, 128
+
+
+@dataclass
+class Geometry:
+    """Widths the glue operators need (the Linears carry their own shapes): Qwen2-VL family."""
+    vis_dim: int = VIS_DIM
+    vis_heads: int = VIS_HEADS
+    llm_dim: int = LLM_DIM
+    heads: int = LLM_HEADS
+    kv_heads: int = LLM_KV_HEADS
+    head_dim: int = HEAD_DIM
+    vocab: int = VOCAB
+
+
+QWEN2VL_7B = Geometry()
+QWEN2VL_72B = Geometry(llm_dim=8192, heads=64, kv_heads=8, head_dim=128)     # BASELINE configuration 5
 
 
 def _rope_tables(rows: int, dim: int, device, dtype, base: float = 10000.0):
@@ -39,9 +56,17 @@ def _rope(x, cos, sin):
 
 
 class FullPrefill:
-    def __init__(self, pf: Prefill, seed: int = 7, fused_glue: bool = True, sample: int = 0):
+    def __init__(self, pf: Prefill, seed: int = 7, fused_glue: bool = True, sample: int = 0,
+                 geometry: Optional[Geometry] = None, kv_fp8: bool = False):
         #: norm -> quantize and activation -> Hadamard -> quantize as single launches
         self.fused_glue = fused_glue
+        self.g = geometry or QWEN2VL_7B
+        #: fp8 (e4m3fn) KV cache, SURVEY 8(f4): the K|V columns of the fused q|k|v GEMM output are quantized on write
+        #: with one static scale per KV head (calibrated with the activation scales), and the attention of the same
+        #: step consumes the cache contents read back by the same launch (mq_kv_quant_fp8_readback)
+        self.kv_fp8 = kv_fp8
+        self.kv_cache: List[torch.Tensor] = []
+        self.kv_scales: List[torch.Tensor] = []
         assert pf.share_groups, "the chained prefill uses the fused q/k/v and gate/up GEMMs"
         self.pf, self.dev, self.dtype = pf, pf.device, pf.dtype
         by: Dict[str, List[Layer]] = {}
@@ -51,13 +76,13 @@ class FullPrefill:
         g = torch.Generator(device=self.dev).manual_seed(seed)
         rnd = lambda *shape, std=1.0: (torch.randn(shape, generator=g, device=self.dev) * std).to(self.dtype)
         self.patches = rnd(M_VIS, 1176)
-        self.text_embeds = rnd(M_TXT, LLM_DIM)
-        self.lm_head = rnd(VOCAB, LLM_DIM, std=0.02)             # a weight: the same for every sample
+        self.text_embeds = rnd(M_TXT, self.g.llm_dim)
+        self.lm_head = rnd(self.g.vocab, self.g.llm_dim, std=0.02)             # a weight: the same for every sample
         self.sample = sample
         if sample:
             self.set_sample(sample)
-        self.vcos, self.vsin = _rope_tables(M_VIS, VIS_DIM // VIS_HEADS, self.dev, self.dtype)
-        self.lcos, self.lsin = _rope_tables(M_MERGED + M_TXT, HEAD_DIM, self.dev, self.dtype, 1e6)
+        self.vcos, self.vsin = _rope_tables(M_VIS, self.g.vis_dim // self.g.vis_heads, self.dev, self.dtype)
+        self.lcos, self.lsin = _rope_tables(M_MERGED + M_TXT, self.g.head_dim, self.dev, self.dtype, 1e6)
         self.vcos2, self.vsin2 = self.vcos[:, 0].contiguous(), self.vsin[:, 0].contiguous()     # [T, d] for the kernel
         self.lcos2, self.lsin2 = self.lcos[:, 0].contiguous(), self.lsin[:, 0].contiguous()
         self.calibrating = False
@@ -72,7 +97,7 @@ class FullPrefill:
             g0 = torch.Generator(device=self.dev).manual_seed(7)
             rnd = lambda *shape: torch.randn(shape, generator=g0, device=self.dev).to(self.dtype)
         self.patches = rnd(M_VIS, 1176)
-        self.text_embeds = rnd(M_TXT, LLM_DIM)
+        self.text_embeds = rnd(M_TXT, self.g.llm_dim)
         self.sample = sample
 
     # -- one wrapped Linear (or fused group) -----------------------------------------------
@@ -124,45 +149,68 @@ class FullPrefill:
             L.lin.s_x0, L.lin.s_x1 = s0, s1
 
     # -- the prefill -----------------------------------------------------------------------
+    def kv_cache_bytes(self) -> int:
+        """Bytes the K / V of this prefill occupy in the cache (all layers)."""
+        layers = len(self.by["llm.q_proj"])
+        per_elem = 1 if self.kv_fp8 else torch.empty((), dtype=self.dtype).element_size()
+        return layers * (M_MERGED + M_TXT) * 2 * self.g.kv_heads * self.g.head_dim * per_elem
+
     def step(self) -> torch.Tensor:
-        by = self.by
+        by, g = self.by, self.g
+        VD, VH = g.vis_dim, g.vis_heads
+        D, H, KVH, HD = g.llm_dim, g.heads, g.kv_heads, g.head_dim
         # vision tower
         x = self._lin(by["vis.patch_embed"][0], self.patches)
         for i in range(len(by["vis.attn.qkv"])):
-            qkv = self._norm_lin(by["vis.attn.qkv"][i], x, VIS_DIM)
+            qkv = self._norm_lin(by["vis.attn.qkv"][i], x, VD)
             if self.fused_glue:                               # q and k rotated in place, one launch
-                ops.rope_inplace(qkv[:, :2 * VIS_DIM], 2 * VIS_HEADS, VIS_DIM // VIS_HEADS, self.vcos2, self.vsin2)
-                q, k, v = qkv.view(M_VIS, 3, VIS_HEADS, -1).unbind(1)
+                ops.rope_inplace(qkv[:, :2 * VD], 2 * VH, VD // VH, self.vcos2, self.vsin2)
+                q, k, v = qkv.view(M_VIS, 3, VH, -1).unbind(1)
             else:
-                q, k, v = qkv.view(M_VIS, 3, VIS_HEADS, -1).unbind(1)
+                q, k, v = qkv.view(M_VIS, 3, VH, -1).unbind(1)
                 q, k = _rope(q, self.vcos, self.vsin), _rope(k, self.vcos, self.vsin)
             a = F.scaled_dot_product_attention(q.transpose(0, 1)[None], k.transpose(0, 1)[None],
                                                v.transpose(0, 1)[None])[0]
-            x = self._lin(by["vis.attn.proj"][i], a.transpose(0, 1).reshape(M_VIS, VIS_DIM), residual=x)
-            f = self._norm_lin(by["vis.mlp.fc1"][i], x, VIS_DIM)
+            x = self._lin(by["vis.attn.proj"][i], a.transpose(0, 1).reshape(M_VIS, VD), residual=x)
+            f = self._norm_lin(by["vis.mlp.fc1"][i], x, VD)
             x = self._act_lin(by["vis.mlp.fc2"][i], f, None, ops.ACT_QUICK_GELU, residual=x)   # hidden_act = quick_gelu
-        m = F.rms_norm(x, (VIS_DIM,), eps=1e-6).view(M_MERGED, 4 * VIS_DIM)
+        m = F.rms_norm(x, (VD,), eps=1e-6).view(M_MERGED, 4 * VD)
         m = self._lin(by["merger.mlp.2"][0], F.gelu(self._lin(by["merger.mlp.0"][0], m)))
         # language model: [vision tokens | text tokens]
         hdn = torch.cat([m, self.text_embeds], dim=0)
         T = hdn.shape[0]
-        kv = LLM_KV_HEADS * HEAD_DIM
+        kv = KVH * HD
         for i in range(len(by["llm.q_proj"])):
-            qkv = self._norm_lin(by["llm.q_proj"][i], hdn, LLM_DIM)      # fused q|k|v GEMM
+            qkv = self._norm_lin(by["llm.q_proj"][i], hdn, D)      # fused q|k|v GEMM
             if self.fused_glue:
-                ops.rope_inplace(qkv[:, :LLM_DIM + kv], LLM_HEADS + LLM_KV_HEADS, HEAD_DIM, self.lcos2, self.lsin2)
-                q = qkv[:, :LLM_DIM].view(T, LLM_HEADS, HEAD_DIM)
-                k = qkv[:, LLM_DIM:LLM_DIM + kv].view(T, LLM_KV_HEADS, HEAD_DIM)
+                ops.rope_inplace(qkv[:, :D + kv], H + KVH, HD, self.lcos2, self.lsin2)
+                q = qkv[:, :D].view(T, H, HD)
+                k = qkv[:, D:D + kv].view(T, KVH, HD)
+                v = qkv[:, D + kv:].view(T, KVH, HD)
+                kv_cols = qkv[:, D:].view(T, 2 * KVH, HD)          # K | V side by side, K already rotated
             else:
-                q = _rope(qkv[:, :LLM_DIM].view(T, LLM_HEADS, HEAD_DIM), self.lcos, self.lsin)
-                k = _rope(qkv[:, LLM_DIM:LLM_DIM + kv].view(T, LLM_KV_HEADS, HEAD_DIM), self.lcos, self.lsin)
-            v = qkv[:, LLM_DIM + kv:].view(T, LLM_KV_HEADS, HEAD_DIM)
+                q = _rope(qkv[:, :D].view(T, H, HD), self.lcos, self.lsin)
+                k = _rope(qkv[:, D:D + kv].view(T, KVH, HD), self.lcos, self.lsin)
+                v = qkv[:, D + kv:].view(T, KVH, HD)
+                kv_cols = torch.cat([k, v], dim=1) if self.kv_fp8 else None
+            if self.kv_fp8:
+                if self.calibrating:
+                    if len(self.kv_scales) <= i:
+                        self.kv_scales.append(ops.kv_scale_from_absmax(kv_cols))
+                        self.kv_cache.append(torch.empty((T, 2 * KVH, HD), dtype=torch.float8_e4m3fn, device=self.dev))
+                    else:
+                        self.kv_scales[i] = ops.kv_scale_from_absmax(kv_cols)
+                # write the cache (e4m3, static per-head scales) and attend over what was written: one launch
+                _, hat = ops.kv_quant_fp8_readback(kv_cols, self.kv_scales[i], out=self.kv_cache[i])
+                k, v = hat[:, :KVH], hat[:, KVH:]
             a = F.scaled_dot_product_attention(q.transpose(0, 1)[None], k.transpose(0, 1)[None],
                                                v.transpose(0, 1)[None], is_causal=True, enable_gqa=True)[0]
-            hdn = self._lin(by["llm.o_proj"][i], a.transpose(0, 1).reshape(T, LLM_DIM), residual=hdn)
-            gu = self._norm_lin(by["llm.gate_proj"][i], hdn, LLM_DIM)    # fused gate|up GEMM
+            if i == 0:
+                self.attn_first = a            # [heads, T, head_dim] of the first decoder layer (tests)
+            hdn = self._lin(by["llm.o_proj"][i], a.transpose(0, 1).reshape(T, D), residual=hdn)
+            gu = self._norm_lin(by["llm.gate_proj"][i], hdn, D)    # fused gate|up GEMM
             half = gu.shape[1] // 2
             hdn = self._act_lin(by["llm.down_proj"][i], gu[:, :half], gu[:, half:], ops.ACT_SILU_MUL, residual=hdn)
-        last = F.rms_norm(hdn[-1:], (LLM_DIM,), eps=1e-6)
+        last = F.rms_norm(hdn[-1:], (D,), eps=1e-6)
         self.logits = last @ self.lm_head.t()
         return self.logits

@@ -400,6 +400,28 @@ def kv_quant_fp8(kv: torch.Tensor, scale: torch.Tensor, out: torch.Tensor = None
 
 
 @_on_device
+def kv_quant_fp8_readback(kv: torch.Tensor, scale: torch.Tensor, out: torch.Tensor = None,
+                          readback: torch.Tensor = None):
+    """Quantize-on-write with the read-back fused in (``mq_kv_quant_fp8_readback``): returns (cache bytes, the
+    values a later ``kv_dequant_fp8`` of those bytes gives, in kv's dtype).  kv may hold K and V side by side
+    ([T, 2 * kv_heads, head_dim], the K|V columns of the fused q|k|v output) with scale [2 * kv_heads]."""
+    _need_cuda(kv, scale, out, readback)
+    T, H, D = kv.shape
+    assert kv.stride(2) == 1 and kv.stride(1) == D and scale.dtype == torch.float32 and scale.numel() == H
+    if out is None:
+        out = torch.empty((T, H, D), dtype=torch.float8_e4m3fn, device=kv.device)
+    if readback is None:
+        readback = torch.empty((T, H, D), dtype=kv.dtype, device=kv.device)
+    assert out.dtype == torch.float8_e4m3fn and out.stride(2) == 1 and out.stride(1) == D
+    assert readback.dtype == kv.dtype and readback.stride(2) == 1 and readback.stride(1) == D and readback.shape == kv.shape
+    row = H * D
+    call("mq_kv_quant_fp8_readback", kv.data_ptr(), dtype_code(kv.dtype), T, H, D, kv.stride(0) if T > 1 else row,
+         scale.data_ptr(), out.data_ptr(), out.stride(0) if T > 1 else row, readback.data_ptr(),
+         readback.stride(0) if T > 1 else row, _stream())
+    return out, readback
+
+
+@_on_device
 def kv_dequant_fp8(q: torch.Tensor, scale: torch.Tensor, dtype: torch.dtype = torch.float16,
                    out: torch.Tensor = None) -> torch.Tensor:
     """e4m3fn cache [T, kv_heads, head_dim] -> ``dtype`` in front of SDPA (``mq_kv_dequant_fp8``)."""

@@ -108,11 +108,11 @@ def internvl2_8b_specs(batch: int = 1, msq: bool = False) -> List[LinearSpec]:
     ]
 
 
-def qwen2vl_72b_specs(batch: int = 1, msq: bool = True) -> List[LinearSpec]:
+def qwen2vl_72b_specs(batch: int = 1, msq: bool = True, v: int = 32, l: int = 80) -> List[LinearSpec]:
     """BASELINE config 5: Qwen2-VL-72B.  LLM hidden 8192, 80 layers, 64 heads / 8 KV heads, ff 29568 padded to
     30720 (online Hadamard 60 x 512); the ViT of the 7B model with a 5120 -> 5120 -> 8192 merger.  W4 image
     ~35 GB: one full replica per 288 GB GPU."""
-    v, l, mv, ml = 32, 80, M_VIS * batch, M_LLM * batch
+    mv, ml = M_VIS * batch, M_LLM * batch
     return [
         LinearSpec("vis.patch_embed", mv, 1176, 1176, 1280, 1),
         LinearSpec("vis.attn.qkv", mv, 1280, 1280, 3840, v, bias=True),

@@ -94,3 +94,61 @@ def test_attention_with_fp8_kv_stays_near_fp16_sdpa(T):
     assert rel < ATTN_REL_TOL, rel
     cos = float((got * ref).sum() / (got.norm() * ref.norm()))
     assert cos > 0.998, cos
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_write_with_fused_read_back_equals_write_then_read(dtype):
+    """mq_kv_quant_fp8_readback on the K|V columns of a fused q|k|v output (in place, token stride of the wider
+    tensor): cache bytes = the write kernel's = the oracle's, read-back = what the read kernel / the oracle
+    return for those bytes, bit for bit."""
+    from mquant_amd import ops
+    T, H, KVH, D = 37, 6, 2, 64
+    g = torch.Generator(device=DEV).manual_seed(11)
+    qkv = (torch.randn((T, (H + 2 * KVH) * D), generator=g, device=DEV) * 3.0).to(dtype)
+    kv = qkv[:, H * D:].view(T, 2 * KVH, D)                   # K heads then V heads, side by side
+    scale = ops.kv_scale_from_absmax(kv)
+    cache = torch.empty((T + 3, 2 * KVH, D), dtype=torch.float8_e4m3fn, device=DEV)
+    got_q, got_y = ops.kv_quant_fp8_readback(kv, scale, out=cache[3:])
+    want_q = oracle.kv_quant_fp8(kv.float().cpu().numpy(), scale.cpu().numpy())
+    np.testing.assert_array_equal(got_q.view(torch.uint8).cpu().numpy(), want_q)
+    np.testing.assert_array_equal(ops.kv_quant_fp8(kv, scale).view(torch.uint8).cpu().numpy(), want_q)
+    want_y = oracle.kv_dequant_fp8(want_q, scale.cpu().numpy(), MODE[dtype])
+    np.testing.assert_array_equal(got_y.float().cpu().numpy(), want_y)
+    assert torch.equal(got_y, ops.kv_dequant_fp8(got_q, scale, dtype))
+
+
+def test_fp8_kv_cache_wired_into_the_prefill_of_the_72b_geometry():
+    """BASELINE configuration 5 (Qwen2-VL-72B head geometry 64 / 8 / 128; depth cut to 1 ViT block + 2 decoder
+    layers): every decoder layer writes its K|V -- straight out of the fused q|k|v GEMM output, K already rotated
+    -- into the e4m3 cache with calibrated per-head scales and attends over the cache contents read back by the
+    same launch.  PARITY UNPINNED (the reference has no KV-cache quantization): the check is against the same
+    prefill with fp16 K / V.  The first decoder layer sees identical inputs in both runs, so its attention output
+    is held to the tolerance of the attention-level test above (3 mantissa bits = 2.6 % rms per element: relative
+    error <= 6 %, cosine >= 0.998).  The logits only have to stay finite and correlated: the weights are random,
+    such a stack amplifies any perturbation (and flips static int8 levels) layer by layer, which says nothing
+    about a trained model -- profiles/r3_kv_fp8.txt reports the drift at full depth."""
+    from mquant_amd import ops, workload
+    from mquant_amd.full_prefill import QWEN2VL_72B, FullPrefill
+    specs = workload.qwen2vl_72b_specs(v=1, l=2)
+    pf = workload.Prefill(specs, device=DEV, share_groups=True)
+    outs = {}
+    for kv8 in (False, True):
+        fp = FullPrefill(pf, fused_glue=True, geometry=QWEN2VL_72B, kv_fp8=kv8)
+        fp.calibrate()
+        outs[kv8] = (fp.step().float().clone(), fp.attn_first.float().clone())
+        if kv8:
+            assert len(fp.kv_cache) == 2 and fp.kv_cache[0].dtype == torch.float8_e4m3fn
+            assert fp.kv_cache[0].shape == (768, 16, 128) and fp.kv_scales[0].shape == (16,)
+            assert fp.kv_cache_bytes() * 2 == FullPrefill(pf, geometry=QWEN2VL_72B).kv_cache_bytes()
+            # the bytes in the cache decode to finite values inside the calibrated range of every head
+            y = ops.kv_dequant_fp8(fp.kv_cache[1], fp.kv_scales[1], torch.float16).float()
+            assert torch.isfinite(y).all()
+            assert bool((y.abs().amax(dim=(0, 2)) <= fp.kv_scales[1] * 448.0 * 1.001).all())
+        fp.restore_hot_path_scales()
+    (la, aa), (lb, ab) = outs[False], outs[True]
+    assert torch.isfinite(la).all() and torch.isfinite(lb).all()
+    rel = float((aa - ab).norm() / aa.norm())
+    cos = float(torch.nn.functional.cosine_similarity(aa.flatten(), ab.flatten(), dim=0))
+    assert rel <= 0.06 and cos >= 0.998, (rel, cos)
+    lcos = float(torch.nn.functional.cosine_similarity(la.flatten(), lb.flatten(), dim=0))
+    assert lcos > 0.9, lcos

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""fp8 KV cache wired into the whole synthetic prefill (BASELINE configuration 5): TTFT and KV bytes
+with and without, Qwen2-VL-72B geometry (80 layers, 64 / 8 / 128) and the 7B benchmark model.  Parity unpinned
+(the reference has no KV-cache quantization).  Output -> profiles/r3_kv_fp8.txt."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+torch.set_grad_enabled(False)
+from mquant_amd import workload  # noqa: E402
+from mquant_amd.full_prefill import QWEN2VL_7B, QWEN2VL_72B, FullPrefill  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def ttft(fp, iters=30):
+    fp.step()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fp.step()
+    for _ in range(5):
+        g.replay()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2], fp.logits.float().clone()
+
+
+which = sys.argv[1:] or ["7b", "72b"]
+for name in which:
+    specs, geo = (workload.qwen2vl_7b_specs(msq=True), QWEN2VL_7B) if name == "7b" else (workload.qwen2vl_72b_specs(), QWEN2VL_72B)
+    pf = workload.Prefill(specs, device=dev, share_groups=True)
+    res = {}
+    for kv8 in (False, True):
+        fp = FullPrefill(pf, fused_glue=True, geometry=geo, kv_fp8=kv8)
+        fp.calibrate()
+        ms, logits = ttft(fp)
+        res[kv8] = (ms, fp.kv_cache_bytes(), logits)
+        fp.restore_hot_path_scales()
+        del fp
+        torch.cuda.empty_cache()
+    (m0, b0, l0), (m1, b1, l1) = res[False], res[True]
+    rel = float((l0 - l1).norm() / l0.norm())
+    cos = float(torch.nn.functional.cosine_similarity(l0.flatten(), l1.flatten(), dim=0))
+    layers = sum(sp.count for sp in specs if sp.name == "llm.q_proj")
+    print(f"Qwen2-VL-{name.upper()} whole synthetic prefill (1 x 448^2 image + 512 tokens, {layers} decoder layers, hipGraph replay, median of 30):")
+    print(f"  fp16 K/V             : TTFT {m0:8.3f} ms   KV bytes written {b0 / 1e6:8.2f} MB")
+    print(f"  fp8 (e4m3) KV cache  : TTFT {m1:8.3f} ms   KV bytes written {b1 / 1e6:8.2f} MB   (+{(m1 - m0) * 1e3 / layers:.1f} us per layer: one "
+          f"mq_kv_quant_fp8_readback launch; the attention reads the cache contents)")
+    print(f"  last-token logits, fp8 vs fp16 K/V: relative error {rel:.4f}, cosine {cos:.5f}")
+    del pf
+    torch.cuda.empty_cache()
