@@ -424,11 +424,21 @@ class ActQuantWrapper(torch.nn.Module):
     def _dynamic_real_ok(self, x_dtype=torch.float32) -> bool:
         """Dynamic per-token int8 (the reference's default activation mode, quant_utils.py:205-268) also
         has real-integer kernels: symmetric, and asymmetric (``--a_asym``) when the wrapper is not split
-        (the zero point travels through the same rank-1 epilogue term as the split column); per token or
-        per tensor (``act_per_tensor``).  Group-wise scales stay on the simulated path."""
+        (the zero point travels through the same rank-1 epilogue term as the split column); per token,
+        per tensor (``act_per_tensor``) or group-wise (``groupsize``: symmetric, groups of 64 / 128 / 256 ... channels)."""
         qz = self.quantizer
-        if not (2 <= qz.bits <= 8) or getattr(qz, "groupsize", -1) > 0:
+        if not (2 <= qz.bits <= 8):
             return False
+        g = getattr(qz, "groupsize", -1)
+        if g > 0 and not getattr(qz, "act_per_tensor", False):
+            # group-wise scales: symmetric levels, a group = 64 or a multiple of 128 consecutive channels (the k-steps of
+            # the GEMM), whole groups in the (padded) input width, no split column (the reference's reshape of the
+            # K - 1 quantized columns fails there too) and symmetric weights (no rank-1 epilogue term in this kernel)
+            name, wmod = self._weight_module()
+            wq = self.weight_quantizers.get(name)
+            width = wmod.weight.shape[1] if wmod.weight.dim() == 2 else 0
+            return (bool(getattr(qz, "sym", False)) and not self.split and (g == 64 or g % 128 == 0) and g <= 1024
+                    and (g & (g - 1)) == 0 and width > 0 and width % g == 0 and wq is not None and bool(getattr(wq, "sym", False)))
         if getattr(qz, "act_per_tensor", False) and x_dtype != torch.float32:
             # the reference keeps the per-tensor range, scale, zero point AND x / scale in x's dtype
             # (quant_utils.py:214-231: ``torch.tensor(0).to(x)``, ``xmax / self.maxq``): on half / bf16
@@ -492,7 +502,8 @@ class ActQuantWrapper(torch.nn.Module):
                 s1 = float(qz.quantizer_text.scale) if qz.quantizer_text.scale is not None else s0
         else:
             dynamic = dict(bits=int(qz.bits), clip_ratio=float(qz.clip_ratio), sym=bool(qz.sym),
-                           per_tensor=bool(qz.act_per_tensor))
+                           per_tensor=bool(qz.act_per_tensor),
+                           groupsize=(int(qz.groupsize) if getattr(qz, "groupsize", -1) > 0 and not qz.act_per_tensor else -1))
         return dict(levels=levels, scale=scale, bits=wq.bits,
                     bias=None if bias is None else bias.data.to(device), s0=s0, s1=s1,
                     had=had, w0=w0, dynamic=dynamic, w_shift=w_shift)

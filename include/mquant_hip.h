@@ -379,6 +379,23 @@ int mq_gemm_w4a8_i32_ws(const int8_t *a, long lda, const void *w, int w_bits,
                         long M, long N, long K_pad, int32_t *acc, long ldacc,
                         void *workspace, size_t workspace_bytes, void *stream);
 
+/* Dynamic GROUP-WISE activation quantizer (--a_groupsize g; ActQuantizer.find_params_per_token_groupwise,
+ * quant_utils.py:181-203, + sym_quant :46-50), symmetric: one scale per row and group of g consecutive channels,
+ * scale = max(|amin * clip|, amax * clip) / maxq (1 for an all-zero group), no zero inclusion, every intermediate
+ * rounded to x_dtype exactly like the reference's tensors of that dtype.  g: a power of two in 16..1024 dividing K;
+ * K_pad must hold whole groups.  scales_out: fp32 [M, K / g].  out as for mq_quantize_act_i8 (row-major or tiled). */
+int mq_quantize_act_group_i8(const void *x, int x_dtype, long M, long K, long ldx, int groupsize, int bits,
+                             float clip_ratio, float *scales_out, int8_t *out, long K_pad, long ldo, void *stream);
+
+/* The GEMM for group-wise activation scales: y[m][n] = (sum_g (float(acc_g[m][n]) * s_x_groups[m][g])) * s_w[n] + bias[n],
+ * acc_g = the exact int32 sum over the group's k, groups added in ascending order in fp32 (one rounding per group).
+ * Replaces F.linear on the group-wise fake-quantized activations (quant_utils.py:384 after :181-203; the reference
+ * accumulates s * q products in floating point in library order: outputs agree to the 1e-3 of the other modes).
+ * group_k: 64 or a multiple of 128; n_groups * group_k covers K_pad up to its zero padding. */
+int mq_gemm_w4a8_groupscale(const int8_t *a, long lda, const void *w, int w_bits, long M, long N, long K_pad,
+                            const float *s_x_groups, long n_groups, int group_k, const float *s_w,
+                            const float *bias, void *out, int out_dtype, long ldo, void *stream);
+
 /* Scaled row sums of the int8 activation levels, for ASYMMETRIC weights (--w_asym; WeightQuantizer with
  * sym = False, quant_utils.py:446-509).  With the weight levels stored as q - 2^(b-1) the fake-quantized
  * weight is s_w[n] (stored + 2^(b-1) - z_w[n]); the zero points come back through the rank-1 epilogue term

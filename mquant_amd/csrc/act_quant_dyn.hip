@@ -251,3 +251,116 @@ extern "C" int mq_quantize_act_range_i8(const void *x, int x_dtype, long M, long
 #undef MQ_DQ_LAUNCH
     return check_launch("quantize_act_range_i8");
 }
+
+/* Dynamic symmetric GROUP-WISE quantizer (--a_groupsize g; quant_utils.py:181-203 + sym_quant :46-50): one scale
+ * per row and group of g consecutive channels,
+ *     xmax = amax * clip; xmin = amin * clip (no zero inclusion); xmax = max(|xmin|, xmax)
+ *     scale = xmax / maxq, 1 where xmax == 0;    q = clamp(rint(x / scale), -(maxq+1), maxq)
+ * with every intermediate rounded to x's dtype like the reference's tensors of that dtype (amax * clip, the quotient
+ * by maxq and x / scale are half tensors for a half model).  A thread owns 16 consecutive channels, the g / 16 lanes
+ * of a group sit side by side in one wave and combine their extrema with shuffles.  scale_out: fp32 [M, K / g]. */
+namespace mq {
+
+struct GqArgs {
+    const void *x;
+    long M, K, ldx;
+    int lanes_per_group;           // g / 16: 1 .. 64, a power of two
+    float clip, maxq;
+    float *scale_out;
+    long n_groups;
+    int8_t *out;
+    long K_pad, ldo;
+    int vec_ok;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void act_quant_group_kernel(GqArgs p)
+{
+    typedef typename Elem<DT>::T T;
+    const long cpr = p.K_pad / 16;                                  // 16-channel chunks per row (a multiple of lanes_per_group)
+    const long total = p.M * cpr;
+    const long span = ((total + 63) / 64) * 64;                    // whole waves: every lane takes part in the shuffles
+    for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < span; c += (long)gridDim.x * 256) {
+        const bool live = c < total;
+        const long cc = live ? c : total - 1;
+        const long row = cc / cpr;
+        const long col = (cc - row * cpr) * 16;
+        const T *xr = reinterpret_cast<const T *>(p.x) + row * p.ldx + col;
+        float v[16];
+        if (col + 16 <= p.K && p.vec_ok) {
+            if (sizeof(T) == 2) {
+                const v8us a = *reinterpret_cast<const v8us *>(xr);
+                const v8us b = *reinterpret_cast<const v8us *>(xr + 8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { v[i] = Elem<DT>::ld((T)a[i]); v[8 + i] = Elem<DT>::ld((T)b[i]); }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const v4f a = *reinterpret_cast<const v4f *>((const float *)xr + 4 * j);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[4 * j + i] = a[i];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = (col + i < p.K) ? Elem<DT>::ld(xr[i]) : 0.0f;
+        }
+        float mn = v[0], mx = v[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) { mn = fminf(mn, v[i]); mx = fmaxf(mx, v[i]); }
+        for (int st = 1; st < p.lanes_per_group; st <<= 1) {
+            mn = fminf(mn, __shfl_xor(mn, st, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, st, 64));
+        }
+        const float xmin = Elem<DT>::rnd(mn * p.clip), xmax0 = Elem<DT>::rnd(mx * p.clip);
+        const float xmax = fmaxf(fabsf(xmin), xmax0);
+        const float s = (xmax == 0.0f) ? 1.0f : Elem<DT>::rnd(xmax / p.maxq);
+        if (!live) continue;
+        const long chunk = cc - row * cpr;
+        if ((chunk % p.lanes_per_group) == 0 && col < p.K) p.scale_out[row * p.n_groups + chunk / p.lanes_per_group] = s;
+        int q[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float t = rintf(Elem<DT>::rnd(v[i] / s));
+            t = fminf(fmaxf(t, -(p.maxq + 1.0f)), p.maxq);
+            q[i] = (col + i < p.K) ? (int)t : 0;
+        }
+        v4i pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            pk[j] = (q[4 * j] & 0xff) | ((q[4 * j + 1] & 0xff) << 8) | ((q[4 * j + 2] & 0xff) << 16) | ((q[4 * j + 3] & 0xff) << 24);
+        *reinterpret_cast<v4i *>(p.out + act_offset(row, col, p.K_pad, p.ldo)) = pk;
+    }
+}
+
+}  // namespace mq
+
+extern "C" int mq_quantize_act_group_i8(const void *x, int x_dtype, long M, long K, long ldx, int groupsize, int bits,
+                                        float clip_ratio, float *scale_out, int8_t *out, long K_pad, long ldo, void *stream)
+{
+    using namespace mq;
+    if (M == 0) return MQ_OK;
+    MQ_REQUIRE(x && out && scale_out && M >= 0 && K > 0 && ldx >= K, "mq_quantize_act_group_i8: bad shape");
+    MQ_REQUIRE(bits >= 2 && bits <= 8, "mq_quantize_act_group_i8: bits must be 2..8");
+    MQ_REQUIRE(groupsize >= 16 && groupsize <= 1024 && (groupsize & (groupsize - 1)) == 0 && K % groupsize == 0,
+               "mq_quantize_act_group_i8: groupsize=%d must be a power of two in 16..1024 that divides K=%ld", groupsize, K);
+    MQ_REQUIRE(K_pad >= K && K_pad % 16 == 0 && (K_pad / 16) % (groupsize / 16) == 0 && ((uintptr_t)out) % 16 == 0 &&
+                   (ldo == MQ_LD_TILED ? K_pad % 64 == 0 : (ldo >= K_pad && ldo % 16 == 0)),
+               "mq_quantize_act_group_i8: bad K_pad / ldo / alignment (K_pad must hold whole groups)");
+    GqArgs p;
+    p.x = x; p.M = M; p.K = K; p.ldx = ldx; p.lanes_per_group = groupsize / 16; p.clip = clip_ratio;
+    p.maxq = (float)((1 << (bits - 1)) - 1);
+    p.scale_out = scale_out; p.n_groups = K / groupsize; p.out = out; p.K_pad = K_pad; p.ldo = ldo;
+    const size_t esz = (x_dtype == MQ_F32) ? 4 : 2;
+    p.vec_ok = (((uintptr_t)x) % 16 == 0) && ((ldx * esz) % 16 == 0);
+    long blocks = ceil_div(M * (K_pad / 16), 256);
+    if (blocks > 256L * 16) blocks = 256L * 16;
+    hipStream_t st = (hipStream_t)stream;
+    switch (x_dtype) {
+    case MQ_F16: hipLaunchKernelGGL(act_quant_group_kernel<MQ_F16>, dim3((unsigned)blocks), dim3(256), 0, st, p); break;
+    case MQ_BF16: hipLaunchKernelGGL(act_quant_group_kernel<MQ_BF16>, dim3((unsigned)blocks), dim3(256), 0, st, p); break;
+    case MQ_F32: hipLaunchKernelGGL(act_quant_group_kernel<MQ_F32>, dim3((unsigned)blocks), dim3(256), 0, st, p); break;
+    default: return fail(MQ_EINVAL, "mq_quantize_act_group_i8: unknown dtype %d", x_dtype);
+    }
+    return check_launch("quantize_act_group_i8");
+}

@@ -41,6 +41,13 @@ struct GemmArgs {
     float sx0, sx1;
     const uint8_t *row_sel;
     const float *sx_vec = nullptr;   // per-row activation scales (dynamic per-token quantizer); overrides sx0/sx1
+    // group-wise activation scales (--a_groupsize, quant_utils.py:181-203): sx_groups[m * n_groups + g], one group =
+    // group_k consecutive k (64 or a multiple of 128).  The grouped kernel folds them into fp32 accumulators group by
+    // group; the epilogue then receives FLOAT bits in the accumulator registers (acc_float) and skips the row scale.
+    const float *sx_groups = nullptr;
+    long n_groups = 0;
+    int group_k = 0;
+    int acc_float = 0;
     const void *residual = nullptr;  // [M, ldr] in the output dtype: out = cast(cast(y) + residual)
     long ldr = 0;
     const float *s_w, *bias, *x0, *w0;
@@ -304,7 +311,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][
             }
             // int4 weights: the accumulator carries a factor 16; float(16 a) * (s_x / 16) is the same real
             // product as float(a) * s_x (exact power-of-two rescale on both sides): same bits, no shift
-            const float sx = (W_BITS == 4) ? rowpar[row * 2] * 0.0625f : rowpar[row * 2];
+            const float sx = p.acc_float ? 1.0f : ((W_BITS == 4) ? rowpar[row * 2] * 0.0625f : rowpar[row * 2]);
             const float xz = rowpar[row * 2 + 1];
             float res[8];
             if (p.residual) {   // issued ahead of the arithmetic below
@@ -333,8 +340,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][
             const v2f sx2 = v2f{sx, sx}, xz2 = v2f{xz, xz};
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
-                v2f t = v2f{(float)a[e], (float)a[e + 1]};
-                t = t * sx2;
+                v2f t = p.acc_float ? v2f{__int_as_float(a[e]), __int_as_float(a[e + 1])} : v2f{(float)a[e], (float)a[e + 1]};
+                if (!p.acc_float) t = t * sx2;
                 t = t * v2f{swv[e], swv[e + 1]};
                 if (p.bias) t = t + v2f{bsv[e], bsv[e + 1]};
                 if (p.x0) {

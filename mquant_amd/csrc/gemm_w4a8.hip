@@ -33,7 +33,10 @@ namespace mq {
 template <int W_BITS, int EPI>
 int dispatch_ws(const GemmArgs &p, int tile, hipStream_t st);   // gemm_ws.hip (tiled activations only)
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int W_BITS, int EPI, int DMA_POS>
+// GROUPED (--a_groupsize): the int32 accumulators of one activation group (64 or a multiple of 128 k) are scaled by
+// the group's activation scale of their row and added to fp32 accumulators in ascending group order; the epilogue
+// gets the float bits (GemmArgs::acc_float).  Exact integers inside a group, one fp32 rounding per group and row.
+template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int W_BITS, int EPI, int DMA_POS, bool GROUPED = false>
 __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmArgs p)
 {
     constexpr int NWAVES = WARPS_M * WARPS_N;
@@ -113,10 +116,34 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
     };
 
     v4i acc[TN][TM];
+    v4f facc[GROUPED ? TN : 1][GROUPED ? TM : 1];
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+        for (int j = 0; j < TM; ++j) {
+            acc[i][j] = v4i{0, 0, 0, 0};
+            if (GROUPED) facc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+        }
+    // D layout: column (lane & 15) = activation row, so a lane needs ONE group scale per row tile
+    auto fold_group = [&](long gi) {
+        if (gi >= p.n_groups) gi = p.n_groups - 1;         // zero-padded tail of K_pad: the accumulators are 0 there
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            long row = m0 + (wm * TM + j) * 16 + (lane & 15);
+            if (row >= p.M) row = p.M - 1;
+            float sg = p.sx_groups[row * p.n_groups + gi];
+            if (W_BITS == 4) sg = sg * 0.0625f;                // the int4 levels sit in the high nibble: exact rescale
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float t = (float)acc[i][j][r] * sg;
+                    facc[GROUPED ? i : 0][GROUPED ? j : 0][r] = facc[GROUPED ? i : 0][GROUPED ? j : 0][r] + t;
+                }
+                acc[i][j] = v4i{0, 0, 0, 0};
+            }
+        }
+    };
 
     // ---- main loop ------------------------------------------------------------------------
 #pragma unroll
@@ -177,8 +204,22 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
                 for (int j = 0; j < TM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf, xf[j], acc[i][j], 0, 0, 0);
             }
+            if (GROUPED && p.group_k == 64) fold_group((k_begin + it) * 2 + kt);
+        }
+        if (GROUPED && p.group_k >= 128) {
+            const long kstep = k_begin + it + 1;                       // k-steps done, in units of 128
+            const int per = p.group_k >> 7;
+            if (kstep % per == 0 || it + 1 == nk) fold_group((kstep - 1) / per);
         }
         if (++cur == STAGES) cur = 0;
+    }
+    if (GROUPED) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = __float_as_int(facc[GROUPED ? i : 0][GROUPED ? j : 0][r]);
     }
 
     if (MQ_EXP == 4) {   // timing experiment: everything but the epilogue
@@ -411,12 +452,12 @@ static int launch_gemm_pipe(const GemmArgs &p, hipStream_t st)
     return check_launch("splitk_reduce");
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int W_BITS, int EPI, int DMA_POS = 1>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int W_BITS, int EPI, int DMA_POS = 1, bool GROUPED = false>
 static int launch_gemm(const GemmArgs &p, hipStream_t st)
 {
     constexpr int PIECES = (BM / 16) * 2 + ((W_BITS == 4) ? (BN / 16) : (BN / 16) * 2);
     constexpr int SMEM = STAGES * PIECES * 1024;
-    auto kern = gemm_w4a8_kernel<BM, BN, WARPS_M, WARPS_N, STAGES, W_BITS, EPI, DMA_POS>;
+    auto kern = gemm_w4a8_kernel<BM, BN, WARPS_M, WARPS_N, STAGES, W_BITS, EPI, DMA_POS, GROUPED>;
     {
         const int rc = ensure_dynamic_lds((const void *)kern, SMEM);
         if (rc != MQ_OK) return rc;
@@ -541,7 +582,7 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
                        const float *s_w, const float *bias, const float *x0, const float *w0,
                        void *out, int epi, long ldo, void *workspace, size_t workspace_bytes,
                        void *stream, const float *sx_vec = nullptr, const void *residual = nullptr,
-                       long ldr = 0)
+                       long ldr = 0, const float *sx_groups = nullptr, long n_groups = 0, int group_k = 0)
 {
     MQ_REQUIRE(M >= 0 && N >= 0 && K_pad >= 0, "mq_gemm_w4a8: negative shape");
     if (M == 0 || N == 0) return MQ_OK;
@@ -568,6 +609,29 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
     MQ_REQUIRE(!residual || (epi != EPI_I32 && ldr >= N), "mq_gemm_w4a8: bad residual geometry");
     p.res_vec = residual && (((uintptr_t)residual) % 16 == 0) && ((ldr * ((epi == EPI_F32) ? 4 : 2)) % 16 == 0);
     p.out = out; p.ldo = ldo;
+    if (sx_groups) {
+        // group-wise activation scales: the symmetric 128 x 128 kernel, no split-K, floating-point outputs only
+        MQ_REQUIRE(epi != EPI_I32 && group_k > 0 && (group_k == 64 || group_k % 128 == 0) && K_pad % 64 == 0 && !sx_vec,
+                   "mq_gemm_w4a8_groupscale: group size %d (64 or a multiple of 128)", group_k);
+        p.sx_groups = sx_groups; p.n_groups = n_groups; p.group_k = group_k; p.acc_float = 1;
+        p.splits = 1; p.partial = nullptr;
+        p.vec_ok = (N % 8 == 0) && (ldo % 8 == 0) && (((uintptr_t)out) % 16 == 0);
+        auto al = [](const void *q) { return q == nullptr || ((uintptr_t)q) % 16 == 0; };
+        p.par_ok = al(s_w) && al(bias) && al(w0);
+        hipStream_t gst = (hipStream_t)stream;
+        if (w_bits == 4) {
+            switch (epi) {
+            case EPI_F16: return launch_gemm<128, 128, 2, 4, 3, 4, EPI_F16, 1, true>(p, gst);
+            case EPI_BF16: return launch_gemm<128, 128, 2, 4, 3, 4, EPI_BF16, 1, true>(p, gst);
+            default: return launch_gemm<128, 128, 2, 4, 3, 4, EPI_F32, 1, true>(p, gst);
+            }
+        }
+        switch (epi) {
+        case EPI_F16: return launch_gemm<128, 128, 2, 4, 3, 8, EPI_F16, 1, true>(p, gst);
+        case EPI_BF16: return launch_gemm<128, 128, 2, 4, 3, 8, EPI_BF16, 1, true>(p, gst);
+        default: return launch_gemm<128, 128, 2, 4, 3, 8, EPI_F32, 1, true>(p, gst);
+        }
+    }
     const Plan pl = make_plan(M, N, K_pad, workspace != nullptr, workspace_bytes, g_force_tile,
                               workspace ? g_force_splits : 0, w_bits == 4, a_tiled);
     p.splits = pl.splits;
@@ -648,6 +712,20 @@ extern "C" int mq_gemm_w4a8_rowscale_ws(const int8_t *a, long lda, const void *w
     if (!s_x_rows) return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_rowscale_ws: s_x_rows is required");
     return mq::gemm_common(a, lda, w, w_bits, M, N, K_pad, 1.0f, 1.0f, nullptr, s_w, bias, x0, w0,
                            out, out_dtype, ldo, workspace, workspace_bytes, stream, s_x_rows);
+}
+
+extern "C" int mq_gemm_w4a8_groupscale(const int8_t *a, long lda, const void *w, int w_bits, long M, long N,
+                                       long K_pad, const float *s_x_groups, long n_groups, int group_k, const float *s_w,
+                                       const float *bias, void *out, int out_dtype, long ldo, void *stream)
+{
+    if (out_dtype != MQ_F16 && out_dtype != MQ_BF16 && out_dtype != MQ_F32)
+        return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_groupscale: unknown output dtype %d", out_dtype);
+    if (M == 0 || N == 0) return MQ_OK;
+    if (!s_x_groups || n_groups <= 0) return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_groupscale: s_x_groups is required");
+    if ((long)group_k * n_groups > K_pad || (long)group_k * n_groups + 127 < K_pad)
+        return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_groupscale: %ld groups of %d do not cover K_pad=%ld", n_groups, group_k, K_pad);
+    return mq::gemm_common(a, lda, w, w_bits, M, N, K_pad, 1.0f, 1.0f, nullptr, s_w, bias, nullptr, nullptr,
+                           out, out_dtype, ldo, nullptr, 0, stream, nullptr, nullptr, 0, s_x_groups, n_groups, group_k);
 }
 
 extern "C" int mq_gemm_w4a8_i32(const int8_t *a, long lda, const void *w, int w_bits, long M,

@@ -173,6 +173,12 @@ class W4A8Linear:
         if self.had is not None:
             x2 = ops.hadamard(x2, self.had.n, self.had.K, self.had.bits, self.had.fp32_had)
         a = WORKSPACE.act(x2.device, x2.shape[0], self.K_pad)
+        g = int(self.dynamic.get("groupsize", -1) or -1)
+        if g > 0:
+            # group-wise scales (--a_groupsize): exact int32 sums inside a group, fp32 across groups
+            a, s_groups = ops.quantize_act_group_i8(x2, g, self.dynamic["bits"], self.dynamic["clip_ratio"], out=a)
+            return ops.gemm_w4a8_groupscale(a, self.w_img, self.w_bits, self.N, s_groups, g, self.s_w, bias=self.bias,
+                                            out_dtype=x2.dtype, out=out)
         if self.dynamic.get("per_tensor", False):
             asym = self.w_colsum is not None
             a, s_rows, _, shift, x0 = ops.quantize_act_tensor_i8(x2, self.dynamic["bits"], self.dynamic["clip_ratio"],

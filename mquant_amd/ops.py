@@ -522,6 +522,38 @@ def quantize_act_dyn_i8(x: torch.Tensor, bits: int = 8, clip_ratio: float = 1.0,
 
 
 @_on_device
+def quantize_act_group_i8(x: torch.Tensor, groupsize: int, bits: int = 8, clip_ratio: float = 1.0, *, out=None,
+                          tiled: bool = False):
+    """Dynamic symmetric GROUP-WISE quantizer (``--a_groupsize``; reference quant_utils.py:181-203), every
+    intermediate in x's dtype like the reference.  Returns (int8 [M, ceil128(K)], scales fp32 [M, K / groupsize])."""
+    x2 = _rows(x)
+    _need_cuda(x2, out)
+    M, K = x2.shape
+    out, optr, K_pad, ldo = _out_act(out, tiled, M, ceil_to(K, 128), x.device)
+    scales = torch.empty((M, K // groupsize), dtype=torch.float32, device=x.device)
+    call("mq_quantize_act_group_i8", x2.data_ptr(), dtype_code(x2.dtype), M, K, x2.stride(0), int(groupsize), int(bits),
+         float(clip_ratio), scales.data_ptr(), optr, K_pad, ldo, _stream())
+    return out, scales
+
+
+@_on_device
+def gemm_w4a8_groupscale(a, w_img: torch.Tensor, w_bits: int, N: int, s_groups: torch.Tensor, group_k: int,
+                         s_w: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
+                         out_dtype: torch.dtype = torch.float16, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = (sum_g float(acc_g) * s_groups[m][g]) * s_w[n] + bias[n] (``mq_gemm_w4a8_groupscale``): exact int32 sums
+    inside a group of ``group_k`` consecutive k, fp32 across groups in ascending order."""
+    _need_cuda(a, w_img, s_groups, s_w, bias, out)
+    aptr, lda, M, K_pad = _a_args(a)
+    assert s_groups.dtype == torch.float32 and s_groups.is_contiguous() and s_groups.shape[0] == M
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=w_img.device)
+    call("mq_gemm_w4a8_groupscale", aptr, lda, w_img.data_ptr(), w_bits, M, N, K_pad, s_groups.data_ptr(),
+         s_groups.shape[1], int(group_k), s_w.data_ptr(), _ptr(bias), out.data_ptr(), dtype_code(out.dtype),
+         out.stride(0), _stream())
+    return out
+
+
+@_on_device
 def quantize_act_dyn_asym_i8(x: torch.Tensor, bits: int = 8, clip_ratio: float = 1.0, *, out=None, tiled: bool = False):
     """Dynamic ASYMMETRIC per-token quantizer (``--a_asym``).  Returns (stored int8 levels q - 2^(bits-1)
     [M, ceil128(K)], scale [M], zero [M], shift [M] = scale * (2^(bits-1) - zero)); dequantised value =

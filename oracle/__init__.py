@@ -222,6 +222,18 @@ def quant_dyn(x, bits=8, clip=1.0, skip_col0=False):
     return q, scale
 
 
+def quant_group(x, groupsize, bits=8, clip=1.0, mode=0):
+    """quant_utils.py:181-203: (levels int8 [rows, cols], scales fp32 [rows, cols / groupsize]); mode = dtype of x."""
+    x = _f32(x)
+    rows, cols = x.shape
+    assert cols % groupsize == 0
+    q = np.empty((rows, cols), dtype=np.int8)
+    scale = np.empty((rows, cols // groupsize), dtype=np.float32)
+    lib().orc_quant_group(_p(x, C.c_float), C.c_long(rows), C.c_long(cols), C.c_long(groupsize), C.c_int(bits),
+                          C.c_float(clip), C.c_int(mode), _p(scale, C.c_float), _p(q, C.c_int8))
+    return q, scale
+
+
 def quant_dyn_asym(x, bits=8, clip=1.0):
     """quant_utils.py:239-268 (asymmetric branch): dynamic per-token -> (stored int8 levels q - 2^(bits-1),
     scale, zero, shift = scale * (2^(bits-1) - zero)) per row."""

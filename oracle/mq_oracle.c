@@ -174,6 +174,36 @@ void orc_quant_dyn(const float *x, long rows, long cols, int bits, float clip, i
     }
 }
 
+/* Dynamic symmetric GROUP-WISE quantizer (--a_groupsize g), quant_utils.py:181-203
+ * (find_params_per_token_groupwise) + sym_quant :46-50.  Per row and group of g consecutive channels:
+ *   xmax = amax * clip; xmin = amin * clip        (NO zero inclusion, unlike the per-token rule)
+ *   xmax = max(|xmin|, xmax); scale = xmax / maxq, 1 where xmax == 0;   q = clamp(round(x / scale))
+ * The reference keeps every one of these tensors in x's dtype (amax, the product with the Python float,
+ * the quotient by the int64 maxq tensor, x / scale), torch evaluating each op in fp32 and rounding once:
+ * mode 0 = fp32, 1 = fp16, 2 = bf16 inputs. */
+void orc_quant_group(const float *x, long rows, long cols, long g, int bits, float clip, int mode,
+                     float *scale, int8_t *q)
+{
+    const float maxq = (float)((1 << (bits - 1)) - 1);
+    const long G = cols / g;
+    for (long r = 0; r < rows; ++r)
+        for (long gi = 0; gi < G; ++gi) {
+            const float *h = x + r * cols + gi * g;
+            float mn = h[0], mx = h[0];
+            for (long k = 1; k < g; ++k) { if (h[k] < mn) mn = h[k]; if (h[k] > mx) mx = h[k]; }
+            const float xmin = round_mid(mn * clip, mode), xmax0 = round_mid(mx * clip, mode);
+            const float xmax = fmaxf(fabsf(xmin), xmax0);
+            const float s = (xmax == 0.0f) ? 1.0f : round_mid(xmax / maxq, mode);
+            scale[r * G + gi] = s;
+            for (long k = 0; k < g; ++k) {
+                float v = rintf(round_mid(h[k] / s, mode));
+                if (v < -(maxq + 1.0f)) v = -(maxq + 1.0f);
+                if (v > maxq) v = maxq;
+                q[r * cols + gi * g + k] = (int8_t)v;
+            }
+        }
+}
+
 /* Dynamic ASYMMETRIC per-token quantizer (--a_asym), quant_utils.py:239-268 (else-branch) +
  * asym_quant :27-31, maxq = 2^bits - 1:
  *   xmin = min(min_k x, 0)*clip; xmax = max(max_k x, 0)*clip; both 0 -> (-1, +1)

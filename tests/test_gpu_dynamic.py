@@ -212,7 +212,8 @@ def test_modes_the_kernels_do_not_cover_stay_on_the_simulated_path():
     x = torch.from_numpy(make_x(1, (8, 256))).to(DEV).half()
     # per-tensor ranges on HALF activations: the reference evaluates range, scale and x / scale in half precision
     # (quant_utils.py:214-231); the integer kernels work in fp32, so only fp32 activations take them
-    for kw in (dict(bits=8, sym=False, groupsize=64), dict(bits=8, sym=True, groupsize=128), dict(bits=16),
+    # (symmetric group-wise scales with groups of 64 / 128 / 256 ... now run the integer kernels: tests/test_gpu_groupwise.py)
+    for kw in (dict(bits=8, sym=False, groupsize=64), dict(bits=8, sym=True, groupsize=32), dict(bits=16),
                dict(bits=8, sym=True, act_per_tensor=True), dict(bits=8, sym=False, act_per_tensor=True)):
         wrap = qu.ActQuantWrapper(lin)
         rtn_module(wrap, "l", 4, True, False, [], {})
