@@ -300,10 +300,47 @@ __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
             }
         }
         __syncthreads();
-        if (m > 512 || m < 8) {   // remaining strides through LDS (fp32 staging: HALF_LDS is off)
+        // (co-factors above 512 always stage in fp32: the register block below exists only in those instantiations and
+        //  cannot raise the register count -- and lower the occupancy -- of the half-precision-staging kernels)
+        if (!HALF_LDS && m > 512 && m <= 8192) {
+            // Strides 512 .. m/2: the co-factor row is R = m / 512 chunks whose 512-point transforms are done; what is
+            // left is an R-point butterfly over the elements at the same offset of the R chunks, in the same ascending
+            // stride order.  One thread takes one (k, offset) column through all of it in registers: ONE pass over
+            // LDS (then scale and cast) instead of log2(R) read-modify-write passes plus a scaling pass.
+            const int R = m >> 9;
+            for (long t = tid; t < (n >> 9) / R * 512; t += HAD_THREADS) {
+                const int k = (int)(t >> 9), o = (int)t & 511;
+                float w[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    if (c < R) w[c] = S::ld(*reinterpret_cast<const YT *>(ybase + yoff(k, c * 512 + o)));
+#pragma unroll
+                for (int h = 1; h < 16; h <<= 1) {
+                    if (h >= R) break;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        if ((c & h) == 0 && c + h < R) {
+                            const float a0 = w[c], a1 = w[c + h];
+                            w[c] = a0 + a1;
+                            w[c + h] = a0 - a1;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    if (c < R) {
+                        float v = w[c] * scale;
+                        if (mid_round) v = Elem<DT>::rnd(v);
+                        *reinterpret_cast<YT *>(ybase + yoff(k, c * 512 + o)) = S::st(v);
+                    }
+                }
+            }
+            __syncthreads();
+        } else if (!HALF_LDS && (m > 512 || m < 8)) {   // remaining strides through LDS (fp32 staging: HALF_LDS is off)
             for (long h = (m < 8) ? 1 : 512; h < m; h <<= 1) {
+                const int hs = __builtin_ctzl((unsigned long)h);               // h is a power of two
                 for (long b = tid; b < n / 2; b += HAD_THREADS) {
-                    const long i = (b / h) * 2 * h + (b % h);
+                    const long i = ((b >> hs) << (hs + 1)) + (b & (h - 1));
                     const int k = (int)(i >> mshift), i0 = (int)i & (m - 1);
                     YT *pa = reinterpret_cast<YT *>(ybase + yoff(k, i0));
                     YT *pb = reinterpret_cast<YT *>(ybase + yoff(k, i0 + (int)h));
@@ -324,13 +361,22 @@ __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
         }
 
         // ---------------- B/C: K x K stage, cast, store / quantize -----------------------
-        if (K == 1) {
-            for (long idx = (long)tid * 8; idx < n; idx += HAD_THREADS * 8) {
+        if (UNIT == 0 && K == 1) {
+            if ((n & 3) == 0 && (!QUANT || ((p.ldq & 3) == 0 && (((uintptr_t)p.qout) & 3) == 0))) {
+                for (long idx = (long)tid * 4; idx < n; idx += HAD_THREADS * 4) {
+                    float v4[4];
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    if (idx + i < n)
-                        had_emit1<DT, QUANT>(p, row, idx + i,
-                                             S::ld(*reinterpret_cast<const YT *>(ybase + yoff(0, (int)(idx + i)))), s);
+                    for (int i = 0; i < 4; ++i) v4[i] = S::ld(*reinterpret_cast<const YT *>(ybase + yoff(0, (int)(idx + i))));
+                    had_emit_n<DT, QUANT, 4>(p, row, idx, v4, rs, true, p.qout + act_offset(row, idx, p.K_pad, p.ldq));
+                }
+            } else {
+                for (long idx = (long)tid * 8; idx < n; idx += HAD_THREADS * 8) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (idx + i < n)
+                            had_emit1<DT, QUANT>(p, row, idx + i,
+                                                 S::ld(*reinterpret_cast<const YT *>(ybase + yoff(0, (int)(idx + i)))), s);
+                }
             }
         } else if (UNIT == 5) {
             // prepared descriptor: mask-driven 5 x 2 units (had_kxk_unit), one unit per wave for K = 156, m = 128.
