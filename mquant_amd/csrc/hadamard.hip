@@ -195,6 +195,22 @@ __device__ __forceinline__ void had_kxk_unit(const HadArgs &p, long row, const R
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int j = j0 + jj * 16 + r;
+            if (UG == 2 && QUANT) {
+                // two output rows (r, r + 1) per group of four levels: one quantizer branch and one column-0 test per four
+                if ((r & 1) || j >= K) continue;                   // K % 4 == 0 and j0 % 4 == 0: rows r, r + 1 are both valid or both past K
+                const float v4[4] = {Elem<DT>::rnd(acc[jj][0][r]), Elem<DT>::rnd(acc[jj][1][r]),
+                                     Elem<DT>::rnd(acc[jj][0][r + 1]), Elem<DT>::rnd(acc[jj][1][r + 1])};
+                int q[4];
+                quant_levels<4>(v4, rs.s, rs.inv, rs.rcp, -128.0f, 127.0f, q);
+                if (p.skip_col0 && j == 0 && col0 == 0) {          // (row j = 0, column 0) is flat column 0
+                    if (p.x0_out) p.x0_out[row] = v4[0];
+                    q[0] = 0;
+                }
+                int8_t *o = obase + (jj * 16 + r) * ostride;
+                *reinterpret_cast<unsigned short *>(o) = (unsigned short)((q[0] & 0xff) | ((q[1] & 0xff) << 8));
+                *reinterpret_cast<unsigned short *>(o + ostride) = (unsigned short)((q[2] & 0xff) | ((q[3] & 0xff) << 8));
+                continue;
+            }
             if (j < K) {
                 int8_t *o = obase + (jj * 16 + r) * ostride;
                 if (UG == 4) {

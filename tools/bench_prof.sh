@@ -17,6 +17,21 @@ for r in rows:
     name = n.split("(")[0].replace("void ", "")
     key = (name, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]))
     agg.setdefault(key, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+# one tile shape serves two layer shapes of very different depth (down_proj / o_proj, ViT fc2 / proj): split a key whose
+# durations fall into two clusters (largest relative gap > 1.5x with >= 15 % of the launches on either side)
+split = collections.OrderedDict()
+for (name, blocks), v in agg.items():
+    sv = sorted(v)
+    best, cut = 1.0, None
+    for i in range(max(1, len(sv) * 15 // 100), len(sv) - max(1, len(sv) * 15 // 100)):
+        if sv[i] / sv[i - 1] > best:
+            best, cut = sv[i] / sv[i - 1], i
+    if cut is not None and best > 1.5:
+        split[(name + " [shorter launches]", blocks)] = sv[:cut]
+        split[(name + " [longer launches]", blocks)] = sv[cut:]
+    else:
+        split[(name, blocks)] = v
+agg = split
 tot = sum(sum(v) for v in agg.values())
 with open(sys.argv[1] + "_kernel_stats.csv", "w") as fh:
     fh.write("kernel,workgroups,calls,avg_us,min_us,total_ms,share\n")
