@@ -24,12 +24,6 @@ __device__ __forceinline__ void dma16_s(const char *uniform_base, unsigned lane_
 
 enum { EPI_F16 = MQ_F16, EPI_BF16 = MQ_BF16, EPI_F32 = MQ_F32, EPI_I32 = 3 };
 
-// Experiment switch for bottleneck hunting (never set in the shipped build): 1 = no DMA inside the
-// k-loop (compute side alone), 2 = no LDS reads / MFMA (DMA side alone).
-#ifndef MQ_EXP
-#define MQ_EXP 0
-#endif
-
 struct GemmArgs {
     const int8_t *a;
     long lda;

@@ -148,10 +148,10 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
     // ---- main loop ------------------------------------------------------------------------
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
-        if (MQ_EXP != 5 && s < nk) issue_stage(s, s);
+        if (s < nk) issue_stage(s, s);
 
     int cur = 0;
-    for (int it = 0; it < (MQ_EXP == 5 ? 0 : nk); ++it) {
+    for (int it = 0; it < nk; ++it) {
         // stage `it` has landed when at most the (STAGES-2) younger stages are outstanding
         const int younger = nk - 1 - it;
         if (younger >= STAGES - 2) {
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
         const bool more = it + STAGES - 1 < nk;
         int nxt = cur + STAGES - 1;
         if (nxt >= STAGES) nxt -= STAGES;
-        if (MQ_EXP != 1 && DMA_POS == 0 && more) issue_stage(nxt, it + STAGES - 1);
+        if (DMA_POS == 0 && more) issue_stage(nxt, it + STAGES - 1);
 
         const char *xs = smem + cur * STAGE_BYTES;
         const char *ws = xs + X_BYTES;
@@ -184,9 +184,8 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
             }
             // the DMA of the stage after next is issued behind the first fragment reads, so its
             // issue slots overlap MFMA execution instead of delaying the first MFMA of the step
-            if (MQ_EXP != 1 && DMA_POS == 1 && kt == 0 && more) issue_stage(nxt, it + STAGES - 1);
-            if (MQ_EXP != 1 && DMA_POS == 2 && kt == 1 && more) issue_stage(nxt, it + STAGES - 1);
-            if (MQ_EXP == 2) continue;
+            if (DMA_POS == 1 && kt == 0 && more) issue_stage(nxt, it + STAGES - 1);
+            if (DMA_POS == 2 && kt == 1 && more) issue_stage(nxt, it + STAGES - 1);
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
                 const int nt = wn * TN + i;
@@ -222,15 +221,6 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = __float_as_int(facc[GROUPED ? i : 0][GROUPED ? j : 0][r]);
     }
 
-    if (MQ_EXP == 4) {   // timing experiment: everything but the epilogue
-        int t = 0;
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-            for (int j = 0; j < TM; ++j) t ^= acc[i][j][0] ^ acc[i][j][1] ^ acc[i][j][2] ^ acc[i][j][3];
-        if (t == 0x12345678) reinterpret_cast<int *>(p.out)[0] = t;
-        return;
-    }
     gemm_epilogue<TM, TN, NWAVES, STAGES * STAGE_BYTES, W_BITS, EPI>(p, acc, smem, wave, lane, wm, wn, m0, nt0, split);
 }
 

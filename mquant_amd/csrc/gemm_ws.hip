@@ -24,35 +24,15 @@
 //   math, step it:  B(it+1) | read (it, kt1) | MFMA (it, kt0) | read (it+1, kt0) | MFMA (it, kt1)
 #include "gemm_common.h"
 
-// Debug build only (-DMQ_STAMP): cycle stamps of workgroup 0 (math wave 0: slots 0-7, loader wave 0:
-// slots 8-15) into the split-K workspace, read back by tools/gemm_stamps.py.
-#ifdef MQ_STAMP
-#define MQ_STAMP_AT(i) do { if (blockIdx.x == MQ_STAMP && lane == 0 && (wave == 0 || wave == NM) && p.partial) \
-    reinterpret_cast<long long *>(p.partial)[(wave >= NM ? 8 : 0) + (i)] = (long long)clock64(); } while (0)
-#define MQ_STAMP_T() ((long long)clock64())
-#define MQ_STAMP_ACC(v, t0) do { const long long t1_ = MQ_STAMP_T(); (v) += t1_ - (t0); (t0) = t1_; } while (0)
-#define MQ_STAMP_PUT(i, v) do { if (blockIdx.x == MQ_STAMP && lane == 0 && (wave == 0 || wave == NM) && p.partial) \
-    reinterpret_cast<long long *>(p.partial)[i] = (v); } while (0)
-#else
-#define MQ_STAMP_AT(i) do { } while (0)
-#define MQ_STAMP_T() 0LL
-#define MQ_STAMP_ACC(v, t0) do { } while (0)
-#define MQ_STAMP_PUT(i, v) do { } while (0)
-#endif
-
 namespace mq {
 
-template <int BM, int BN, int MW_M, int MW_N, int KS, int NL, int S, int W_BITS, int EPI>
-__global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(GemmArgs p)
+template <int BM, int BN, int MW_M, int MW_N, int NL, int S, int W_BITS, int EPI>
+__global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmArgs p)
 {
-    // Math waves: MW_M x MW_N wave tiles, times KS "k groups".  A single wave cannot overlap its own
-    // VALU / LDS instructions with its MFMAs (12 MFMAs alone: 0.19 us per k-step, with the 24 unpack
-    // VALU between them: 0.30 us, tools/probes/math_loop.hip), a second wave on the SIMD can.  Small
-    // tiles offer only four 32-wide wave tiles, so with KS = 2 two groups of four waves share them:
-    // group g takes the K = 32 sub-steps of parity g into its own accumulators, the epilogue adds
-    // the two partial sums (integers: exact and order-free).
-    constexpr int NMT = MW_M * MW_N;                // wave tiles
-    constexpr int NM = NMT * KS;                    // math waves
+    // Math waves: MW_M x MW_N wave tiles of (BM / MW_M) x (BN / MW_N), one or two per SIMD.  (A second group of
+    // math waves working the K = 32 sub-steps of the other parity, and wide 96 x 64 / 64 x 64 wave tiles, were
+    // built in round 2, exact, and no faster on any model shape -- DESIGN 4.1; they are not in the tree any more.)
+    constexpr int NM = MW_M * MW_N;                 // math waves
     constexpr int NT = (NM + NL) * 64;              // threads
     constexpr int TM = BM / MW_M / 32;              // 32-row activation fragments per math wave
     constexpr int TN = BN / MW_N / 32;              // 32-channel weight fragments per math wave
@@ -67,11 +47,8 @@ __global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(G
     static_assert(BM % (MW_M * 32) == 0 && BN % (MW_N * 32) == 0, "tile shape");
     static_assert(PIECES % NL == 0, "pieces must divide over the loader waves");
     static_assert(S >= 4 && S <= 8 && (S - 2) * LPW < 64, "ring depth (vmcnt is 6 bits)");
-    static_assert(KS == 1 || KS == 2, "k groups");
     constexpr int BODY = RING > BM * PITCH ? RING : BM * PITCH;   // the epilogue slab reuses the ring (and may exceed it)
-    constexpr bool TWO_SLABS = (KS == 2) && (2 * BM * PITCH <= RING);   // else the k groups are added through one slab
     static_assert(NM * 64 >= BN && NM * 64 >= BM, "parameter prefetch: one thread per channel / row");
-    static_assert(KS == 1 || (W_BITS == 4 ? true : true), "k groups");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *par_sw = reinterpret_cast<float *>(smem + BODY);      // [BN] weight scales
@@ -83,7 +60,6 @@ __global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(G
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    MQ_STAMP_AT(0);
 
     // ---- workgroup -> (split, bn, bm), XCD-aware and bijective (gemm_common.h) ---------------------
     int bm, bn, split, kb, nk;
@@ -99,7 +75,7 @@ __global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(G
     // a dependent MFMA chain only three or four instructions long and every VALU / LDS instruction
     // between two sub-steps would add to it (tools/probes/math_loop.hip: 520 -> 760 cycles per k-step);
     // even and odd sub-steps therefore accumulate into separate sets, added at the end (integers: exact).
-    constexpr int NACC = (KS == 1 && TM * TN < 6) ? 2 : 1;
+    constexpr int NACC = (TM * TN < 6) ? 2 : 1;
     v16i acc[NACC][TN][TM];
 
     if (wave >= NM) {
@@ -150,51 +126,39 @@ __global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(G
             }
         };
         // Ring fill.  The first stages of a launch come from HBM and a CU keeps only so many misses in
-        // flight: issuing the whole ring takes ~4000 cycles (tools/gemm_stamps.py), all of it in front of
+        // flight: issuing the whole ring takes ~4000 cycles (profiles/r2_gemm_phase_stamps.txt), all of it in front of
         // the first MFMA if B(0) waits for it.  Only PRE0 stages go out before B(0); the rest of the ring
         // is filled at most two stages per k-step while the math waves already work (a stage is consumed
         // more slowly than it arrives, so the ring fills up behind them).
-#ifndef MQ_PRE0
-#define MQ_PRE0 3
-#endif
-        constexpr int PRE0 = (MQ_PRE0 > 0 && MQ_PRE0 < S) ? MQ_PRE0 : S;
+        constexpr int PRE0 = 3 < S ? 3 : S;            // measured against 1, 2 and the whole ring (profiles/r3_gemm_ring_prefill_depth.txt)
         const int pre0 = nk < PRE0 ? nk : PRE0;
 #pragma unroll
         for (int s = 0; s < PRE0; ++s)
             if (s < pre0) issue(s, s);
-        MQ_STAMP_AT(1);
         wait_younger(pre0 - 1);                      // stage 0 landed
-        MQ_STAMP_AT(2);
         __builtin_amdgcn_s_barrier();                // B(0)
-        MQ_STAMP_AT(3);
         int last = pre0 - 1;                         // last stage issued
         int slot = pre0 == S ? 0 : pre0;             // slot of stage last + 1
-        long long tw = 0, tb = 0, ti = 0, tt = MQ_STAMP_T();
         for (int it = 0; it < nk; ++it) {
             const int need = it + 1 < nk ? it + 1 : nk - 1;
             const int younger = last - need;
             if (younger == S - 3) MQ_WS_WAIT(S - 3);   // steady state: S-3 stages stay in flight across the barrier
             else wait_younger(younger > 0 ? younger : 0);
             __builtin_amdgcn_s_barrier();            // B(it+1): every math wave has finished step it-1
-            MQ_STAMP_ACC(tb, tt);
-#ifdef MQ_STAMP
-            if (it < 200) MQ_STAMP_PUT(32 + it, tt);   // barrier release times = step boundaries
-#endif
             // stages up to it-1+S fit the ring now
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 if (last + 1 < nk && last + 1 <= it - 1 + S) {
-                    if (MQ_EXP != 6) issue(slot, last + 1);   // MQ_EXP 6: timing experiment, no LDS-DMA inside the k-loop
+                    issue(slot, last + 1);
                     ++last;
                     if (++slot == S) slot = 0;
                 }
             }
         }
-        MQ_STAMP_PUT(16, tw); MQ_STAMP_PUT(17, tb); MQ_STAMP_PUT(18, ti);
         __builtin_amdgcn_s_setprio(0);
     } else {
         // =========================== math waves =============================================
-        const int kg = wave / NMT, wm = (wave % NMT) / MW_N, wn = wave % MW_N;
+        const int wm = wave / MW_N, wn = wave % MW_N;
         // Epilogue parameters: straight-line loads at clamped indices now (no use before the k-loop ends,
         // so B(0) does not wait for these cold misses), selected and parked in LDS after the loop.
         float pr_sw = 0.0f, pr_bs = 0.0f, pr_wz = 0.0f, pr_sx = 0.0f, pr_xz = 0.0f;
@@ -280,16 +244,10 @@ __global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(G
         constexpr int DS_PER_GAP = (N_DS + N_MFMA - 1) / N_MFMA, VALU_PER_GAP = (N_VALU + N_MFMA - 1) / N_MFMA;
         auto substep = [&](int sub, int slot2, int sub2) {       // (slot2, sub2): where sub-step s+2 lives
             __builtin_amdgcn_sched_barrier(0);
-            if (MQ_EXP != 8) {                   // MQ_EXP 8 / 9: timing experiments without the reads / the MFMAs
-                load_x((sub + 2) & 3, slot2, sub2);
-                load_w((sub + 2) & 3, slot2, sub2);
-            }
+            load_x((sub + 2) & 3, slot2, sub2);
+            load_w((sub + 2) & 3, slot2, sub2);
             unpack((sub + 1) & 3, (sub + 1) & 1);
-            if (MQ_EXP != 9) mfmas(sub);
-            else {
-#pragma unroll
-                for (int j = 0; j < TM; ++j) acc[0][0][j][0] += X[sub][j][0] ^ WU[sub & 1][0][j & 3];
-            }
+            mfmas(sub);
 #pragma unroll
             for (int m = 0; m < N_MFMA; ++m) {   // a single wave issues back-to-back LDS reads slowly: spread them
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // MFMA
@@ -298,54 +256,7 @@ __global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(G
             }
             __builtin_amdgcn_sched_barrier(0);
         };
-        MQ_STAMP_AT(1);
         __builtin_amdgcn_s_barrier();                // B(0): stage 0 landed
-        MQ_STAMP_AT(2);
-        if constexpr (KS == 2) {
-            // Group g takes the K = 32 sub-steps g and g + 2 of every stage ("own steps", two per stage,
-            // register set = own step parity).  An own step is TM x TN >= 4 MFMAs (>= 128 cycles of
-            // matrix time), so its fragments are read ONE own step ahead (two sets instead of four: the
-            // wide wave tiles need the registers for accumulators) and the nibbles are unpacked at its
-            // start; the reads of the next own step are spread between the MFMAs.
-            auto own = [&](int set, int slot_n, int sub_n) {
-                __builtin_amdgcn_sched_barrier(0);
-                unpack(set, set);
-                __builtin_amdgcn_sched_barrier(0);
-                load_x(set ^ 1, slot_n, sub_n);
-                load_w(set ^ 1, slot_n, sub_n);
-#pragma unroll
-                for (int i = 0; i < TN; ++i)
-#pragma unroll
-                    for (int j = 0; j < TM; ++j)
-                        acc[0][i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(WU[set][i], X[set][j], acc[0][i][j], 0, 0, 0);
-#ifdef MQ_OWN_INTERLEAVE
-#pragma unroll
-                for (int m = 0; m < N_MFMA; ++m) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, DS_PER_GAP, 0);
-                }
-#else
-                // all reads of the next own step first (their latency runs under this step's MFMAs)
-                __builtin_amdgcn_sched_group_barrier(0x100, N_DS, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, N_MFMA, 0);
-#endif
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            load_x(0, 0, kg);
-            load_w(0, 0, kg);
-            int cur = 0;
-            for (int it = 0; it < nk; ++it) {
-                __builtin_amdgcn_s_barrier();        // B(it+1): stage it+1 landed
-                int nxt = cur + 1;
-                if (nxt == S) nxt = 0;
-                if (it + 1 >= nk) nxt = cur;         // last step: harmless re-reads of a live slot
-                if (MQ_EXP != 7) {
-                    own(0, cur, kg + 2);
-                    own(1, nxt, kg);
-                }
-                cur = nxt;
-            }
-        } else {
         load_x(0, 0, 0);
         load_w(0, 0, 0);
         load_x(1, 0, 1);
@@ -357,13 +268,11 @@ __global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(G
             int nxt = cur + 1;
             if (nxt == S) nxt = 0;
             if (it + 1 >= nk) nxt = cur;             // last step: harmless re-reads of a live slot
-            if (MQ_EXP == 7) { cur = nxt; continue; }   // timing experiment: loaders alone
             substep(0, cur, 2);
             substep(1, cur, 3);
             substep(2, nxt, 0);
             substep(3, nxt, 1);
             cur = nxt;
-        }
         }
         if (NACC == 2) {
 #pragma unroll
@@ -392,48 +301,23 @@ __global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(G
     }
 
     // =========================== epilogue: all waves ==========================================
-    MQ_STAMP_AT(4);
     __syncthreads();                                 // the ring is free: park the raw accumulators
-    MQ_STAMP_AT(5);
     {
         // D layout of the 32x32 form: column (-> row m) = lane & 31, rows (-> channels) 8 q + 4 (lane >> 5) + e
-        const int kg = wave / NMT, wm = (wave % NMT) / MW_N, wn = wave % MW_N;
+        const int wm = wave / MW_N, wn = wave % MW_N;
         const int ml = lane & 31, nh = (lane >> 5) * 4;
-        auto cell = [&](int slab, int i, int j, int q) {
-            return reinterpret_cast<v4i *>(smem + slab * (BM * PITCH) + ((wm * TM + j) * 32 + ml) * PITCH + ((wn * TN + i) * 32 + q * 8 + nh) * 4);
-        };
-        auto park = [&](int slab) {
+        if (wave < NM) {
 #pragma unroll
             for (int j = 0; j < TM; ++j)
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        *cell(slab, i, j, q) = v4i{acc[0][i][j][4 * q], acc[0][i][j][4 * q + 1], acc[0][i][j][4 * q + 2], acc[0][i][j][4 * q + 3]};
-        };
-        if (KS == 2 && !TWO_SLABS) {
-            if (wave < NM && kg == 1) park(0);
-            __syncthreads();
-            if (wave < NM && kg == 0) {
-#pragma unroll
-                for (int j = 0; j < TM; ++j)
-#pragma unroll
-                    for (int i = 0; i < TN; ++i)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const v4i o = *cell(0, i, j, q);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) acc[0][i][j][4 * q + e] += o[e];
-                        }
-            }
-            __syncthreads();
-            if (wave < NM && kg == 0) park(0);
-        } else if (wave < NM) {
-            park(kg);
+                        *reinterpret_cast<v4i *>(smem + ((wm * TM + j) * 32 + ml) * PITCH + ((wn * TN + i) * 32 + q * 8 + nh) * 4) =
+                            v4i{acc[0][i][j][4 * q], acc[0][i][j][4 * q + 1], acc[0][i][j][4 * q + 2], acc[0][i][j][4 * q + 3]};
         }
     }
     __syncthreads();
-    MQ_STAMP_AT(6);
 
     constexpr int LPR = BN / 8;                      // lanes per output row (8 channels per lane)
     constexpr int RPI = NT / LPR;                    // rows per iteration of the whole workgroup
@@ -464,10 +348,6 @@ __global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(G
             const int row = (t * RPI + lrow < BM) ? t * RPI + lrow : BM - 1;
             q0[t] = *reinterpret_cast<const v4i *>(smem + row * PITCH + c8 * 4);
             q1[t] = *reinterpret_cast<const v4i *>(smem + row * PITCH + c8 * 4 + 16);
-            if (TWO_SLABS) {
-                q0[t] += *reinterpret_cast<const v4i *>(smem + BM * PITCH + row * PITCH + c8 * 4);
-                q1[t] += *reinterpret_cast<const v4i *>(smem + BM * PITCH + row * PITCH + c8 * 4 + 16);
-            }
             sxr[t] = par_sx[row];
             xzr[t] = par_xz[row];
         }
@@ -518,7 +398,6 @@ __global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(G
                 *reinterpret_cast<v8us *>(reinterpret_cast<unsigned short *>(p.out) + m * p.ldo + n) = h;
             }
         }
-        MQ_STAMP_AT(7);
         return;
     }
 #pragma unroll 1
@@ -528,10 +407,6 @@ __global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(G
         if (row >= BM || m >= p.M || n >= p.N) continue;
         v4i q0 = *reinterpret_cast<const v4i *>(smem + row * PITCH + c8 * 4);
         v4i q1 = *reinterpret_cast<const v4i *>(smem + row * PITCH + c8 * 4 + 16);
-        if (TWO_SLABS) {    // the two k groups' partial sums
-            q0 += *reinterpret_cast<const v4i *>(smem + BM * PITCH + row * PITCH + c8 * 4);
-            q1 += *reinterpret_cast<const v4i *>(smem + BM * PITCH + row * PITCH + c8 * 4 + 16);
-        }
         int a[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
         if (W_BITS == 4) {
 #pragma unroll
@@ -612,23 +487,22 @@ __global__ __launch_bounds__((MW_M * MW_N * KS + NL) * 64) void gemm_ws_kernel(G
             }
         }
     }
-    MQ_STAMP_AT(7);
 }
 
-template <int BM, int BN, int MW_M, int MW_N, int KS, int NL, int S, int W_BITS, int EPI>
+template <int BM, int BN, int MW_M, int MW_N, int NL, int S, int W_BITS, int EPI>
 static int launch_ws(const GemmArgs &p, hipStream_t st)
 {
     constexpr int PIECES = (BM / 16) * 2 + ((W_BITS == 4) ? (BN / 32) * 2 : (BN / 16) * 2);
     constexpr int RING = S * PIECES * 1024, SLAB = BM * (BN * 4 + 16);
     constexpr int SMEM = (RING > SLAB ? RING : SLAB) + (3 * BN + 2 * BM) * 4;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
-    auto kern = gemm_ws_kernel<BM, BN, MW_M, MW_N, KS, NL, S, W_BITS, EPI>;
+    auto kern = gemm_ws_kernel<BM, BN, MW_M, MW_N, NL, S, W_BITS, EPI>;
     int rc = ensure_dynamic_lds((const void *)kern, SMEM);
     if (rc != MQ_OK) return rc;
     GemmArgs g = p;
     set_geometry(g, BM, BN, 128, W_BITS);
     if (!geometry_in_range(g)) return fail(MQ_EINVAL, "mq_gemm_w4a8: %u x %u x %d workgroups exceed the range of the launch-geometry arithmetic", g.m_blocks, g.n_blocks, g.splits);
-    hipLaunchKernelGGL(kern, dim3(g.m_blocks * g.n_blocks * (unsigned)g.splits), dim3((MW_M * MW_N * KS + NL) * 64), SMEM, st, g);
+    hipLaunchKernelGGL(kern, dim3(g.m_blocks * g.n_blocks * (unsigned)g.splits), dim3((MW_M * MW_N + NL) * 64), SMEM, st, g);
     return check_launch("gemm_ws");
 }
 
@@ -636,38 +510,13 @@ template <int W_BITS, int EPI>
 int dispatch_ws(const GemmArgs &p, int tile, hipStream_t st)
 {
     switch (tile) {
-    // production shapes: one math wave per SIMD (1 x 4 wave tiles) or two (2 x 4), four loader waves
-    case 40: return launch_ws<96, 128, 1, 4, 1, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI>(p, st);
-    case 41: return launch_ws<128, 128, 2, 4, 1, 4, (W_BITS == 4 ? 6 : 4), W_BITS, EPI>(p, st);
+    // one math wave per SIMD (1 x 4 wave tiles) or two (2 x 4), four loader waves
+    case 40: return launch_ws<96, 128, 1, 4, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI>(p, st);
+    case 41: return launch_ws<128, 128, 2, 4, 4, (W_BITS == 4 ? 6 : 4), W_BITS, EPI>(p, st);
     case 42:
-        if constexpr (W_BITS == 4) return launch_ws<192, 128, 2, 4, 1, 4, 4, W_BITS, EPI>(p, st);
+        if constexpr (W_BITS == 4) return launch_ws<192, 128, 2, 4, 4, 4, W_BITS, EPI>(p, st);
         else break;
-    case 43: return launch_ws<64, 128, 1, 4, 1, 4, (W_BITS == 4 ? 8 : 6), W_BITS, EPI>(p, st);
-    // two k groups per wave tile (sub-steps of opposite parity, phases M P M P / P M P M): measured on
-    // par with the above; kept selectable for comparison
-    case 44:
-        if constexpr (W_BITS == 4) return launch_ws<128, 128, 1, 4, 2, 4, 6, W_BITS, EPI>(p, st);
-        else return launch_ws<128, 128, 1, 4, 1, 4, 4, W_BITS, EPI>(p, st);
-    case 45: return launch_ws<96, 128, 1, 4, 2, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI>(p, st);
-    case 46: return launch_ws<64, 128, 1, 4, 2, 4, (W_BITS == 4 ? 8 : 6), W_BITS, EPI>(p, st);
-    // Wide wave tiles (two 32-channel fragments per wave, two k groups): 30-45 % fewer LDS bytes per
-    // MFMA than the 1 x 4 / 2 x 4 arrangements -- and the same time per k-step on every model shape
-    // (the k-step is set by the barrier / LDS-DMA / fragment-read pipeline, not by LDS
-    // bandwidth or MFMA issue alone).  Kept selectable for comparison, exact like the others.
-    case 47: return launch_ws<96, 128, 1, 2, 2, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI>(p, st);
-    case 48:
-        if constexpr (W_BITS == 4) return launch_ws<128, 128, 2, 2, 2, 4, 6, W_BITS, EPI>(p, st);
-        else break;
-    case 49:
-        if constexpr (W_BITS == 4) return launch_ws<192, 128, 2, 2, 2, 4, 4, W_BITS, EPI>(p, st);
-        else break;
-    // the same wave tiles with one k group (four math waves)
-    case 50:
-        if constexpr (W_BITS == 4) return launch_ws<192, 128, 2, 2, 1, 4, 4, W_BITS, EPI>(p, st);
-        else break;
-    case 51:
-        if constexpr (W_BITS == 4) return launch_ws<128, 128, 2, 2, 1, 4, 6, W_BITS, EPI>(p, st);
-        else break;
+    case 43: return launch_ws<64, 128, 1, 4, 4, (W_BITS == 4 ? 8 : 6), W_BITS, EPI>(p, st);
     default: break;
     }
     return fail(MQ_EINVAL, "gemm_ws: unknown tile %d", tile);

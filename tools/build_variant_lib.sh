@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage: tools/build_variant_lib.sh <name> <extra hipcc flags...> -> mquant_amd/libmquant_hip_<name>.so: gemm_ws.hip rebuilt with
-# the flags (e.g. -DMQ_STAMP=8, -DMQ_PRE0=2), every other object from the regular build.  Select with MQUANT_HIP_LIB.
+# the flags, every other object from the regular build.  Select with MQUANT_HIP_LIB.  (How the A/B files under profiles/ were
+# produced while experiment switches existed in the source; today it serves patched working copies of gemm_ws.hip.)
 set -e
 cd "$(dirname "$0")/../mquant_amd/csrc"
 NAME=$1; shift
