@@ -305,6 +305,19 @@ int mq_kv_dequant_fp8(const uint8_t *q, long T, int heads, int head_dim, long ld
 int mq_kv_quant_fp8_readback(const void *kv, int dtype, long T, int heads, int head_dim, long ld,
                              const float *scale, uint8_t *out, long ldo, void *readback, long ldr, void *stream);
 
+/* Prefill attention straight off the e4m3 cache (no reference counterpart -- the reference leaves
+ * attention to the HF model code and never quantizes a cache; parity unpinned, checker = softmax attention over the
+ * dequantised cache).  K and V are read as ONE byte per element and widened inside the kernel; the per-head scales
+ * fold into the score / output scale, so no dequantised copy of the cache ever exists in HBM:
+ *     O[t][h][:] = softmax_k((Q[t][h] . K8[k][g]) * s[g] * softmax_scale) @ V8[k][g] * s[kv_heads + g],  g = h / (heads / kv_heads)
+ * q / out: [T][ld] elements of `dtype` (MQ_F16 / MQ_BF16) with heads * head_dim values per token (ldq lets the Q
+ * columns of a fused q|k|v GEMM output be read in place); kv_cache: [T][ldkv] bytes, per token the K heads then the
+ * V heads (the layout mq_kv_quant_fp8 writes for the K|V columns); kv_scale: [2 * kv_heads] floats.  head_dim == 128;
+ * q / cache rows 16-byte aligned, out rows 8-byte aligned.  causal != 0: key index <= query index. */
+int mq_attn_prefill_fp8kv(const void *q, int dtype, long T, int heads, int kv_heads, int head_dim, long ldq,
+                          const uint8_t *kv_cache, long ldkv, const float *kv_scale, float softmax_scale,
+                          int causal, void *out, long ldo, void *stream);
+
 
 /* ---------------------------------------------------------------------------
  * GPTQ: the column loop of one lazy-batch block, gptq/gptq_utils.py:258-279 (symmetric

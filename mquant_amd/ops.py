@@ -436,6 +436,29 @@ def kv_dequant_fp8(q: torch.Tensor, scale: torch.Tensor, dtype: torch.dtype = to
     return out
 
 
+@_on_device
+def attn_prefill_fp8kv(q: torch.Tensor, kv_cache: torch.Tensor, kv_scale: torch.Tensor, causal: bool = True,
+                       softmax_scale: float = None, out: torch.Tensor = None) -> torch.Tensor:
+    """Prefill attention that reads the e4m3 cache directly (``mq_attn_prefill_fp8kv``): q [T, heads, 128] fp16 /
+    bf16 (may be a column slice of the fused q|k|v output), kv_cache [T, 2 * kv_heads, 128] float8_e4m3fn (K heads
+    then V heads, what ``kv_quant_fp8`` writes for the K|V columns), kv_scale [2 * kv_heads] -> [T, heads * 128]."""
+    _need_cuda(q, kv_cache, kv_scale, out)
+    T, H, D = q.shape
+    T2, H2, D2 = kv_cache.shape
+    assert T2 == T and D2 == D and H2 % 2 == 0 and kv_cache.dtype == torch.float8_e4m3fn
+    assert q.stride(2) == 1 and q.stride(1) == D and kv_cache.stride(2) == 1 and kv_cache.stride(1) == D
+    assert kv_scale.dtype == torch.float32 and kv_scale.numel() == H2 and kv_scale.is_contiguous()
+    if out is None:
+        out = torch.empty((T, H * D), dtype=q.dtype, device=q.device)
+    assert out.dtype == q.dtype and out.shape == (T, H * D) and out.stride(1) == 1
+    if softmax_scale is None:
+        softmax_scale = D ** -0.5
+    call("mq_attn_prefill_fp8kv", q.data_ptr(), dtype_code(q.dtype), T, H, H2 // 2, D, q.stride(0) if T > 1 else H * D,
+         kv_cache.data_ptr(), kv_cache.stride(0) if T > 1 else H2 * D, kv_scale.data_ptr(), float(softmax_scale),
+         1 if causal else 0, out.data_ptr(), out.stride(0) if T > 1 else H * D, _stream())
+    return out
+
+
 def kv_scale_from_absmax(kv: torch.Tensor) -> torch.Tensor:
     """Static per-head scale from calibration activations [T, kv_heads, head_dim]: absmax / 448."""
     return (kv.float().abs().amax(dim=(0, 2)).clamp_min(1e-8) / FP8_E4M3_MAX).contiguous()

@@ -1,0 +1,118 @@
+"""Prefill attention that reads the e4m3 KV cache directly (``mq_attn_prefill_fp8kv``).  The reference
+has no attention kernel and no cache quantizer: PARITY UNPINNED.  The checker restated here is softmax attention in
+float64 over the DEQUANTISED cache (value * per-head scale), which is what dequantise-on-read followed by SDPA
+computes; the kernel multiplies the e4m3 values themselves and folds the scales into the score / output scale, so
+the two differ by floating-point rounding only (P and the output are rounded to q's dtype, accumulation is fp32)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+torch.set_grad_enabled(False)
+
+
+def _case(seed, T, H, HKV, dtype, q_gain=1.0):
+    from mquant_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    D = 128
+    qkv = (torch.randn(T, (H + 2 * HKV) * D, generator=g, device=DEV) * 0.8).to(dtype)
+    qkv[:, :H * D] *= q_gain
+    # per-head magnitudes differ by > 100x: a scale that is wrong for one head shows immediately
+    gain = torch.tensor([0.05, 1.0, 6.0, 20.0] * HKV, device=DEV)[:2 * HKV].repeat_interleave(D)
+    qkv[:, H * D:] = (qkv[:, H * D:].float() * gain).to(dtype)
+    q = qkv[:, :H * D].view(T, H, D)                                   # column slices of the fused output, read in place
+    kv = qkv[:, H * D:].view(T, 2 * HKV, D)
+    scale = ops.kv_scale_from_absmax(kv)
+    cache = ops.kv_quant_fp8(kv, scale)
+    return q, cache, scale
+
+
+def _ref(q, cache, scale, causal):
+    """float64 softmax attention over the dequantised cache -> [T, H * D]"""
+    T, H, D = q.shape
+    HKV = cache.shape[1] // 2
+    kvd = cache.float().double() * scale.double()[None, :, None]
+    k, v = kvd[:, :HKV], kvd[:, HKV:]
+    rep = H // HKV
+    k = k.repeat_interleave(rep, dim=1).permute(1, 0, 2)               # [H, T, D]
+    v = v.repeat_interleave(rep, dim=1).permute(1, 0, 2)
+    s = torch.einsum("thd,hkd->htk", q.double(), k) * D ** -0.5
+    if causal:
+        s = s.masked_fill(torch.ones(T, T, device=q.device, dtype=torch.bool).triu(1), float("-inf"))
+    o = torch.softmax(s, dim=-1) @ v                                   # [H, T, D]
+    return o.permute(1, 0, 2).reshape(T, H * D)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("T,H,HKV,causal", [(768, 28, 4, True), (768, 64, 8, True), (1, 4, 2, True), (33, 8, 8, True),
+                                            (129, 4, 1, True), (500, 8, 2, False), (2048, 8, 2, True)])
+def test_attention_over_the_fp8_cache_equals_attention_over_the_dequantised_cache(dtype, T, H, HKV, causal):
+    from mquant_amd import ops
+    q, cache, scale = _case(T + H, T, H, HKV, dtype)
+    got = ops.attn_prefill_fp8kv(q, cache, scale, causal=causal)
+    assert got.shape == (T, H * 128) and got.dtype == dtype
+    want = _ref(q, cache, scale, causal)
+    err = (got.double() - want).abs()
+    # per head: the rounding of P and of the output to 10 (fp16) / 7 (bf16) mantissa bits, relative to the head's range
+    tol = 2.5e-3 if dtype == torch.float16 else 1.6e-2
+    per_head = want.view(T, H, 128).abs().amax(dim=(0, 2)).clamp_min(1e-9)
+    rel = err.view(T, H, 128).amax(dim=(0, 2)) / per_head
+    assert float(rel.max()) < tol, rel.cpu().numpy()
+    cos = F.cosine_similarity(got.double().flatten(), want.flatten(), dim=0)
+    assert float(cos) > (0.999999 if dtype == torch.float16 else 0.99995)
+
+
+def test_peaked_scores_and_the_first_rows():
+    """Large logits (one key dominates), and the causal rows 0 and 1 that attend to one and two keys."""
+    from mquant_amd import ops
+    T, H, HKV = 300, 4, 2
+    q, cache, scale = _case(5, T, H, HKV, torch.float16, q_gain=6.0)
+    got = ops.attn_prefill_fp8kv(q, cache, scale, causal=True).double()
+    want = _ref(q, cache, scale, True)
+    assert torch.isfinite(got).all()
+    v0 = cache.float().double()[0, HKV:] * scale.double()[HKV:, None]   # row 0 attends to key 0 only: O = V[0]
+    np.testing.assert_allclose(got[0].view(H, 128).cpu().numpy(), v0.repeat_interleave(H // HKV, dim=0).cpu().numpy(),
+                               rtol=2 ** -10, atol=1e-6)
+    per_head = want.view(T, H, 128).abs().amax(dim=(0, 2))
+    rel = (got - want).abs().view(T, H, 128).amax(dim=(0, 2)) / per_head
+    assert float(rel.max()) < 4e-3, rel
+
+
+def test_it_agrees_with_dequantise_then_sdpa_in_half_precision():
+    """The path it replaces: mq_kv_dequant_fp8 -> fp16 K / V in HBM -> torch SDPA."""
+    from mquant_amd import ops
+    T, H, HKV = 768, 28, 4
+    q, cache, scale = _case(11, T, H, HKV, torch.float16)
+    got = ops.attn_prefill_fp8kv(q, cache, scale, causal=True).float()
+    kvd = ops.kv_dequant_fp8(cache, scale, torch.float16)
+    k, v = kvd[:, :HKV], kvd[:, HKV:]
+    rep = H // HKV
+    o = F.scaled_dot_product_attention(q.permute(1, 0, 2)[None], k.repeat_interleave(rep, 1).permute(1, 0, 2)[None],
+                                       v.repeat_interleave(rep, 1).permute(1, 0, 2)[None], is_causal=True)
+    o = o[0].permute(1, 0, 2).reshape(T, H * 128).float()
+    assert float((got - o).abs().max() / o.abs().max()) < 5e-3       # two fp16 pipelines, each ~1e-3 from the exact result
+    assert float(F.cosine_similarity(got.flatten(), o.flatten(), dim=0)) > 0.999999
+
+
+def test_out_buffer_and_strides():
+    from mquant_amd import ops
+    T, H, HKV = 200, 8, 2
+    q, cache, scale = _case(2, T, H, HKV, torch.float16)
+    wide = torch.full((T, H * 128 + 64), 7.0, device=DEV, dtype=torch.float16)
+    ops.attn_prefill_fp8kv(q, cache, scale, out=wide[:, :H * 128])
+    want = ops.attn_prefill_fp8kv(q.contiguous(), cache, scale)
+    assert torch.equal(wide[:, :H * 128], want) and bool((wide[:, H * 128:] == 7.0).all())
+
+
+def test_bad_arguments_are_refused():
+    from mquant_amd import ops
+    from mquant_amd._lib import MQuantHipError as MQuantError
+    q, cache, scale = _case(1, 16, 4, 2, torch.float16)
+    with pytest.raises((MQuantError, AssertionError)):
+        ops.attn_prefill_fp8kv(q.float(), cache, scale)
+    with pytest.raises((MQuantError, AssertionError)):
+        ops.attn_prefill_fp8kv(q[:, :, :64].contiguous(), cache[:, :, :64].contiguous(), scale)
+    with pytest.raises((MQuantError, AssertionError)):
+        ops.attn_prefill_fp8kv(q[:, :3].contiguous(), cache, scale)     # 3 heads over 2 kv heads
