@@ -57,7 +57,7 @@ def _rope(x, cos, sin):
 
 class FullPrefill:
     def __init__(self, pf: Prefill, seed: int = 7, fused_glue: bool = True, sample: int = 0,
-                 geometry: Optional[Geometry] = None, kv_fp8: bool = False):
+                 geometry: Optional[Geometry] = None, kv_fp8: bool = False, attn_fp8: bool = False):
         #: norm -> quantize and activation -> Hadamard -> quantize as single launches
         self.fused_glue = fused_glue
         self.g = geometry or QWEN2VL_7B
@@ -65,6 +65,10 @@ class FullPrefill:
         #: with one static scale per KV head (calibrated with the activation scales), and the attention of the same
         #: step consumes the cache contents read back by the same launch (mq_kv_quant_fp8_readback)
         self.kv_fp8 = kv_fp8
+        #: with kv_fp8: the attention of the prefill reads the e4m3 cache itself (mq_attn_prefill_fp8kv) instead of a
+        #: half-precision read-back through torch SDPA -- no fp16 copy of K / V exists after the q|k|v GEMM output
+        self.attn_fp8 = attn_fp8
+        assert kv_fp8 or not attn_fp8, "attn_fp8 reads the fp8 cache: it needs kv_fp8"
         self.kv_cache: List[torch.Tensor] = []
         self.kv_scales: List[torch.Tensor] = []
         assert pf.share_groups, "the chained prefill uses the fused q/k/v and gate/up GEMMs"
@@ -200,14 +204,22 @@ class FullPrefill:
                         self.kv_cache.append(torch.empty((T, 2 * KVH, HD), dtype=torch.float8_e4m3fn, device=self.dev))
                     else:
                         self.kv_scales[i] = ops.kv_scale_from_absmax(kv_cols)
-                # write the cache (e4m3, static per-head scales) and attend over what was written: one launch
-                _, hat = ops.kv_quant_fp8_readback(kv_cols, self.kv_scales[i], out=self.kv_cache[i])
-                k, v = hat[:, :KVH], hat[:, KVH:]
-            a = F.scaled_dot_product_attention(q.transpose(0, 1)[None], k.transpose(0, 1)[None],
-                                               v.transpose(0, 1)[None], is_causal=True, enable_gqa=True)[0]
+            if self.kv_fp8 and self.attn_fp8 and not self.calibrating:
+                # write the cache (e4m3, static per-head scales); the attention kernel reads those bytes
+                ops.kv_quant_fp8(kv_cols, self.kv_scales[i], out=self.kv_cache[i])
+                flat = ops.attn_prefill_fp8kv(q, self.kv_cache[i], self.kv_scales[i], causal=True)      # [T, heads * head_dim]
+                a = flat.view(T, H, HD).transpose(0, 1)
+            else:
+                if self.kv_fp8:
+                    # write the cache and attend over what was written, read back by the same launch
+                    _, hat = ops.kv_quant_fp8_readback(kv_cols, self.kv_scales[i], out=self.kv_cache[i])
+                    k, v = hat[:, :KVH], hat[:, KVH:]
+                a = F.scaled_dot_product_attention(q.transpose(0, 1)[None], k.transpose(0, 1)[None],
+                                                   v.transpose(0, 1)[None], is_causal=True, enable_gqa=True)[0]
+                flat = a.transpose(0, 1).reshape(T, D)
             if i == 0:
                 self.attn_first = a            # [heads, T, head_dim] of the first decoder layer (tests)
-            hdn = self._lin(by["llm.o_proj"][i], a.transpose(0, 1).reshape(T, D), residual=hdn)
+            hdn = self._lin(by["llm.o_proj"][i], flat, residual=hdn)
             gu = self._norm_lin(by["llm.gate_proj"][i], hdn, D)    # fused gate|up GEMM
             half = gu.shape[1] // 2
             hdn = self._act_lin(by["llm.down_proj"][i], gu[:, :half], gu[:, half:], ops.ACT_SILU_MUL, residual=hdn)

@@ -152,3 +152,31 @@ def test_fp8_kv_cache_wired_into_the_prefill_of_the_72b_geometry():
     assert rel <= 0.06 and cos >= 0.998, (rel, cos)
     lcos = float(torch.nn.functional.cosine_similarity(la.flatten(), lb.flatten(), dim=0))
     assert lcos > 0.9, lcos
+
+
+@pytest.mark.parametrize("geo_name", ["7b", "72b"])
+def test_the_prefill_attends_over_the_cache_bytes_themselves(geo_name):
+    """attn_fp8: no half-precision read-back -- mq_kv_quant_fp8 writes the cache and mq_attn_prefill_fp8kv reads the
+    e4m3 bytes.  Against the read-back + SDPA variant of the same prefill: identical cache bytes in layer 0 (same
+    inputs, same scales), the layer-0 attention output within half-precision rounding of it, logits correlated (see the
+    test above for why the random stack allows no more)."""
+    from mquant_amd import workload
+    from mquant_amd.full_prefill import QWEN2VL_7B, QWEN2VL_72B, FullPrefill
+    if geo_name == "72b":
+        specs, geo = workload.qwen2vl_72b_specs(v=1, l=2), QWEN2VL_72B
+    else:
+        specs, geo = workload._qwen2vl_7b_specs(True, 1, 2), QWEN2VL_7B
+    pf = workload.Prefill(specs, device=DEV, share_groups=True)
+    outs = {}
+    for direct in (False, True):
+        fp = FullPrefill(pf, fused_glue=True, geometry=geo, kv_fp8=True, attn_fp8=direct)
+        fp.calibrate()
+        logits = fp.step().float().clone()
+        outs[direct] = (logits, fp.attn_first.float().clone(), fp.kv_cache[0].view(torch.uint8).clone())
+        fp.restore_hot_path_scales()
+    (la, aa, ca), (lb, ab, cb) = outs[False], outs[True]
+    assert torch.equal(ca, cb)
+    assert torch.isfinite(lb).all()
+    assert float((aa - ab).abs().max() / aa.abs().max()) < 5e-3
+    assert float(torch.nn.functional.cosine_similarity(aa.flatten(), ab.flatten(), dim=0)) > 0.99999
+    assert float(torch.nn.functional.cosine_similarity(la.flatten(), lb.flatten(), dim=0)) > 0.9
