@@ -426,15 +426,22 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = max(3, min(args.steps, 10))
 
-    def timed(run):
-        run()
-        torch.cuda.synchronize(dev)
-        e0.record()
-        for _ in range(reps):
+    def timed(run, batches=5):
+        """average duration of one replay: median over ``batches`` batches of ``reps`` back-to-back replays (a single
+        batch right after the host-side checks above was seen 13 % slow on a fresh box: clocks / power state)"""
+        for _ in range(2):
             run()
-        e1.record()
         torch.cuda.synchronize(dev)
-        return e0.elapsed_time(e1) / reps
+        got = []
+        for _ in range(batches):
+            e0.record()
+            for _ in range(reps):
+                run()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            got.append(e0.elapsed_time(e1) / reps)
+        got.sort()
+        return got[len(got) // 2]
 
     hot_ms = timed(capture(pf.step))                 # the hot path alone (no logits, no exchange), stream-timed
     gemm_ms = timed(capture(pf.step_gemm_only))
