@@ -37,8 +37,9 @@ typedef float at_v16f __attribute__((ext_vector_type(16)));
 
 struct AttnArgs {
     const void *q;           // [T, heads * 128] (row stride ldq elements), fp16 / bf16
-    const uint8_t *kv;       // [T, 2 * kv_heads, 128] e4m3: K heads, then V heads (row stride ldkv bytes)
-    const float *kv_scale;   // [2 * kv_heads]
+    const uint8_t *k, *v;    // first K / V head of token 0; a token's heads are contiguous, row stride ldkv BYTES.  e4m3 cache:
+                             // v = k + kv_heads * 128 ([T, 2 * kv_heads, 128]); 16-bit K / V: two column slices of the q|k|v output
+    const float *kv_scale;   // e4m3 only: [2 * kv_heads]
     void *out;               // [T, heads * 128] (row stride ldo elements), q's dtype
     long T, ldq, ldkv, ldo;
     int heads, kv_heads, causal;
@@ -62,7 +63,8 @@ template <> struct AttnMma<MQ_BF16> {
 constexpr int AT_D = 128;            // head_dim
 constexpr int AT_KB = 32;            // keys per block
 constexpr int AT_VROW = 256;         // bytes per V row in LDS (32-byte groups XOR-ed by key & 3)
-constexpr int AT_WAVE_LDS = 16384;   // per wave: the V tile (8 KiB) during the loop, its partial O^T (16 KiB) in the merge
+constexpr int AT_KROW = 272;         // 16-bit K / V only: bytes per K row in LDS (256 + 16: 16 consecutive rows hit 16 different 16-byte slots)
+constexpr int AT_WAVE_LDS = 8192 + 32 * AT_KROW;   // per wave: the V tile (8 KiB) [+ the 16-bit K tile] during the loop, its partial O^T (16 KiB) in the merge
 constexpr int AT_STATS = 4 * 32 * 2 * 4;
 
 template <int DT> struct AttnCvt;
@@ -84,9 +86,12 @@ __device__ __forceinline__ void widen16(const v4i w, v4i &a, v4i &b)
     b = v4i{AttnCvt<DT>::lo(w[2]), AttnCvt<DT>::hi(w[2]), AttnCvt<DT>::lo(w[3]), AttnCvt<DT>::hi(w[3])};
 }
 
-template <int DT>
-__global__ __launch_bounds__(256, 2) void attn_prefill_fp8kv_kernel(AttnArgs p)
+// KV8: K / V are e4m3 bytes (widened here); else they are 16-bit values of q's dtype, used as they are.
+template <int DT, bool KV8>
+__global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p)
 {
+    constexpr int EB = KV8 ? 1 : 2;                                   // bytes per K / V element
+    constexpr int NR = KV8 ? 4 : 8;                                   // 16-byte loads per lane and operand and block
     typedef AttnMma<DT> MM;
     __shared__ __attribute__((aligned(16))) char smem[4 * AT_WAVE_LDS + AT_STATS];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -95,8 +100,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_fp8kv_kernel(AttnArgs p)
     const long qt = (long)gridDim.x - 1 - blockIdx.x;                // the deepest (last) query tiles start first
     const long q_row = qt * 32 + (lane & 31);                         // the query this lane owns (D layout: lane = column)
     const int ko = lane >> 5;                                         // lane half: d 64 ko.. of K / Q, keys + 4 ko of S, octet ko of P
-    const float sc = p.kv_scale[kvh] * p.softmax_scale * 1.4426950408889634f;   // K scale and log2(e) folded into the score scale
-    const float s_v = p.kv_scale[p.kv_heads + kvh];
+    const float sc = (KV8 ? p.kv_scale[kvh] : 1.0f) * p.softmax_scale * 1.4426950408889634f;   // K scale and log2(e) folded into the score scale
+    const float s_v = KV8 ? p.kv_scale[p.kv_heads + kvh] : 1.0f;
     char *vt = smem + wave * AT_WAVE_LDS;                             // this wave's V tile: [32 keys][128 d] 16-bit, row-major, swizzled
 
     // ---- Q^T operand: lane = query; k-step ds covers d = 64 ko + 8 ds .. + 7 (the K operand is loaded to match) ----
@@ -118,34 +123,60 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_fp8kv_kernel(AttnArgs p)
     long n_all = (p.T + AT_KB - 1) / AT_KB;
     const int n_blocks = (int)((p.causal && qt + 1 < n_all) ? qt + 1 : n_all);
 
-    // a lane's loads for one block: K -- 64 bytes of key (lane & 31), d 64 ko..; V -- 64 bytes of key lane / 2, d 64 (lane & 1)..
-    const int v_key = lane >> 1, v_d = (lane & 1) * 64;
-    auto load_block = [&](int kb, v4i (&kraw)[4], v4i (&vraw)[4]) {
-        const long kkey = (long)kb * AT_KB + (lane & 31), vkey = (long)kb * AT_KB + v_key;
-        const uint8_t *kp = p.kv + kkey * p.ldkv + (long)kvh * AT_D + 64 * ko;
-        const uint8_t *vp = p.kv + vkey * p.ldkv + (long)(p.kv_heads + kvh) * AT_D + v_d;
+    // A lane's loads for one block.  e4m3: K -- the 64 bytes d 64 ko.. of key (lane & 31), straight into its MFMA operands;
+    // V -- the 64 bytes d 64 (lane & 1).. of key lane / 2.  16-bit K / V: rows are 256 bytes and a lane-per-row pattern
+    // would touch 64 cache lines per instruction (measured: 55 us against 25 us for the e4m3 cache at the 7B shape), so
+    // both tiles are loaded COALESCED -- instruction j = rows 4 j .. 4 j + 3, lane = (row, 16-byte piece) -- and K takes
+    // the detour through a padded LDS tile as well.
+    const int v_key = KV8 ? lane >> 1 : lane >> 4, v_d = (lane & 1) * 64, pc16 = (lane & 15) * 16;
+    char *kt = vt + 8192;
+    auto load_block = [&](int kb, v4i (&kraw)[NR], v4i (&vraw)[NR]) {
+        if (KV8) {
+            const long kkey = (long)kb * AT_KB + (lane & 31), vkey = (long)kb * AT_KB + v_key;
+            const uint8_t *kp = p.k + kkey * p.ldkv + (long)kvh * AT_D + 64 * ko;
+            const uint8_t *vp = p.v + vkey * p.ldkv + (long)kvh * AT_D + v_d;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            kraw[j] = kkey < p.T ? *reinterpret_cast<const v4i *>(kp + 16 * j) : v4i{0, 0, 0, 0};
-            vraw[j] = vkey < p.T ? *reinterpret_cast<const v4i *>(vp + 16 * j) : v4i{0, 0, 0, 0};
+            for (int j = 0; j < NR; ++j) {
+                kraw[j] = kkey < p.T ? *reinterpret_cast<const v4i *>(kp + 16 * j) : v4i{0, 0, 0, 0};
+                vraw[j] = vkey < p.T ? *reinterpret_cast<const v4i *>(vp + 16 * j) : v4i{0, 0, 0, 0};
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const long key = (long)kb * AT_KB + 4 * j + v_key;
+                const long off = key * p.ldkv + (long)kvh * AT_D * 2 + pc16;
+                kraw[j] = key < p.T ? *reinterpret_cast<const v4i *>(p.k + off) : v4i{0, 0, 0, 0};
+                vraw[j] = key < p.T ? *reinterpret_cast<const v4i *>(p.v + off) : v4i{0, 0, 0, 0};
+            }
         }
     };
 
-    v4i kraw[4], vraw[4];
+    v4i kraw[NR], vraw[NR];
     if (wave < n_blocks) load_block(wave, kraw, vraw);
     const int t16 = lane & 15, g16 = (lane >> 4) & 1;
     for (int kb = wave; kb < n_blocks; kb += 4) {
-        // ---- widen: K into MFMA operands, V into this wave's LDS tile -------------------------------------------
+        // ---- K into MFMA operands, V into this wave's LDS tile (e4m3: widened on the way) ------------------------
         v4i Kf[8];
+        if (KV8) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) widen16<DT>(kraw[j], Kf[2 * j], Kf[2 * j + 1]);
+            for (int j = 0; j < 4; ++j) widen16<DT>(kraw[j], Kf[2 * j], Kf[2 * j + 1]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v4i a, b;
-            widen16<DT>(vraw[j], a, b);
-            const int col = ((v_d + 16 * j) * 2) ^ ((v_key & 3) << 5);        // 32 B = sixteen values = one swizzle group
-            *reinterpret_cast<v4i *>(vt + v_key * AT_VROW + col) = a;
-            *reinterpret_cast<v4i *>(vt + v_key * AT_VROW + col + 16) = b;
+            for (int j = 0; j < 4; ++j) {
+                v4i a, b;
+                widen16<DT>(vraw[j], a, b);
+                const int col = ((v_d + 16 * j) * 2) ^ ((v_key & 3) << 5);    // 32 B = sixteen values = one swizzle group
+                *reinterpret_cast<v4i *>(vt + v_key * AT_VROW + col) = a;
+                *reinterpret_cast<v4i *>(vt + v_key * AT_VROW + col + 16) = b;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = 4 * j + v_key;
+                *reinterpret_cast<v4i *>(kt + r * AT_KROW + pc16) = kraw[j & (NR - 1)];
+                *reinterpret_cast<v4i *>(vt + r * AT_VROW + (pc16 ^ ((r & 3) << 5))) = vraw[j & (NR - 1)];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
         if (kb + 4 < n_blocks) load_block(kb + 4, kraw, vraw);        // in flight during this block's arithmetic
         const long key0 = (long)kb * AT_KB;
@@ -155,7 +186,10 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_fp8kv_kernel(AttnArgs p)
 #pragma unroll
         for (int e = 0; e < 16; ++e) S[e] = 0.0f;
 #pragma unroll
-        for (int ds = 0; ds < 8; ++ds) S = MM::mma(Kf[ds], Qf[ds], S);
+        for (int ds = 0; ds < 8; ++ds) {
+            if (KV8) S = MM::mma(Kf[ds], Qf[ds], S);
+            else S = MM::mma(*reinterpret_cast<const v4i *>(kt + (lane & 31) * AT_KROW + (64 * ko + 8 * ds) * 2), Qf[ds], S);
+        }
 
         // ---- online softmax (log2 domain); register r <-> key key0 + (r & 3) + 8 (r >> 2) + 4 ko -----------------
         float s[16], m_blk = -1.0e30f;
@@ -265,6 +299,21 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_fp8kv_kernel(AttnArgs p)
 
 }  // namespace mq
 
+static int attn_launch(const mq::AttnArgs &a, int dtype, bool kv8, void *stream)
+{
+    using namespace mq;
+    const dim3 grid((unsigned)((a.T + 31) / 32), (unsigned)a.heads);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (kv8) {
+        if (dtype == MQ_F16) hipLaunchKernelGGL((attn_prefill_kernel<MQ_F16, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attn_prefill_kernel<MQ_BF16, true>), grid, dim3(256), 0, st, a);
+    } else {
+        if (dtype == MQ_F16) hipLaunchKernelGGL((attn_prefill_kernel<MQ_F16, false>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attn_prefill_kernel<MQ_BF16, false>), grid, dim3(256), 0, st, a);
+    }
+    return check_launch("attn_prefill");
+}
+
 extern "C" int mq_attn_prefill_fp8kv(const void *q, int dtype, long T, int heads, int kv_heads, int head_dim, long ldq,
                                      const uint8_t *kv_cache, long ldkv, const float *kv_scale, float softmax_scale,
                                      int causal, void *out, long ldo, void *stream)
@@ -279,10 +328,25 @@ extern "C" int mq_attn_prefill_fp8kv(const void *q, int dtype, long T, int heads
     MQ_REQUIRE(((uintptr_t)q) % 16 == 0 && (ldq * 2) % 16 == 0 && ((uintptr_t)kv_cache) % 16 == 0 && ldkv % 16 == 0 &&
                    ((uintptr_t)out) % 8 == 0 && (ldo * 2) % 8 == 0,
                "mq_attn_prefill_fp8kv: q / cache rows must be 16-byte aligned, out rows 8-byte aligned");
-    AttnArgs a{q, kv_cache, kv_scale, out, T, ldq, ldkv, ldo, heads, kv_heads, causal ? 1 : 0, softmax_scale};
-    const dim3 grid((unsigned)((T + 31) / 32), (unsigned)heads);
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MQ_F16) hipLaunchKernelGGL(attn_prefill_fp8kv_kernel<MQ_F16>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(attn_prefill_fp8kv_kernel<MQ_BF16>, grid, dim3(256), 0, st, a);
-    return check_launch("attn_prefill_fp8kv");
+    AttnArgs a{q, kv_cache, kv_cache + (long)kv_heads * AT_D, kv_scale, out, T, ldq, ldkv, ldo, heads, kv_heads, causal ? 1 : 0, softmax_scale};
+    return attn_launch(a, dtype, true, stream);
+}
+
+extern "C" int mq_attn_prefill(const void *q, int dtype, long T, int heads, int kv_heads, int head_dim, long ldq,
+                               const void *k, const void *v, long ldkv, float softmax_scale, int causal, void *out, long ldo,
+                               void *stream)
+{
+    using namespace mq;
+    MQ_REQUIRE(dtype == MQ_F16 || dtype == MQ_BF16, "mq_attn_prefill: dtype must be fp16 or bf16 (got %d)", dtype);
+    MQ_REQUIRE(T >= 0 && heads >= 1 && kv_heads >= 1 && heads % kv_heads == 0, "mq_attn_prefill: bad head counts %d / %d", heads, kv_heads);
+    MQ_REQUIRE(head_dim == AT_D, "mq_attn_prefill: head_dim %d (this kernel is built for 128)", head_dim);
+    if (T == 0) return MQ_OK;
+    MQ_REQUIRE(q && k && v && out, "mq_attn_prefill: null pointer");
+    MQ_REQUIRE(ldq >= (long)heads * AT_D && ldo >= (long)heads * AT_D && ldkv >= (long)kv_heads * AT_D, "mq_attn_prefill: row strides too short");
+    MQ_REQUIRE(((uintptr_t)q) % 16 == 0 && (ldq * 2) % 16 == 0 && ((uintptr_t)k) % 16 == 0 && ((uintptr_t)v) % 16 == 0 && (ldkv * 2) % 16 == 0 &&
+                   ((uintptr_t)out) % 8 == 0 && (ldo * 2) % 8 == 0,
+               "mq_attn_prefill: q / k / v rows must be 16-byte aligned, out rows 8-byte aligned");
+    AttnArgs a{q, reinterpret_cast<const uint8_t *>(k), reinterpret_cast<const uint8_t *>(v), nullptr, out, T, ldq, ldkv * 2, ldo,
+               heads, kv_heads, causal ? 1 : 0, softmax_scale};
+    return attn_launch(a, dtype, false, stream);
 }

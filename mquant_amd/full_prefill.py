@@ -57,7 +57,8 @@ def _rope(x, cos, sin):
 
 class FullPrefill:
     def __init__(self, pf: Prefill, seed: int = 7, fused_glue: bool = True, sample: int = 0,
-                 geometry: Optional[Geometry] = None, kv_fp8: bool = False, attn_fp8: bool = False):
+                 geometry: Optional[Geometry] = None, kv_fp8: bool = False, attn_fp8: bool = False,
+                 attn_kernel: Optional[bool] = None):
         #: norm -> quantize and activation -> Hadamard -> quantize as single launches
         self.fused_glue = fused_glue
         self.g = geometry or QWEN2VL_7B
@@ -69,6 +70,10 @@ class FullPrefill:
         #: half-precision read-back through torch SDPA -- no fp16 copy of K / V exists after the q|k|v GEMM output
         self.attn_fp8 = attn_fp8
         assert kv_fp8 or not attn_fp8, "attn_fp8 reads the fp8 cache: it needs kv_fp8"
+        #: decoder attention over 16-bit K / V with this repository's kernel (mq_attn_prefill: reads the q / k / v column
+        #: slices of the fused GEMM output in place and writes the [T, heads * head_dim] layout o_proj consumes) instead
+        #: of torch SDPA; part of the fused glue by default
+        self.attn_kernel = (fused_glue if attn_kernel is None else attn_kernel) and self.g.head_dim == 128
         self.kv_cache: List[torch.Tensor] = []
         self.kv_scales: List[torch.Tensor] = []
         assert pf.share_groups, "the chained prefill uses the fused q/k/v and gate/up GEMMs"
@@ -214,9 +219,13 @@ class FullPrefill:
                     # write the cache and attend over what was written, read back by the same launch
                     _, hat = ops.kv_quant_fp8_readback(kv_cols, self.kv_scales[i], out=self.kv_cache[i])
                     k, v = hat[:, :KVH], hat[:, KVH:]
-                a = F.scaled_dot_product_attention(q.transpose(0, 1)[None], k.transpose(0, 1)[None],
-                                                   v.transpose(0, 1)[None], is_causal=True, enable_gqa=True)[0]
-                flat = a.transpose(0, 1).reshape(T, D)
+                if self.attn_kernel:
+                    flat = ops.attn_prefill(q, k, v, causal=True)
+                    a = flat.view(T, H, HD).transpose(0, 1)
+                else:
+                    a = F.scaled_dot_product_attention(q.transpose(0, 1)[None], k.transpose(0, 1)[None],
+                                                       v.transpose(0, 1)[None], is_causal=True, enable_gqa=True)[0]
+                    flat = a.transpose(0, 1).reshape(T, D)
             if i == 0:
                 self.attn_first = a            # [heads, T, head_dim] of the first decoder layer (tests)
             hdn = self._lin(by["llm.o_proj"][i], flat, residual=hdn)

@@ -459,6 +459,31 @@ def attn_prefill_fp8kv(q: torch.Tensor, kv_cache: torch.Tensor, kv_scale: torch.
     return out
 
 
+@_on_device
+def attn_prefill(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = True, softmax_scale: float = None,
+                 out: torch.Tensor = None) -> torch.Tensor:
+    """Prefill attention over unquantised K / V (``mq_attn_prefill``): q [T, heads, 128], k and v [T, kv_heads, 128] of
+    the same fp16 / bf16 dtype and the same token stride (column slices of the fused q|k|v output work in place)
+    -> [T, heads * 128], the layout o_proj consumes."""
+    _need_cuda(q, k, v, out)
+    T, H, D = q.shape
+    assert k.shape == v.shape and k.shape[0] == T and k.shape[2] == D and k.dtype == q.dtype and v.dtype == q.dtype
+    HKV = k.shape[1]
+    assert q.stride(2) == 1 and q.stride(1) == D
+    for t in (k, v):
+        assert t.stride(2) == 1 and t.stride(1) == D
+    assert T <= 1 or k.stride(0) == v.stride(0), "k and v must share their token stride"
+    if out is None:
+        out = torch.empty((T, H * D), dtype=q.dtype, device=q.device)
+    assert out.dtype == q.dtype and out.shape == (T, H * D) and out.stride(1) == 1
+    if softmax_scale is None:
+        softmax_scale = D ** -0.5
+    call("mq_attn_prefill", q.data_ptr(), dtype_code(q.dtype), T, H, HKV, D, q.stride(0) if T > 1 else H * D,
+         k.data_ptr(), v.data_ptr(), k.stride(0) if T > 1 else HKV * D, float(softmax_scale), 1 if causal else 0,
+         out.data_ptr(), out.stride(0) if T > 1 else H * D, _stream())
+    return out
+
+
 def kv_scale_from_absmax(kv: torch.Tensor) -> torch.Tensor:
     """Static per-head scale from calibration activations [T, kv_heads, head_dim]: absmax / 448."""
     return (kv.float().abs().amax(dim=(0, 2)).clamp_min(1e-8) / FP8_E4M3_MAX).contiguous()

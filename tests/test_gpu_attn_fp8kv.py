@@ -116,3 +116,32 @@ def test_bad_arguments_are_refused():
         ops.attn_prefill_fp8kv(q[:, :, :64].contiguous(), cache[:, :, :64].contiguous(), scale)
     with pytest.raises((MQuantError, AssertionError)):
         ops.attn_prefill_fp8kv(q[:, :3].contiguous(), cache, scale)     # 3 heads over 2 kv heads
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("T,H,HKV,causal", [(768, 28, 4, True), (768, 64, 8, True), (1, 4, 2, True), (97, 8, 8, True),
+                                            (500, 8, 2, False), (1500, 4, 1, True)])
+def test_attention_over_unquantised_k_v(dtype, T, H, HKV, causal):
+    """mq_attn_prefill: the same kernel with 16-bit K / V read in place from the fused q|k|v output; checker = float64
+    softmax attention."""
+    from mquant_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(T + 3 * H)
+    D = 128
+    qkv = (torch.randn(T, (H + 2 * HKV) * D, generator=g, device=DEV) * 0.9).to(dtype)
+    q = qkv[:, :H * D].view(T, H, D)
+    k = qkv[:, H * D:(H + HKV) * D].view(T, HKV, D)
+    v = qkv[:, (H + HKV) * D:].view(T, HKV, D)
+    got = ops.attn_prefill(q, k, v, causal=causal)
+    rep = H // HKV
+    kk = k.double().repeat_interleave(rep, dim=1).permute(1, 0, 2)
+    vv = v.double().repeat_interleave(rep, dim=1).permute(1, 0, 2)
+    s = torch.einsum("thd,hkd->htk", q.double(), kk) * D ** -0.5
+    if causal:
+        s = s.masked_fill(torch.ones(T, T, device=DEV, dtype=torch.bool).triu(1), float("-inf"))
+    want = (torch.softmax(s, dim=-1) @ vv).permute(1, 0, 2).reshape(T, H * D)
+    tol = 2.5e-3 if dtype == torch.float16 else 1.6e-2
+    assert float((got.double() - want).abs().max() / want.abs().max()) < tol
+    # and against torch SDPA in the same dtype (the op it replaces in the whole-prefill glue)
+    o = F.scaled_dot_product_attention(q.permute(1, 0, 2)[None], k.permute(1, 0, 2)[None], v.permute(1, 0, 2)[None],
+                                       is_causal=causal, enable_gqa=True)[0].permute(1, 0, 2).reshape(T, H * D)
+    assert float((got.float() - o.float()).abs().max() / o.float().abs().max()) < 2 * tol

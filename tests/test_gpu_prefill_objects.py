@@ -183,7 +183,7 @@ def test_full_prefill_fused_glue_equals_unfused_glue():
     pf = workload.Prefill(specs, device=DEV, share_groups=True)
     outs = []
     for fused in (False, True):
-        fp = FullPrefill(pf, fused_glue=fused)
+        fp = FullPrefill(pf, fused_glue=fused, attn_kernel=False)       # same SDPA on both sides: this test is about the glue kernels
         fp.calibrate()
         outs.append(fp.step().float().clone())
         fp.restore_hot_path_scales()
@@ -193,3 +193,26 @@ def test_full_prefill_fused_glue_equals_unfused_glue():
     assert float((a - b).abs().max()) <= 0.02 * span, (float((a - b).abs().max()), span)
     cos = torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0)
     assert float(cos) > 0.999
+
+
+def test_full_prefill_with_this_repositorys_attention_kernel():
+    """The decoder attention of the chained prefill through mq_attn_prefill (q / k / v read in place from the fused GEMM
+    output) against torch SDPA in the same prefill: the first decoder layer sees identical inputs, so its attention output
+    is held to half-precision rounding; the logits of the random 2-layer stack stay correlated (a random stack amplifies
+    any rounding difference and flips static int8 levels on the way)."""
+    from mquant_amd import workload
+    from mquant_amd.full_prefill import FullPrefill
+    specs = workload._qwen2vl_7b_specs(True, 1, 2)
+    pf = workload.Prefill(specs, device=DEV, share_groups=True)
+    outs = []
+    for own in (False, True):
+        fp = FullPrefill(pf, fused_glue=True, attn_kernel=own)
+        assert fp.attn_kernel == own
+        fp.calibrate()
+        outs.append((fp.step().float().clone(), fp.attn_first.float().clone()))
+        fp.restore_hot_path_scales()
+    (la, aa), (lb, ab) = outs
+    assert torch.isfinite(lb).all()
+    assert float((aa - ab).abs().max() / aa.abs().max()) < 5e-3
+    assert float(torch.nn.functional.cosine_similarity(aa.flatten(), ab.flatten(), dim=0)) > 0.99999
+    assert float(torch.nn.functional.cosine_similarity(la.flatten(), lb.flatten(), dim=0)) > 0.99
