@@ -68,12 +68,16 @@ constexpr int AT_WAVE_LDS = 8192 + 32 * AT_KROW;   // per wave: the V tile (8 Ki
 constexpr int AT_STATS = 4 * 32 * 2 * 4;
 
 template <int DT> struct AttnCvt;
+typedef float at_v2f __attribute__((ext_vector_type(2)));
 template <> struct AttnCvt<MQ_F16> {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ unsigned pack2(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(at_v2f{a, b}, h2)); }   // V_CVT_PK_F16_F32, RNE
     static __device__ __forceinline__ int lo(int w) { return __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, false)); }
     static __device__ __forceinline__ int hi(int w) { return __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, true)); }
 };
 template <> struct AttnCvt<MQ_BF16> {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ unsigned pack2(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(at_v2f{a, b}, b2)); }   // V_CVT_PK_BF16_F32, RNE
     static __device__ __forceinline__ int lo(int w) { return __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, false)); }
     static __device__ __forceinline__ int hi(int w) { return __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, true)); }
 };
@@ -191,33 +195,30 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p)
             else S = MM::mma(*reinterpret_cast<const v4i *>(kt + (lane & 31) * AT_KROW + (64 * ko + 8 * ds) * 2), Qf[ds], S);
         }
 
-        // ---- online softmax (log2 domain); register r <-> key key0 + (r & 3) + 8 (r >> 2) + 4 ko -----------------
-        float s[16], m_blk = -1.0e30f;
+        // ---- online softmax (log2 domain); register r <-> key key0 + (r & 3) + 8 (r >> 2) + 4 ko.  The maximum is taken
+        // over the raw scores (sc > 0) and the scale rides in the exponent's fma; a masked score is -1e30 BEFORE scaling,
+        // which exp2 turns into an exact 0 -- every row of a block this wave visits has at least one unmasked key (causal:
+        // key0 <= q), so the running maximum is never the mask value and no 0 / 1 ambiguity arises.
         const bool edge = key0 + AT_KB > p.T || (p.causal && key0 + AT_KB - 1 > qt * 32);   // wave-uniform
         if (edge) {
+            const int kmax = (int)((p.causal && q_row < p.T ? q_row : p.T - 1) - key0);     // last admissible key of this row, relative
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long key = key0 + (r & 3) + 8 * (r >> 2) + 4 * ko;
-                const bool ok = key < p.T && (!p.causal || key <= q_row);
-                s[r] = ok ? S[r] * sc : -1.0e30f;
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = S[r] * sc;
+            for (int r = 0; r < 16; ++r)
+                if ((r & 3) + 8 * (r >> 2) + 4 * ko > kmax) S[r] = -1.0e30f;
         }
+        float m_raw = fmaxf(S[0], S[1]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) m_blk = fmaxf(m_blk, s[r]);
-        m_blk = fmaxf(m_blk, __shfl_xor(m_blk, 32, 64));              // lane + 32 holds the other 16 keys of this query
-        const float m_new = fmaxf(m_run, m_blk);
+        for (int r = 2; r < 16; ++r) m_raw = fmaxf(m_raw, S[r]);
+        m_raw = fmaxf(m_raw, __shfl_xor(m_raw, 32, 64));              // lane + 32 holds the other 16 keys of this query
+        const float m_new = fmaxf(m_run, m_raw * sc);
         float psum = 0.0f;
         unsigned pk[8];                                               // P as 16-bit pairs: pk[2 g + e2] = keys 8 g + 4 ko + 2 e2, + 1
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-            const float p0 = s[r] <= -1.0e29f ? 0.0f : __builtin_amdgcn_exp2f(s[r] - m_new);
-            const float p1 = s[r + 1] <= -1.0e29f ? 0.0f : __builtin_amdgcn_exp2f(s[r + 1] - m_new);
-            const unsigned short h0 = Elem<DT>::st(p0), h1 = Elem<DT>::st(p1);
-            psum += Elem<DT>::ld(h0) + Elem<DT>::ld(h1);              // the sum of what the second GEMM actually multiplies
-            pk[r >> 1] = (unsigned)h0 | ((unsigned)h1 << 16);
+            const float p0 = __builtin_amdgcn_exp2f(fmaf(S[r], sc, -m_new));
+            const float p1 = __builtin_amdgcn_exp2f(fmaf(S[r + 1], sc, -m_new));
+            psum += p0 + p1;
+            pk[r >> 1] = AttnCvt<DT>::pack2(p0, p1);
         }
         if (__any(m_new > m_run)) {                                   // some query's maximum moved: rescale the running output
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
