@@ -199,8 +199,8 @@ def full_prefill_report(pf, dev, args):
             return med, p90, len(times), bool(torch.isfinite(fp.logits.float()).all().item())
         med_u, p90_u, _, _ = measure(False)
         med, p90, iters, finite = measure(True)
-        return {"what": "whole synthetic prefill: W4A8 Linears (this repo's kernels) + attention (decoder: mq_attn_prefill on "
-                        "the q|k|v GEMM output in place; ViT, head_dim 80: torch SDPA) and fp16 lm_head on the last position; "
+        return {"what": "whole synthetic prefill: W4A8 Linears (this repo's kernels) + attention (mq_attn_prefill on the q|k|v GEMM "
+                        "outputs in place: decoder head_dim 128 causal, vision tower head_dim 80) and fp16 lm_head on the last position; "
                         "RMS norm -> quantize, SiLU*up / QuickGELU -> Hadamard -> quantize, residual adds (GEMM epilogue) and "
                         "RoPE (one in-place launch) run fused; ttft_ms_median_unfused_glue = the same dataflow with those steps "
                         "as separate torch ops and torch SDPA everywhere",

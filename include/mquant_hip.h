@@ -319,7 +319,8 @@ int mq_attn_prefill_fp8kv(const void *q, int dtype, long T, int heads, int kv_he
                           int causal, void *out, long ldo, void *stream);
 /* The same kernel over UNQUANTISED K / V of q's dtype (the K and V column slices of the fused q|k|v GEMM output, read in
  * place): k / v point at the first K / V head of token 0, a token's kv_heads * head_dim values contiguous, row stride ldkv
- * ELEMENTS.  Replaces repeat_kv + scaled_dot_product_attention in the glue of the whole-prefill report. */
+ * ELEMENTS.  head_dim 128 or 80 (Qwen2-VL's vision tower; rows stay 16-byte aligned: 160 bytes per head).  Replaces
+ * repeat_kv + scaled_dot_product_attention in the glue of the whole-prefill report. */
 int mq_attn_prefill(const void *q, int dtype, long T, int heads, int kv_heads, int head_dim, long ldq,
                     const void *k, const void *v, long ldkv, float softmax_scale, int causal, void *out, long ldo,
                     void *stream);

@@ -60,12 +60,24 @@ template <> struct AttnMma<MQ_BF16> {
     }
 };
 
-constexpr int AT_D = 128;            // head_dim
 constexpr int AT_KB = 32;            // keys per block
-constexpr int AT_VROW = 256;         // bytes per V row in LDS (32-byte groups XOR-ed by key & 3)
-constexpr int AT_KROW = 272;         // 16-bit K / V only: bytes per K row in LDS (256 + 16: 16 consecutive rows hit 16 different 16-byte slots)
-constexpr int AT_WAVE_LDS = 8192 + 32 * AT_KROW;   // per wave: the V tile (8 KiB) [+ the 16-bit K tile] during the loop, its partial O^T (16 KiB) in the merge
 constexpr int AT_STATS = 4 * 32 * 2 * 4;
+// Per head dimension HD (128: Qwen2-VL decoder; 80: its vision tower, 16-bit K / V only): the V tile is [32 keys][HD] 16-bit
+// values, rows padded to whole 32-column d-tiles.  HD = 128: 256-byte rows, 32-byte groups XOR-ed by key & 3; HD = 80: 192-byte
+// rows (the four rows of a transpose read already fall into four different 64-byte bank slots).  The 16-bit K tile has rows
+// of 2 HD + 16 bytes (an odd number of 16-byte slots: conflict-free ds_read_b128 with lane = key).
+template <int HD> struct AttnGeo {
+    static constexpr int NKS = HD / 16;                       // k-steps of the first GEMM
+    static constexpr int NDT = (HD + 31) / 32;                // 32-row d-tiles of the second GEMM
+    static constexpr int HALF = HD / 2;                       // d values of one lane half
+    static constexpr int VROW = NDT * 64;                     // bytes per V row in LDS
+    static constexpr int VBYTES = 32 * VROW;
+    static constexpr int KROW = 2 * HD + 16;
+    static constexpr int OBYTES = NDT * 16 * 64 * 4;          // a wave's partial O^T in the merge
+    static constexpr int LOOP = VBYTES + 32 * KROW;
+    static constexpr int WAVE_LDS = LOOP > OBYTES ? LOOP : OBYTES;
+    static __device__ __forceinline__ int vswz(int key) { return HD == 128 ? (key & 3) << 5 : 0; }
+};
 
 template <int DT> struct AttnCvt;
 typedef float at_v2f __attribute__((ext_vector_type(2)));
@@ -91,10 +103,12 @@ __device__ __forceinline__ void widen16(const v4i w, v4i &a, v4i &b)
 }
 
 // KV8: K / V are e4m3 bytes (widened here); else they are 16-bit values of q's dtype, used as they are.
-template <int DT, bool KV8>
+template <int DT, bool KV8, int HD>
 __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p)
 {
-    constexpr int EB = KV8 ? 1 : 2;                                   // bytes per K / V element
+    typedef AttnGeo<HD> G;
+    static_assert(HD == 128 || (HD == 80 && !KV8), "head dimensions built: 128, and 80 for 16-bit K / V");
+    constexpr int NKS = G::NKS, NDT = G::NDT, AT_D = HD, AT_VROW = G::VROW, AT_KROW = G::KROW, AT_WAVE_LDS = G::WAVE_LDS;
     constexpr int NR = KV8 ? 4 : 8;                                   // 16-byte loads per lane and operand and block
     typedef AttnMma<DT> MM;
     __shared__ __attribute__((aligned(16))) char smem[4 * AT_WAVE_LDS + AT_STATS];
@@ -109,17 +123,17 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p)
     char *vt = smem + wave * AT_WAVE_LDS;                             // this wave's V tile: [32 keys][128 d] 16-bit, row-major, swizzled
 
     // ---- Q^T operand: lane = query; k-step ds covers d = 64 ko + 8 ds .. + 7 (the K operand is loaded to match) ----
-    v4i Qf[8];
+    v4i Qf[NKS];
     {
-        const unsigned short *qp = reinterpret_cast<const unsigned short *>(p.q) + q_row * p.ldq + (long)head * AT_D + 64 * ko;
+        const unsigned short *qp = reinterpret_cast<const unsigned short *>(p.q) + q_row * p.ldq + (long)head * AT_D + G::HALF * ko;
 #pragma unroll
-        for (int ds = 0; ds < 8; ++ds)
+        for (int ds = 0; ds < NKS; ++ds)
             Qf[ds] = (q_row < p.T) ? *reinterpret_cast<const v4i *>(qp + ds * 8) : v4i{0, 0, 0, 0};
     }
 
-    at_v16f O[4];
+    at_v16f O[NDT];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) O[dt][e] = 0.0f;
     float m_run = -1.0e30f, l_run = 0.0f;                              // log2 domain
@@ -133,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p)
     // both tiles are loaded COALESCED -- instruction j = rows 4 j .. 4 j + 3, lane = (row, 16-byte piece) -- and K takes
     // the detour through a padded LDS tile as well.
     const int v_key = KV8 ? lane >> 1 : lane >> 4, v_d = (lane & 1) * 64, pc16 = (lane & 15) * 16;
-    char *kt = vt + 8192;
+    char *kt = vt + G::VBYTES;
     auto load_block = [&](int kb, v4i (&kraw)[NR], v4i (&vraw)[NR]) {
         if (KV8) {
             const long kkey = (long)kb * AT_KB + (lane & 31), vkey = (long)kb * AT_KB + v_key;
@@ -149,8 +163,9 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p)
             for (int j = 0; j < NR; ++j) {
                 const long key = (long)kb * AT_KB + 4 * j + v_key;
                 const long off = key * p.ldkv + (long)kvh * AT_D * 2 + pc16;
-                kraw[j] = key < p.T ? *reinterpret_cast<const v4i *>(p.k + off) : v4i{0, 0, 0, 0};
-                vraw[j] = key < p.T ? *reinterpret_cast<const v4i *>(p.v + off) : v4i{0, 0, 0, 0};
+                const bool ok = key < p.T && pc16 < 2 * HD;               // HD = 80: ten 16-byte pieces per row, lanes 10..15 of a row idle
+                kraw[j] = ok ? *reinterpret_cast<const v4i *>(p.k + off) : v4i{0, 0, 0, 0};
+                vraw[j] = ok ? *reinterpret_cast<const v4i *>(p.v + off) : v4i{0, 0, 0, 0};
             }
         }
     };
@@ -160,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p)
     const int t16 = lane & 15, g16 = (lane >> 4) & 1;
     for (int kb = wave; kb < n_blocks; kb += 4) {
         // ---- K into MFMA operands, V into this wave's LDS tile (e4m3: widened on the way) ------------------------
-        v4i Kf[8];
+        v4i Kf[KV8 ? 8 : 1];
         if (KV8) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) widen16<DT>(kraw[j], Kf[2 * j], Kf[2 * j + 1]);
@@ -176,8 +191,10 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int r = 4 * j + v_key;
-                *reinterpret_cast<v4i *>(kt + r * AT_KROW + pc16) = kraw[j & (NR - 1)];
-                *reinterpret_cast<v4i *>(vt + r * AT_VROW + (pc16 ^ ((r & 3) << 5))) = vraw[j & (NR - 1)];
+                if (pc16 < 2 * HD) {
+                    *reinterpret_cast<v4i *>(kt + r * AT_KROW + pc16) = kraw[j & (NR - 1)];
+                    *reinterpret_cast<v4i *>(vt + r * AT_VROW + (pc16 ^ G::vswz(r))) = vraw[j & (NR - 1)];
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -190,9 +207,9 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p)
 #pragma unroll
         for (int e = 0; e < 16; ++e) S[e] = 0.0f;
 #pragma unroll
-        for (int ds = 0; ds < 8; ++ds) {
-            if (KV8) S = MM::mma(Kf[ds], Qf[ds], S);
-            else S = MM::mma(*reinterpret_cast<const v4i *>(kt + (lane & 31) * AT_KROW + (64 * ko + 8 * ds) * 2), Qf[ds], S);
+        for (int ds = 0; ds < NKS; ++ds) {
+            if (KV8) S = MM::mma(Kf[KV8 ? ds : 0], Qf[ds], S);
+            else S = MM::mma(*reinterpret_cast<const v4i *>(kt + (lane & 31) * AT_KROW + (G::HALF * ko + 8 * ds) * 2), Qf[ds], S);
         }
 
         // ---- online softmax (log2 domain); register r <-> key key0 + (r & 3) + 8 (r >> 2) + 4 ko.  The maximum is taken
@@ -224,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p)
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             l_run *= alpha;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) O[dt][e] *= alpha;
             m_run = m_new;
@@ -242,14 +259,16 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p)
             const auto x1 = __builtin_amdgcn_permlane32_swap(pk[4 * ks + 1], pk[4 * ks + 3], false, false);
             const v4i pf = v4i{(int)x0[0], (int)x1[0], (int)x0[1], (int)x1[1]};
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < NDT; ++dt) {
                 // A operand: row d = 32 dt + (lane & 31), keys 16 ks + 8 ko + 0..7, two transpose reads of [4 k][16 d]
+                // (HD = 80: rows 80..95 of the last tile hold whatever the padding holds; an output row depends on its own
+                //  operand row only, and those rows are never stored)
                 const int d_lane = dt * 32 + 16 * g16 + 4 * (t16 & 3);
                 const int kA = ks * 16 + 8 * ko + (t16 >> 2);
                 const at_v4s r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (at_lds_v4s *)(vt + kA * AT_VROW + ((d_lane * 2) ^ ((kA & 3) << 5))));
+                    (at_lds_v4s *)(vt + kA * AT_VROW + ((d_lane * 2) ^ G::vswz(kA))));
                 const at_v4s r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (at_lds_v4s *)(vt + (kA + 4) * AT_VROW + ((d_lane * 2) ^ (((kA + 4) & 3) << 5))));
+                    (at_lds_v4s *)(vt + (kA + 4) * AT_VROW + ((d_lane * 2) ^ G::vswz(kA + 4))));
                 const v2i lo = __builtin_bit_cast(v2i, r0), hi = __builtin_bit_cast(v2i, r1);
                 O[dt] = MM::mma(v4i{lo[0], lo[1], hi[0], hi[1]}, pf, O[dt]);
             }
@@ -263,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p)
     float *stats = reinterpret_cast<float *>(smem + 4 * AT_WAVE_LDS);
     float *mine = reinterpret_cast<float *>(vt);                      // [dt][e][lane]
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) mine[(dt * 16 + e) * 64 + lane] = O[dt][e];
     if (lane < 32) {
@@ -271,6 +290,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p)
         stats[(wave * 32 + lane) * 2 + 1] = l_run;
     }
     __syncthreads();
+    if (wave >= NDT) return;                                          // HD = 80: three d-tiles, the fourth wave is done
     float M = -1.0e30f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) M = fmaxf(M, stats[(w * 32 + (lane & 31)) * 2]);
@@ -290,6 +310,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p)
         unsigned short *o = reinterpret_cast<unsigned short *>(p.out) + q_row * p.ldo + (long)head * AT_D + wave * 32;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+            if (wave * 32 + 8 * g >= HD) break;                       // HD = 80: the last tile holds d 64 .. 79 only
             v4us h;
 #pragma unroll
             for (int e = 0; e < 4; ++e) h[e] = Elem<DT>::st(acc[4 * g + e] * f);
@@ -300,19 +321,22 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p)
 
 }  // namespace mq
 
-static int attn_launch(const mq::AttnArgs &a, int dtype, bool kv8, void *stream)
+template <int HD, bool KV8>
+static void attn_launch_t(const mq::AttnArgs &a, int dtype, hipStream_t st)
 {
     using namespace mq;
     const dim3 grid((unsigned)((a.T + 31) / 32), (unsigned)a.heads);
+    if (dtype == MQ_F16) hipLaunchKernelGGL((attn_prefill_kernel<MQ_F16, KV8, HD>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_prefill_kernel<MQ_BF16, KV8, HD>), grid, dim3(256), 0, st, a);
+}
+
+static int attn_launch(const mq::AttnArgs &a, int dtype, bool kv8, int head_dim, void *stream)
+{
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (kv8) {
-        if (dtype == MQ_F16) hipLaunchKernelGGL((attn_prefill_kernel<MQ_F16, true>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((attn_prefill_kernel<MQ_BF16, true>), grid, dim3(256), 0, st, a);
-    } else {
-        if (dtype == MQ_F16) hipLaunchKernelGGL((attn_prefill_kernel<MQ_F16, false>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((attn_prefill_kernel<MQ_BF16, false>), grid, dim3(256), 0, st, a);
-    }
-    return check_launch("attn_prefill");
+    if (kv8) attn_launch_t<128, true>(a, dtype, st);
+    else if (head_dim == 128) attn_launch_t<128, false>(a, dtype, st);
+    else attn_launch_t<80, false>(a, dtype, st);
+    return mq::check_launch("attn_prefill");
 }
 
 extern "C" int mq_attn_prefill_fp8kv(const void *q, int dtype, long T, int heads, int kv_heads, int head_dim, long ldq,
@@ -320,17 +344,18 @@ extern "C" int mq_attn_prefill_fp8kv(const void *q, int dtype, long T, int heads
                                      int causal, void *out, long ldo, void *stream)
 {
     using namespace mq;
+    constexpr int D = 128;
     MQ_REQUIRE(dtype == MQ_F16 || dtype == MQ_BF16, "mq_attn_prefill_fp8kv: q / out dtype must be fp16 or bf16 (got %d)", dtype);
     MQ_REQUIRE(T >= 0 && heads >= 1 && kv_heads >= 1 && heads % kv_heads == 0, "mq_attn_prefill_fp8kv: bad head counts %d / %d", heads, kv_heads);
-    MQ_REQUIRE(head_dim == AT_D, "mq_attn_prefill_fp8kv: head_dim %d (this kernel is built for 128)", head_dim);
+    MQ_REQUIRE(head_dim == D, "mq_attn_prefill_fp8kv: head_dim %d (the e4m3 variant is built for 128)", head_dim);
     if (T == 0) return MQ_OK;
     MQ_REQUIRE(q && kv_cache && kv_scale && out, "mq_attn_prefill_fp8kv: null pointer");
-    MQ_REQUIRE(ldq >= (long)heads * AT_D && ldo >= (long)heads * AT_D && ldkv >= 2L * kv_heads * AT_D, "mq_attn_prefill_fp8kv: row strides too short");
+    MQ_REQUIRE(ldq >= (long)heads * D && ldo >= (long)heads * D && ldkv >= 2L * kv_heads * D, "mq_attn_prefill_fp8kv: row strides too short");
     MQ_REQUIRE(((uintptr_t)q) % 16 == 0 && (ldq * 2) % 16 == 0 && ((uintptr_t)kv_cache) % 16 == 0 && ldkv % 16 == 0 &&
                    ((uintptr_t)out) % 8 == 0 && (ldo * 2) % 8 == 0,
                "mq_attn_prefill_fp8kv: q / cache rows must be 16-byte aligned, out rows 8-byte aligned");
-    AttnArgs a{q, kv_cache, kv_cache + (long)kv_heads * AT_D, kv_scale, out, T, ldq, ldkv, ldo, heads, kv_heads, causal ? 1 : 0, softmax_scale};
-    return attn_launch(a, dtype, true, stream);
+    AttnArgs a{q, kv_cache, kv_cache + (long)kv_heads * D, kv_scale, out, T, ldq, ldkv, ldo, heads, kv_heads, causal ? 1 : 0, softmax_scale};
+    return attn_launch(a, dtype, true, head_dim, stream);
 }
 
 extern "C" int mq_attn_prefill(const void *q, int dtype, long T, int heads, int kv_heads, int head_dim, long ldq,
@@ -340,14 +365,15 @@ extern "C" int mq_attn_prefill(const void *q, int dtype, long T, int heads, int 
     using namespace mq;
     MQ_REQUIRE(dtype == MQ_F16 || dtype == MQ_BF16, "mq_attn_prefill: dtype must be fp16 or bf16 (got %d)", dtype);
     MQ_REQUIRE(T >= 0 && heads >= 1 && kv_heads >= 1 && heads % kv_heads == 0, "mq_attn_prefill: bad head counts %d / %d", heads, kv_heads);
-    MQ_REQUIRE(head_dim == AT_D, "mq_attn_prefill: head_dim %d (this kernel is built for 128)", head_dim);
+    MQ_REQUIRE(head_dim == 128 || head_dim == 80, "mq_attn_prefill: head_dim %d (built: 128 and 80)", head_dim);
     if (T == 0) return MQ_OK;
     MQ_REQUIRE(q && k && v && out, "mq_attn_prefill: null pointer");
-    MQ_REQUIRE(ldq >= (long)heads * AT_D && ldo >= (long)heads * AT_D && ldkv >= (long)kv_heads * AT_D, "mq_attn_prefill: row strides too short");
+    const long D = head_dim;
+    MQ_REQUIRE(ldq >= (long)heads * D && ldo >= (long)heads * D && ldkv >= (long)kv_heads * D, "mq_attn_prefill: row strides too short");
     MQ_REQUIRE(((uintptr_t)q) % 16 == 0 && (ldq * 2) % 16 == 0 && ((uintptr_t)k) % 16 == 0 && ((uintptr_t)v) % 16 == 0 && (ldkv * 2) % 16 == 0 &&
                    ((uintptr_t)out) % 8 == 0 && (ldo * 2) % 8 == 0,
                "mq_attn_prefill: q / k / v rows must be 16-byte aligned, out rows 8-byte aligned");
     AttnArgs a{q, reinterpret_cast<const uint8_t *>(k), reinterpret_cast<const uint8_t *>(v), nullptr, out, T, ldq, ldkv * 2, ldo,
                heads, kv_heads, causal ? 1 : 0, softmax_scale};
-    return attn_launch(a, dtype, false, stream);
+    return attn_launch(a, dtype, false, head_dim, stream);
 }

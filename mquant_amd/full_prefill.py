@@ -73,7 +73,9 @@ class FullPrefill:
         #: decoder attention over 16-bit K / V with this repository's kernel (mq_attn_prefill: reads the q / k / v column
         #: slices of the fused GEMM output in place and writes the [T, heads * head_dim] layout o_proj consumes) instead
         #: of torch SDPA; part of the fused glue by default
-        self.attn_kernel = (fused_glue if attn_kernel is None else attn_kernel) and self.g.head_dim == 128
+        own = fused_glue if attn_kernel is None else attn_kernel
+        self.attn_kernel = own and self.g.head_dim == 128
+        self.vis_attn_kernel = own and self.g.vis_dim // self.g.vis_heads in (80, 128)      # the vision tower's (non-causal) attention
         self.kv_cache: List[torch.Tensor] = []
         self.kv_scales: List[torch.Tensor] = []
         assert pf.share_groups, "the chained prefill uses the fused q/k/v and gate/up GEMMs"
@@ -178,9 +180,15 @@ class FullPrefill:
             else:
                 q, k, v = qkv.view(M_VIS, 3, VH, -1).unbind(1)
                 q, k = _rope(q, self.vcos, self.vsin), _rope(k, self.vcos, self.vsin)
-            a = F.scaled_dot_product_attention(q.transpose(0, 1)[None], k.transpose(0, 1)[None],
-                                               v.transpose(0, 1)[None])[0]
-            x = self._lin(by["vis.attn.proj"][i], a.transpose(0, 1).reshape(M_VIS, VD), residual=x)
+            if self.vis_attn_kernel:
+                flat = ops.attn_prefill(q, k, v, causal=False)
+            else:
+                a = F.scaled_dot_product_attention(q.transpose(0, 1)[None], k.transpose(0, 1)[None],
+                                                   v.transpose(0, 1)[None])[0]
+                flat = a.transpose(0, 1).reshape(M_VIS, VD)
+            if i == 0:
+                self.vis_attn_first = flat     # [patches, vis_dim] of the first vision block (tests)
+            x = self._lin(by["vis.attn.proj"][i], flat, residual=x)
             f = self._norm_lin(by["vis.mlp.fc1"][i], x, VD)
             x = self._act_lin(by["vis.mlp.fc2"][i], f, None, ops.ACT_QUICK_GELU, residual=x)   # hidden_act = quick_gelu
         m = F.rms_norm(x, (VD,), eps=1e-6).view(M_MERGED, 4 * VD)

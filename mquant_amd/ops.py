@@ -462,9 +462,9 @@ def attn_prefill_fp8kv(q: torch.Tensor, kv_cache: torch.Tensor, kv_scale: torch.
 @_on_device
 def attn_prefill(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = True, softmax_scale: float = None,
                  out: torch.Tensor = None) -> torch.Tensor:
-    """Prefill attention over unquantised K / V (``mq_attn_prefill``): q [T, heads, 128], k and v [T, kv_heads, 128] of
-    the same fp16 / bf16 dtype and the same token stride (column slices of the fused q|k|v output work in place)
-    -> [T, heads * 128], the layout o_proj consumes."""
+    """Prefill attention over unquantised K / V (``mq_attn_prefill``): q [T, heads, D], k and v [T, kv_heads, D] of the
+    same fp16 / bf16 dtype and the same token stride (column slices of the fused q|k|v output work in place), D = 128
+    (Qwen2-VL decoder) or 80 (its vision tower) -> [T, heads * D], the layout o_proj / proj consumes."""
     _need_cuda(q, k, v, out)
     T, H, D = q.shape
     assert k.shape == v.shape and k.shape[0] == T and k.shape[2] == D and k.dtype == q.dtype and v.dtype == q.dtype

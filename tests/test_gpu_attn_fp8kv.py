@@ -119,14 +119,15 @@ def test_bad_arguments_are_refused():
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("T,H,HKV,causal", [(768, 28, 4, True), (768, 64, 8, True), (1, 4, 2, True), (97, 8, 8, True),
-                                            (500, 8, 2, False), (1500, 4, 1, True)])
-def test_attention_over_unquantised_k_v(dtype, T, H, HKV, causal):
-    """mq_attn_prefill: the same kernel with 16-bit K / V read in place from the fused q|k|v output; checker = float64
-    softmax attention."""
+@pytest.mark.parametrize("T,H,HKV,causal,D", [(768, 28, 4, True, 128), (768, 64, 8, True, 128), (1, 4, 2, True, 128),
+                                              (97, 8, 8, True, 128), (500, 8, 2, False, 128), (1500, 4, 1, True, 128),
+                                              (1024, 16, 16, False, 80), (333, 4, 4, False, 80), (200, 6, 2, True, 80),
+                                              (1, 2, 2, False, 80)])
+def test_attention_over_unquantised_k_v(dtype, T, H, HKV, causal, D):
+    """mq_attn_prefill: the same kernel with 16-bit K / V read in place from the fused q|k|v output (head_dim 128: the
+    decoder; 80: Qwen2-VL's vision tower, non-causal); checker = float64 softmax attention."""
     from mquant_amd import ops
     g = torch.Generator(device=DEV).manual_seed(T + 3 * H)
-    D = 128
     qkv = (torch.randn(T, (H + 2 * HKV) * D, generator=g, device=DEV) * 0.9).to(dtype)
     q = qkv[:, :H * D].view(T, H, D)
     k = qkv[:, H * D:(H + HKV) * D].view(T, HKV, D)

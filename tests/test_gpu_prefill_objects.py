@@ -196,10 +196,12 @@ def test_full_prefill_fused_glue_equals_unfused_glue():
 
 
 def test_full_prefill_with_this_repositorys_attention_kernel():
-    """The decoder attention of the chained prefill through mq_attn_prefill (q / k / v read in place from the fused GEMM
-    output) against torch SDPA in the same prefill: the first decoder layer sees identical inputs, so its attention output
-    is held to half-precision rounding; the logits of the random 2-layer stack stay correlated (a random stack amplifies
-    any rounding difference and flips static int8 levels on the way)."""
+    """The attention of the chained prefill through mq_attn_prefill -- vision tower (head_dim 80, non-causal) and decoder
+    (128, causal), q / k / v read in place from the fused GEMM outputs -- against torch SDPA in the same prefill.  The first
+    vision block sees identical inputs in both runs, so its attention output is held to half-precision rounding; the first
+    decoder layer already sees activations that went through a vision block, the merger and static int8 quantizers with
+    that rounding difference in them (a few levels flip), so it is held to 3 %; the logits of the random stack stay
+    correlated."""
     from mquant_amd import workload
     from mquant_amd.full_prefill import FullPrefill
     specs = workload._qwen2vl_7b_specs(True, 1, 2)
@@ -207,12 +209,14 @@ def test_full_prefill_with_this_repositorys_attention_kernel():
     outs = []
     for own in (False, True):
         fp = FullPrefill(pf, fused_glue=True, attn_kernel=own)
-        assert fp.attn_kernel == own
+        assert fp.attn_kernel == own and fp.vis_attn_kernel == own
         fp.calibrate()
-        outs.append((fp.step().float().clone(), fp.attn_first.float().clone()))
+        outs.append((fp.step().float().clone(), fp.attn_first.float().clone(), fp.vis_attn_first.float().clone()))
         fp.restore_hot_path_scales()
-    (la, aa), (lb, ab) = outs
+    (la, aa, va), (lb, ab, vb) = outs
     assert torch.isfinite(lb).all()
-    assert float((aa - ab).abs().max() / aa.abs().max()) < 5e-3
-    assert float(torch.nn.functional.cosine_similarity(aa.flatten(), ab.flatten(), dim=0)) > 0.99999
+    assert float((va - vb).abs().max() / va.abs().max()) < 5e-3
+    assert float(torch.nn.functional.cosine_similarity(va.flatten(), vb.flatten(), dim=0)) > 0.99999
+    assert float((aa - ab).norm() / aa.norm()) < 3e-2
+    assert float(torch.nn.functional.cosine_similarity(aa.flatten(), ab.flatten(), dim=0)) > 0.9995
     assert float(torch.nn.functional.cosine_similarity(la.flatten(), lb.flatten(), dim=0)) > 0.99

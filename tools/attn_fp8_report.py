@@ -68,3 +68,18 @@ for name, T, H, HKV in (("Qwen2-VL-7B", 768, 28, 4), ("Qwen2-VL-72B", 768, 64, 8
     print(f"  mq_kv_dequant_fp8 + torch SDPA (fp16 copy)    : {t_deq:8.2f} us")
     print(f"  torch SDPA on the unquantised fp16 K/V        : {t_f16:8.2f} us")
     print(f"  max |ours - dequant+SDPA| / max|.| = {float((a - b).abs().max() / b.abs().max()):.2e}")
+
+
+# the vision tower's attention: 1024 patches, 16 heads of 80, non-causal (q / k / v = the three column blocks of the qkv GEMM output)
+T, H, D = 1024, 16, 80
+qkv = torch.randn(T, 3 * H * D, device=dev).half()
+q, k, v = qkv.view(T, 3, H, D).unbind(1)
+out = torch.empty(T, H * D, device=dev, dtype=torch.float16)
+t_own = timed(lambda: ops.attn_prefill(q, k, v, causal=False, out=out))
+t_sdpa = timed(lambda: F.scaled_dot_product_attention(q.transpose(0, 1)[None], k.transpose(0, 1)[None], v.transpose(0, 1)[None])[0].transpose(0, 1).reshape(T, H * D))
+a = ops.attn_prefill(q, k, v, causal=False).float()
+b = F.scaled_dot_product_attention(q.transpose(0, 1)[None], k.transpose(0, 1)[None], v.transpose(0, 1)[None])[0].transpose(0, 1).reshape(T, H * D).float()
+print(f"Qwen2-VL vision tower: T={T} heads={H} head_dim={D} non-causal, fp16")
+print(f"  mq_attn_prefill                               : {t_own:8.2f} us   ({4.0 * T * T * D * H / t_own / 1e6:6.1f} TFLOP/s)")
+print(f"  torch SDPA (+ the transpose copy proj needs)  : {t_sdpa:8.2f} us")
+print(f"  max |ours - SDPA| / max|.| = {float((a - b).abs().max() / b.abs().max()):.2e}")
