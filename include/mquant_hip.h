@@ -324,6 +324,15 @@ int mq_attn_prefill_fp8kv(const void *q, int dtype, long T, int heads, int kv_he
 int mq_attn_prefill(const void *q, int dtype, long T, int heads, int kv_heads, int head_dim, long ldq,
                     const void *k, const void *v, long ldkv, float softmax_scale, int causal, void *out, long ldo,
                     void *stream);
+/* Either attention with the NEXT Linear's static int8 activation quantizer fused into its store (the o_proj /
+ * proj input): out[t][c] = clamp(rint(cast_dtype(o[t][c]) / s_t), -128, 127), s_t = scale1 where row_sel[t] != 0 else
+ * scale0 -- the bytes mq_quantize_act_i8 writes for the 16-bit attention output, in the same activation layout (K_pad ==
+ * heads * head_dim, ldo = MQ_LD_TILED or a row stride).  kv_cache != NULL: the e4m3 variant (k, v, ldkv ignored); else the
+ * 16-bit variant (kv_cache, ld_cache, kv_scale ignored). */
+int mq_attn_prefill_quant_i8(const void *q, int dtype, long T, int heads, int kv_heads, int head_dim, long ldq,
+                             const void *k, const void *v, long ldkv, const uint8_t *kv_cache, long ld_cache,
+                             const float *kv_scale, float softmax_scale, int causal, float scale0, float scale1,
+                             const uint8_t *row_sel, int8_t *out, long K_pad, long ldo, void *stream);
 
 
 /* ---------------------------------------------------------------------------

@@ -44,6 +44,13 @@ struct AttnArgs {
     long T, ldq, ldkv, ldo;
     int heads, kv_heads, causal;
     float softmax_scale;
+    // optional: emit the int8 levels of the NEXT Linear's static activation quantizer instead of 16-bit values (the
+    // o_proj / proj input): q = clamp(rint(cast(o) / s), -128, 127), s = qs1 where row_sel[row] != 0 else qs0, in the
+    // activation layout (row-major with leading dimension q_ld, or MQ_LD_TILED) -- what act_quant_kernel writes for `out`
+    int8_t *qout;
+    long q_kpad, q_ld;
+    float qs0, qs1;
+    const uint8_t *row_sel;
 };
 
 template <int DT> struct AttnMma;
@@ -306,7 +313,23 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p)
         for (int e = 0; e < 16; ++e) acc[e] += src[e * 64] * f;
     }
     const float f = L > 0.0f ? s_v / L : 0.0f;
-    if (q_row < p.T) {
+    if (q_row < p.T && p.qout) {
+        const float s = (p.row_sel && p.row_sel[q_row]) ? p.qs1 : p.qs0;
+        const float inv = 1.0f / s;
+        const bool rcp = quant_rcp_ok(s);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (wave * 32 + 8 * g >= HD) break;
+            float v4[4];
+            int q4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v4[e] = Elem<DT>::rnd(acc[4 * g + e] * f);      // the 16-bit value the unfused path stores
+            quant_levels<4>(v4, s, inv, rcp, -128.0f, 127.0f, q4);
+            const long col = (long)head * AT_D + wave * 32 + 8 * g + 4 * ko;
+            *reinterpret_cast<unsigned *>(p.qout + act_offset(q_row, col, p.q_kpad, p.q_ld)) =
+                (q4[0] & 0xff) | ((q4[1] & 0xff) << 8) | ((q4[2] & 0xff) << 16) | ((unsigned)(q4[3] & 0xff) << 24);
+        }
+    } else if (q_row < p.T) {
         unsigned short *o = reinterpret_cast<unsigned short *>(p.out) + q_row * p.ldo + (long)head * AT_D + wave * 32;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -354,7 +377,8 @@ extern "C" int mq_attn_prefill_fp8kv(const void *q, int dtype, long T, int heads
     MQ_REQUIRE(((uintptr_t)q) % 16 == 0 && (ldq * 2) % 16 == 0 && ((uintptr_t)kv_cache) % 16 == 0 && ldkv % 16 == 0 &&
                    ((uintptr_t)out) % 8 == 0 && (ldo * 2) % 8 == 0,
                "mq_attn_prefill_fp8kv: q / cache rows must be 16-byte aligned, out rows 8-byte aligned");
-    AttnArgs a{q, kv_cache, kv_cache + (long)kv_heads * D, kv_scale, out, T, ldq, ldkv, ldo, heads, kv_heads, causal ? 1 : 0, softmax_scale};
+    AttnArgs a{q, kv_cache, kv_cache + (long)kv_heads * D, kv_scale, out, T, ldq, ldkv, ldo, heads, kv_heads, causal ? 1 : 0, softmax_scale,
+               nullptr, 0, 0, 1.0f, 1.0f, nullptr};
     return attn_launch(a, dtype, true, head_dim, stream);
 }
 
@@ -374,6 +398,36 @@ extern "C" int mq_attn_prefill(const void *q, int dtype, long T, int heads, int 
                    ((uintptr_t)out) % 8 == 0 && (ldo * 2) % 8 == 0,
                "mq_attn_prefill: q / k / v rows must be 16-byte aligned, out rows 8-byte aligned");
     AttnArgs a{q, reinterpret_cast<const uint8_t *>(k), reinterpret_cast<const uint8_t *>(v), nullptr, out, T, ldq, ldkv * 2, ldo,
-               heads, kv_heads, causal ? 1 : 0, softmax_scale};
+               heads, kv_heads, causal ? 1 : 0, softmax_scale, nullptr, 0, 0, 1.0f, 1.0f, nullptr};
     return attn_launch(a, dtype, false, head_dim, stream);
+}
+
+extern "C" int mq_attn_prefill_quant_i8(const void *q, int dtype, long T, int heads, int kv_heads, int head_dim, long ldq,
+                                        const void *k, const void *v, long ldkv, const uint8_t *kv_cache, long ld_cache,
+                                        const float *kv_scale, float softmax_scale, int causal, float scale0, float scale1,
+                                        const uint8_t *row_sel, int8_t *out, long K_pad, long ldo, void *stream)
+{
+    using namespace mq;
+    MQ_REQUIRE(dtype == MQ_F16 || dtype == MQ_BF16, "mq_attn_prefill_quant_i8: dtype must be fp16 or bf16 (got %d)", dtype);
+    MQ_REQUIRE(T >= 0 && heads >= 1 && kv_heads >= 1 && heads % kv_heads == 0, "mq_attn_prefill_quant_i8: bad head counts %d / %d", heads, kv_heads);
+    const bool kv8 = kv_cache != nullptr;
+    MQ_REQUIRE(head_dim == 128 || (head_dim == 80 && !kv8), "mq_attn_prefill_quant_i8: head_dim %d (built: 128, and 80 for 16-bit K / V)", head_dim);
+    if (T == 0) return MQ_OK;
+    const long D = head_dim;
+    MQ_REQUIRE(q && out && (kv8 ? kv_scale != nullptr : (k && v)), "mq_attn_prefill_quant_i8: null pointer");
+    MQ_REQUIRE(ldq >= (long)heads * D && ((uintptr_t)q) % 16 == 0 && (ldq * 2) % 16 == 0, "mq_attn_prefill_quant_i8: bad q geometry");
+    MQ_REQUIRE(K_pad == (long)heads * D && K_pad % 64 == 0 && ((uintptr_t)out) % 16 == 0 && (ldo == MQ_LD_TILED || (ldo >= K_pad && ldo % 4 == 0)),
+               "mq_attn_prefill_quant_i8: out must hold exactly heads * head_dim = %ld columns (K_pad %ld, a multiple of 64), ldo = MQ_LD_TILED or a row stride", (long)heads * D, K_pad);
+    MQ_REQUIRE(scale0 > 0.0f && scale1 > 0.0f, "mq_attn_prefill_quant_i8: scales must be positive");
+    AttnArgs a{};
+    a.q = q; a.out = nullptr; a.T = T; a.ldq = ldq; a.ldo = 0; a.heads = heads; a.kv_heads = kv_heads; a.causal = causal ? 1 : 0;
+    a.softmax_scale = softmax_scale; a.qout = out; a.q_kpad = K_pad; a.q_ld = ldo; a.qs0 = scale0; a.qs1 = scale1; a.row_sel = row_sel;
+    if (kv8) {
+        MQ_REQUIRE(ld_cache >= 2L * kv_heads * D && ((uintptr_t)kv_cache) % 16 == 0 && ld_cache % 16 == 0, "mq_attn_prefill_quant_i8: bad cache geometry");
+        a.k = kv_cache; a.v = kv_cache + (long)kv_heads * D; a.kv_scale = kv_scale; a.ldkv = ld_cache;
+    } else {
+        MQ_REQUIRE(ldkv >= (long)kv_heads * D && ((uintptr_t)k) % 16 == 0 && ((uintptr_t)v) % 16 == 0 && (ldkv * 2) % 16 == 0, "mq_attn_prefill_quant_i8: bad k / v geometry");
+        a.k = reinterpret_cast<const uint8_t *>(k); a.v = reinterpret_cast<const uint8_t *>(v); a.kv_scale = nullptr; a.ldkv = ldkv * 2;
+    }
+    return attn_launch(a, dtype, kv8, head_dim, stream);
 }

@@ -128,6 +128,10 @@ class W4A8Linear:
                                 out=a, x0_out=x0)
         return a, x0
 
+    def act_buffer(self, M: int):
+        """The workspace destination a quantizer of this layer's input writes (for producers that quantize themselves)."""
+        return WORKSPACE.act(self.w_img.device, M, self.K_pad)
+
     def quantize_rmsn(self, x: torch.Tensor, mean_dim: float, eps: float,
                       row_sel: Optional[torch.Tensor] = None):
         """Weight-less RMS norm + quantize in one launch (layers without an online Hadamard)."""

@@ -74,6 +74,9 @@ class FullPrefill:
         #: slices of the fused GEMM output in place and writes the [T, heads * head_dim] layout o_proj consumes) instead
         #: of torch SDPA; part of the fused glue by default
         own = fused_glue if attn_kernel is None else attn_kernel
+        #: with the attention kernels: emit the int8 levels of the o_proj / proj input straight from the attention store
+        #: (mq_attn_prefill_quant_i8) instead of a 16-bit tensor plus a quantize launch
+        self.attn_quant = own
         self.attn_kernel = own and self.g.head_dim == 128
         self.vis_attn_kernel = own and self.g.vis_dim // self.g.vis_heads in (80, 128)      # the vision tower's (non-causal) attention
         self.kv_cache: List[torch.Tensor] = []
@@ -180,6 +183,15 @@ class FullPrefill:
             else:
                 q, k, v = qkv.view(M_VIS, 3, VH, -1).unbind(1)
                 q, k = _rope(q, self.vcos, self.vsin), _rope(k, self.vcos, self.vsin)
+            Lp = by["vis.attn.proj"][i]
+            if (self.vis_attn_kernel and self.fused_glue and self.attn_quant and not self.calibrating and i > 0
+                    and Lp.lin.had is None and not Lp.lin.split):
+                qa = Lp.lin.act_buffer(M_VIS)
+                ops.attn_prefill_quant_i8(q, Lp.lin.s_x0, Lp.lin.s_x1, k=k, v=v, causal=False, row_sel=Lp.row_sel, out=qa)
+                x = Lp.lin.gemm_residual(qa, None, x, Lp.row_sel)
+                f = self._norm_lin(by["vis.mlp.fc1"][i], x, VD)
+                x = self._act_lin(by["vis.mlp.fc2"][i], f, None, ops.ACT_QUICK_GELU, residual=x)
+                continue
             if self.vis_attn_kernel:
                 flat = ops.attn_prefill(q, k, v, causal=False)
             else:
@@ -217,12 +229,31 @@ class FullPrefill:
                         self.kv_cache.append(torch.empty((T, 2 * KVH, HD), dtype=torch.float8_e4m3fn, device=self.dev))
                     else:
                         self.kv_scales[i] = ops.kv_scale_from_absmax(kv_cols)
+            Lo = by["llm.o_proj"][i]
+            # attention -> o_proj's static quantizer in ONE launch (the int8 levels of the attention output, tiled): fused
+            # glue, outside calibration, o_proj without an online Hadamard / split
+            quant_out = (self.fused_glue and self.attn_quant and not self.calibrating and i > 0
+                         and Lo.lin.had is None and not Lo.lin.split)
             if self.kv_fp8 and self.attn_fp8 and not self.calibrating:
                 # write the cache (e4m3, static per-head scales); the attention kernel reads those bytes
                 ops.kv_quant_fp8(kv_cols, self.kv_scales[i], out=self.kv_cache[i])
-                flat = ops.attn_prefill_fp8kv(q, self.kv_cache[i], self.kv_scales[i], causal=True)      # [T, heads * head_dim]
-                a = flat.view(T, H, HD).transpose(0, 1)
+                if quant_out:
+                    qa = Lo.lin.act_buffer(T)
+                    ops.attn_prefill_quant_i8(q, Lo.lin.s_x0, Lo.lin.s_x1, kv_cache=self.kv_cache[i], kv_scale=self.kv_scales[i],
+                                              causal=True, row_sel=Lo.row_sel, out=qa)
+                    hdn = Lo.lin.gemm_residual(qa, None, hdn, Lo.row_sel)
+                else:
+                    flat = ops.attn_prefill_fp8kv(q, self.kv_cache[i], self.kv_scales[i], causal=True)      # [T, heads * head_dim]
+                    a = flat.view(T, H, HD).transpose(0, 1)
+            elif quant_out and self.attn_kernel:
+                if self.kv_fp8:
+                    _, hat = ops.kv_quant_fp8_readback(kv_cols, self.kv_scales[i], out=self.kv_cache[i])
+                    k, v = hat[:, :KVH], hat[:, KVH:]
+                qa = Lo.lin.act_buffer(T)
+                ops.attn_prefill_quant_i8(q, Lo.lin.s_x0, Lo.lin.s_x1, k=k, v=v, causal=True, row_sel=Lo.row_sel, out=qa)
+                hdn = Lo.lin.gemm_residual(qa, None, hdn, Lo.row_sel)
             else:
+                quant_out = False
                 if self.kv_fp8:
                     # write the cache and attend over what was written, read back by the same launch
                     _, hat = ops.kv_quant_fp8_readback(kv_cols, self.kv_scales[i], out=self.kv_cache[i])
@@ -235,8 +266,9 @@ class FullPrefill:
                                                        v.transpose(0, 1)[None], is_causal=True, enable_gqa=True)[0]
                     flat = a.transpose(0, 1).reshape(T, D)
             if i == 0:
-                self.attn_first = a            # [heads, T, head_dim] of the first decoder layer (tests)
-            hdn = self._lin(by["llm.o_proj"][i], flat, residual=hdn)
+                self.attn_first = a            # [heads, T, head_dim] of the first decoder layer (tests; layer 0 keeps the 16-bit output)
+            if not quant_out:
+                hdn = self._lin(Lo, flat, residual=hdn)
             gu = self._norm_lin(by["llm.gate_proj"][i], hdn, D)    # fused gate|up GEMM
             half = gu.shape[1] // 2
             hdn = self._act_lin(by["llm.down_proj"][i], gu[:, :half], gu[:, half:], ops.ACT_SILU_MUL, residual=hdn)

@@ -484,6 +484,38 @@ def attn_prefill(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool
     return out
 
 
+@_on_device
+def attn_prefill_quant_i8(q: torch.Tensor, scale0: float, scale1: Optional[float] = None, *, k: torch.Tensor = None,
+                          v: torch.Tensor = None, kv_cache: torch.Tensor = None, kv_scale: torch.Tensor = None,
+                          causal: bool = True, softmax_scale: float = None, row_sel: Optional[torch.Tensor] = None,
+                          out=None, tiled: bool = False):
+    """``attn_prefill`` (k, v) or ``attn_prefill_fp8kv`` (kv_cache, kv_scale) with the next Linear's static int8 quantizer
+    fused into the store (``mq_attn_prefill_quant_i8``): returns the int8 activations ``quantize_act_i8`` would produce
+    from the 16-bit attention output ([T, heads * D] row-major, or a ``TiledAct``)."""
+    _need_cuda(q, k, v, kv_cache, kv_scale, row_sel, out)
+    T, H, D = q.shape
+    assert q.stride(2) == 1 and q.stride(1) == D
+    out, optr, K_pad, ldo = _out_act(out, tiled, T, H * D, q.device)
+    if softmax_scale is None:
+        softmax_scale = D ** -0.5
+    if kv_cache is not None:
+        assert kv_cache.dtype == torch.float8_e4m3fn and kv_cache.shape[0] == T and kv_cache.shape[2] == D
+        assert kv_cache.stride(2) == 1 and kv_cache.stride(1) == D and kv_scale.dtype == torch.float32
+        hkv, kp, vp, ldkv = kv_cache.shape[1] // 2, None, None, 0
+        cp, ldc, sp = kv_cache.data_ptr(), kv_cache.stride(0) if T > 1 else kv_cache.shape[1] * D, kv_scale.data_ptr()
+    else:
+        assert k.shape == v.shape and k.shape[0] == T and k.shape[2] == D and k.dtype == q.dtype and v.dtype == q.dtype
+        for t in (k, v):
+            assert t.stride(2) == 1 and t.stride(1) == D
+        assert T <= 1 or k.stride(0) == v.stride(0)
+        hkv, kp, vp, ldkv = k.shape[1], k.data_ptr(), v.data_ptr(), k.stride(0) if T > 1 else k.shape[1] * D
+        cp, ldc, sp = None, 0, None
+    call("mq_attn_prefill_quant_i8", q.data_ptr(), dtype_code(q.dtype), T, H, hkv, D, q.stride(0) if T > 1 else H * D,
+         kp, vp, ldkv, cp, ldc, sp, float(softmax_scale), 1 if causal else 0, float(scale0),
+         float(scale0 if scale1 is None else scale1), _ptr(row_sel), optr, K_pad, ldo, _stream())
+    return out
+
+
 def kv_scale_from_absmax(kv: torch.Tensor) -> torch.Tensor:
     """Static per-head scale from calibration activations [T, kv_heads, head_dim]: absmax / 448."""
     return (kv.float().abs().amax(dim=(0, 2)).clamp_min(1e-8) / FP8_E4M3_MAX).contiguous()

@@ -146,3 +146,39 @@ def test_attention_over_unquantised_k_v(dtype, T, H, HKV, causal, D):
     o = F.scaled_dot_product_attention(q.permute(1, 0, 2)[None], k.permute(1, 0, 2)[None], v.permute(1, 0, 2)[None],
                                        is_causal=causal, enable_gqa=True)[0].permute(1, 0, 2).reshape(T, H * D)
     assert float((got.float() - o.float()).abs().max() / o.float().abs().max()) < 2 * tol
+
+
+@pytest.mark.parametrize("variant,T,H,HKV,D,causal", [("fp16", 768, 28, 4, 128, True), ("fp8", 768, 28, 4, 128, True),
+                                                      ("fp16", 1024, 16, 16, 80, False), ("fp16", 77, 4, 2, 128, True),
+                                                      ("fp8", 130, 8, 8, 128, False), ("bf16", 300, 8, 4, 80, True)])
+@pytest.mark.parametrize("tiled", [True, False])
+def test_fused_output_quantizer_equals_attention_then_quantize(variant, T, H, HKV, D, causal, tiled):
+    """mq_attn_prefill_quant_i8: the int8 levels of the next Linear's static quantizer straight from the attention store
+    -- bit for bit what mq_quantize_act_i8 makes of the 16-bit attention output, two scales selected by the token-type
+    mask (MSQ), tiled and row-major destinations."""
+    from mquant_amd import ops
+    dtype = torch.bfloat16 if variant == "bf16" else torch.float16
+    g = torch.Generator(device=DEV).manual_seed(T + H + D)
+    qkv = (torch.randn(T, (H + 2 * HKV) * D, generator=g, device=DEV) * 0.9).to(dtype)
+    q = qkv[:, :H * D].view(T, H, D)
+    k = qkv[:, H * D:(H + HKV) * D].view(T, HKV, D)
+    v = qkv[:, (H + HKV) * D:].view(T, HKV, D)
+    sel = (torch.arange(T, device=DEV) % 3 == 1).to(torch.uint8)
+    if variant == "fp8":
+        kv = qkv[:, H * D:].view(T, 2 * HKV, D)
+        scale = ops.kv_scale_from_absmax(kv)
+        cache = ops.kv_quant_fp8(kv, scale)
+        o = ops.attn_prefill_fp8kv(q, cache, scale, causal=causal)
+        kw = dict(kv_cache=cache, kv_scale=scale)
+    else:
+        o = ops.attn_prefill(q, k, v, causal=causal)
+        kw = dict(k=k, v=v)
+    s0 = float(o.float().abs().max()) / 127.0 * 0.8          # some rows saturate
+    s1 = 0.37 * s0
+    want, _ = ops.quantize_act_i8(o, s0, s1, row_sel=sel, tiled=tiled)
+    got = ops.attn_prefill_quant_i8(q, s0, s1, causal=causal, row_sel=sel, tiled=tiled, **kw)
+    a = got.to_rows() if tiled else got
+    b = want.to_rows() if tiled else want
+    assert a.shape == b.shape == (T, H * D)
+    assert torch.equal(a, b)
+    assert int(a.abs().max()) >= 127

@@ -220,3 +220,24 @@ def test_full_prefill_with_this_repositorys_attention_kernel():
     assert float((aa - ab).norm() / aa.norm()) < 3e-2
     assert float(torch.nn.functional.cosine_similarity(aa.flatten(), ab.flatten(), dim=0)) > 0.9995
     assert float(torch.nn.functional.cosine_similarity(la.flatten(), lb.flatten(), dim=0)) > 0.99
+
+
+def test_attention_with_the_fused_output_quantizer_changes_no_bit_of_the_prefill():
+    """FullPrefill.attn_quant: from the second block / layer on the attention kernels hand o_proj / proj their int8
+    activations directly (mq_attn_prefill_quant_i8).  Same 16-bit rounding, same quantizer arithmetic: the logits must be
+    IDENTICAL to the run that stores 16-bit attention outputs and quantizes them in a separate launch."""
+    from mquant_amd import workload
+    from mquant_amd.full_prefill import FullPrefill
+    specs = workload._qwen2vl_7b_specs(True, 3, 3)
+    pf = workload.Prefill(specs, device=DEV, share_groups=True)
+    outs = []
+    for fused_q in (False, True):
+        for kv8 in (False, True):
+            fp = FullPrefill(pf, fused_glue=True, kv_fp8=kv8, attn_fp8=kv8)
+            fp.attn_quant = fused_q
+            fp.calibrate()
+            outs.append(fp.step().float().clone())
+            fp.restore_hot_path_scales()
+    assert torch.isfinite(outs[0]).all() and float(outs[0].abs().max()) > 0
+    assert torch.equal(outs[0], outs[2])      # 16-bit K / V
+    assert torch.equal(outs[1], outs[3])      # fp8 cache, attention over the e4m3 bytes
