@@ -440,6 +440,8 @@ int mq_act_rowsum_scaled(const int8_t *a, long lda, long M, long K_pad, float s_
  * force the number of m-groups of the XCD mapping, 0 = automatic) for the GEMM calls the CALLING THREAD
  * makes afterwards (thread-local state; other threads keep the heuristic). */
 int mq_gemm_debug_force(int tile, int splits);
+/* TEST-ONLY: the plan (tile id, split-K factor) the dispatcher takes for a shape; host arithmetic only. */
+int mq_gemm_debug_plan(long M, long N, long K_pad, int w_bits, int a_tiled, int have_workspace, int *tile, int *splits);
 
 /* ---------------------------------------------------------------------------
  * Min/max observer reduction.  Replaces the two reductions of

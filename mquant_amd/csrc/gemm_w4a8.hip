@@ -510,6 +510,17 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
         // buffering of the fragments) is ~5 % ahead of the 16-wave one (104-107 vs 110-112 us), with
         // row-major activations it is behind
         pl.tile = (w4 && a_tiled) ? 13 : 3;
+        // ... unless a handful of 256 x 256 tiles spill into one more round (Qwen-VL w1|w2: 258 tiles; InternVL2 wqkv at
+        // batch 4: 288): a round of the 256^2 kernel is ~57 us whether 2 or 256 tiles run in it.  Then the 192 x 128
+        // wave-specialised tile is compared on measured per-tile times (us: f0 + c per 128-deep k-step; a partial last
+        // round costs 0.8 .. 1.0 of a full one; profiles/r3_gemm_plan_spill.txt): 101 -> 78 us and 108 -> 82 us there.
+        const long full = t256 / 256, rem = t256 % 256;
+        if (w4 && a_tiled && full >= 1 && rem > 0 && rem < 64) {
+            auto rounds = [](long tiles) { const long f = tiles / 256, r = tiles % 256; return (float)f + (r ? 0.8f + 0.2f * (float)r / 256.0f : 0.0f); };
+            const float t_pipe = rounds(t256) * (4.0f + 1.65f * (float)kps);
+            const float t_192 = rounds(ceil_div(M, 192) * ceil_div(N, 128)) * (7.8f + 0.55f * (float)kps);
+            if (t_192 < t_pipe) pl.tile = 42;
+        }
     } else if (a_tiled && best >= 0 && ceil_div(M, 96) * ceil_div(N, 128) >= 128) {
         // enough 96..192 x 128 tiles for most CUs: the wave-specialised kernel walks the whole reduction
         // (down_proj, K = 19968: 64 us against 60 + 14 us for split-K partials plus the reduce kernel)
@@ -653,6 +664,16 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
 }
 
 }  // namespace mq
+
+// TEST-ONLY: the (tile, split-K) plan the dispatcher would take for a shape (host arithmetic, no device needed).
+extern "C" int mq_gemm_debug_plan(long M, long N, long K_pad, int w_bits, int a_tiled, int have_workspace, int *tile, int *splits)
+{
+    if (!tile || !splits || K_pad <= 0 || K_pad % 128) return mq::fail(MQ_EINVAL, "mq_gemm_debug_plan: bad arguments");
+    const mq::Plan pl = mq::make_plan(M, N, K_pad, have_workspace != 0, have_workspace ? ((size_t)1 << 40) : 0, -1, 0, w_bits == 4, a_tiled != 0);
+    *tile = pl.tile;
+    *splits = pl.splits;
+    return MQ_OK;
+}
 
 extern "C" int mq_gemm_w4a8(const int8_t *a, long lda, const void *w, int w_bits, long M, long N,
                             long K_pad, float s_x0, float s_x1, const uint8_t *row_sel,

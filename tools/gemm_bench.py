@@ -17,6 +17,14 @@ SHAPES = {
     "vis.fc2": (1024, 1280, 5120), "llm.q/o": (768, 3584, 3584), "llm.kv": (768, 512, 3584),
     "llm.qkv*": (768, 4608, 3584), "llm.gate": (768, 18944, 3584), "llm.gate_up*": (768, 37888, 3584),
     "llm.down": (768, 3584, 19968),
+    # the other BASELINE configurations (workload.py): Qwen-VL-7B, InternVL2-8B (batch 1 and 4), Qwen2-VL-72B
+    "qvl.in_proj": (1024, 4992, 1664), "qvl.out_proj": (1024, 1664, 1664), "qvl.c_fc": (1024, 8192, 1664),
+    "qvl.vc_proj": (1024, 1664, 8192), "qvl.c_attn": (768, 12288, 4096), "qvl.c_proj": (768, 4096, 4096),
+    "qvl.w1w2*": (768, 22016, 4096), "qvl.down": (768, 4096, 11008),
+    "ivl.qkv": (1025, 3072, 1024), "ivl.proj": (1025, 1024, 1024), "ivl.fc1": (1025, 4096, 1024), "ivl.fc2": (1025, 1024, 4096),
+    "ivl.wqkv": (768, 6144, 4096), "ivl.wo": (768, 4096, 4096), "ivl.w1w3*": (768, 28672, 4096), "ivl.w2": (768, 4096, 14336),
+    "ivl4.wqkv": (3072, 6144, 4096), "ivl4.wo": (3072, 4096, 4096), "ivl4.w1w3*": (3072, 28672, 4096), "ivl4.w2": (3072, 4096, 14336),
+    "72b.qkv*": (768, 10240, 8192), "72b.o": (768, 8192, 8192), "72b.gate_up*": (768, 59136, 8192), "72b.down": (768, 8192, 30720),
 }
 
 
