@@ -1,8 +1,13 @@
-// attn_fp8kv.hip -- prefill attention that consumes the fp8 (OCP e4m3fn) KV cache DIRECTLY: K and V leave HBM as
-// one byte per element and are widened inside the kernel; there is no dequantise-on-read pass and no fp16 copy of
-// the cache in HBM (BASELINE configuration 5).  The reference has neither a KV-cache quantizer nor an
-// attention kernel of its own (fake_quant/utils.py:220-267 are flags of an unused parser; attention is HF model
-// code): PARITY UNPINNED -- the checker is softmax attention over the dequantised cache, restated in the test.
+// attn_prefill.hip -- prefill attention, three instantiations of one kernel:
+//   * mq_attn_prefill_fp8kv: consumes the fp8 (OCP e4m3fn) KV cache DIRECTLY -- K and V leave HBM as one byte per element
+//     and are widened inside the kernel; no dequantise-on-read pass, no fp16 copy of the cache in HBM (SURVEY 8(f4),
+//     BASELINE configuration 5);
+//   * mq_attn_prefill: the same dataflow over unquantised 16-bit K / V, head_dim 128 (decoder, causal) or 80 (Qwen2-VL's
+//     vision tower), q / k / v read in place from the fused q|k|v GEMM output (glue of the whole-prefill report, 8(f3));
+//   * mq_attn_prefill_quant_i8: either of them with the NEXT Linear's static int8 activation quantizer fused into the store.
+// The reference has neither a KV-cache quantizer nor an attention kernel of its own (fake_quant/utils.py:220-267 are flags
+// of an unused parser; attention is HF model code): PARITY UNPINNED -- the checker is float64 softmax attention (over the
+// dequantised cache for the e4m3 variant), restated in tests/test_gpu_attn_prefill.py.
 //
 //     S[q][k] = (sum_d Q[q][d] * K8[k][d]) * s_k[kvh] * softmax_scale        (causal: k <= q)
 //     O[q][d] = (sum_k softmax_k(S)[q][k] * V8[k][d]) * s_v[kvh]
