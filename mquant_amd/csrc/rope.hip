@@ -33,6 +33,39 @@ __global__ __launch_bounds__(256) void rope_kernel(void *x_, long T, int heads, 
     }
 }
 
+// The same arithmetic, eight pairs per thread with 16-byte accesses and 32-bit index arithmetic (16-bit dtypes, head_dim a
+// multiple of 16, 16-byte aligned rows and tables, fewer than 2^31 groups): the scalar form above spends three 64-bit
+// divisions and eight 2-byte accesses per pair and took 7.4 us on the prefill's 1.6 M pairs.
+template <int DT>
+__global__ __launch_bounds__(256) void rope_vec_kernel(void *x_, unsigned groups, unsigned heads, unsigned gph, int head_dim,
+                                                       long ldx, const void *cos_, const void *sin_)
+{
+    typedef typename Elem<DT>::T E;
+    E *x = reinterpret_cast<E *>(x_);
+    const E *cs = reinterpret_cast<const E *>(cos_), *sn = reinterpret_cast<const E *>(sin_);
+    const int half = head_dim / 2;
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;     // group of 8 pairs: (t, h, g), g < gph = half / 8
+    if (i >= groups) return;
+    const unsigned th = i / gph, g = i - th * gph;
+    const unsigned t = th / heads, h = th - t * heads;
+    E *p = x + (long)t * ldx + (long)h * head_dim + g * 8;
+    const E *ct = cs + (long)t * head_dim + g * 8, *st = sn + (long)t * head_dim + g * 8;
+    const v8us a8 = *reinterpret_cast<const v8us *>(p), b8 = *reinterpret_cast<const v8us *>(p + half);
+    const v8us c0 = *reinterpret_cast<const v8us *>(ct), c1 = *reinterpret_cast<const v8us *>(ct + half);
+    const v8us s0 = *reinterpret_cast<const v8us *>(st), s1 = *reinterpret_cast<const v8us *>(st + half);
+    v8us lo8, hi8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float a = Elem<DT>::ld((E)a8[e]), b = Elem<DT>::ld((E)b8[e]);
+        const float lo = Elem<DT>::rnd(a * Elem<DT>::ld((E)c0[e])) + Elem<DT>::rnd(-b * Elem<DT>::ld((E)s0[e]));
+        const float hi = Elem<DT>::rnd(b * Elem<DT>::ld((E)c1[e])) + Elem<DT>::rnd(a * Elem<DT>::ld((E)s1[e]));
+        lo8[e] = (unsigned short)Elem<DT>::st(lo);
+        hi8[e] = (unsigned short)Elem<DT>::st(hi);
+    }
+    *reinterpret_cast<v8us *>(p) = lo8;
+    *reinterpret_cast<v8us *>(p + half) = hi8;
+}
+
 }  // namespace mq
 
 extern "C" int mq_rope_inplace(void *x, int x_dtype, long T, int heads, int head_dim, long ldx,
@@ -43,9 +76,17 @@ extern "C" int mq_rope_inplace(void *x, int x_dtype, long T, int heads, int head
     MQ_REQUIRE(x && cos && sin && T > 0 && heads > 0 && head_dim > 0 && head_dim % 2 == 0 && ldx >= (long)heads * head_dim,
                "mq_rope_inplace: bad shape");
     const long total = T * heads * (head_dim / 2);
+    hipStream_t st = (hipStream_t)stream;
+    if ((x_dtype == MQ_F16 || x_dtype == MQ_BF16) && head_dim % 16 == 0 && total / 8 < (1L << 31) &&
+        ((uintptr_t)x) % 16 == 0 && (ldx * 2) % 16 == 0 && ((uintptr_t)cos) % 16 == 0 && ((uintptr_t)sin) % 16 == 0) {
+        const unsigned groups = (unsigned)(total / 8), gph = (unsigned)(head_dim / 16);
+        const unsigned vblocks = (groups + 255) / 256;
+        if (x_dtype == MQ_F16) hipLaunchKernelGGL(rope_vec_kernel<MQ_F16>, dim3(vblocks), dim3(256), 0, st, x, groups, (unsigned)heads, gph, head_dim, ldx, cos, sin);
+        else hipLaunchKernelGGL(rope_vec_kernel<MQ_BF16>, dim3(vblocks), dim3(256), 0, st, x, groups, (unsigned)heads, gph, head_dim, ldx, cos, sin);
+        return check_launch("rope_inplace");
+    }
     long blocks = ceil_div(total, 256);
     if (blocks > 4096) blocks = 4096;
-    hipStream_t st = (hipStream_t)stream;
     switch (x_dtype) {
     case MQ_F16: hipLaunchKernelGGL(rope_kernel<MQ_F16>, dim3((unsigned)blocks), dim3(256), 0, st, x, T, heads, head_dim, ldx, cos, sin); break;
     case MQ_BF16: hipLaunchKernelGGL(rope_kernel<MQ_BF16>, dim3((unsigned)blocks), dim3(256), 0, st, x, T, heads, head_dim, ldx, cos, sin); break;

@@ -82,11 +82,12 @@ def test_argument_checks():
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
-def test_rope_inplace_equals_the_torch_formula(dtype):
-    """Harness glue (not MQuant): rotate-half RoPE on the q|k part of a fused q|k|v output."""
+@pytest.mark.parametrize("T,heads,kvh,d", [(77, 6, 2, 64), (768, 28, 4, 128), (1024, 16, 16, 80), (5, 3, 1, 24)])
+def test_rope_inplace_equals_the_torch_formula(dtype, T, heads, kvh, d):
+    """Harness glue (not MQuant): rotate-half RoPE on the q|k part of a fused q|k|v output (16-byte vector kernel for
+    half dtypes and head_dim % 16 == 0, scalar kernel otherwise -- same arithmetic)."""
     from mquant_amd import ops
     from mquant_amd.full_prefill import _rope, _rope_tables
-    T, heads, kvh, d = 77, 6, 2, 64
     qkv = torch.from_numpy(make_x(3, (T, (heads + 2 * kvh) * d))).to(device=DEV, dtype=dtype)
     cos, sin = _rope_tables(T, d, torch.device(DEV), dtype)
     want_q = _rope(qkv[:, :heads * d].view(T, heads, d), cos, sin)
