@@ -36,7 +36,10 @@ __global__ __launch_bounds__(RQ_THREADS) void rmsn_quant_kernel(RqArgs p)
     typedef typename Elem<DT>::T T;
     __shared__ float wsum[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const long row = blockIdx.x;
+    // tiled int8 output: the 16 rows of a piece row are handled on ONE XCD (tiled_row_of, mq_common.h), so the eight
+    // 16-byte chunks that share a 128-byte line meet in one L2 instead of being written back by eight
+    const long row = (p.ldo == MQ_LD_TILED) ? tiled_row_of(blockIdx.x) : (long)blockIdx.x;
+    if (row >= p.M) return;                         // uniform over the workgroup
     const T *xr = reinterpret_cast<const T *>(p.x) + row * p.ldx;
     const long chunks = p.K / 16;
 
@@ -87,6 +90,8 @@ __global__ __launch_bounds__(RQ_THREADS) void rmsn_quant_kernel(RqArgs p)
         inv = 1.0f / sqrtf(ms + p.eps);
     }
     const float s = (p.row_sel && p.row_sel[row]) ? p.scale1 : p.scale0;
+    const float s_inv = 1.0f / s;
+    const bool s_rcp = quant_rcp_ok(s);
 
 #pragma unroll
     for (int c = 0; c < RQ_MAX_CHUNKS; ++c) {
@@ -95,10 +100,8 @@ __global__ __launch_bounds__(RQ_THREADS) void rmsn_quant_kernel(RqArgs p)
             int q[16];
             float y[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                y[i] = Elem<DT>::rnd(v[c][i] * inv);
-                q[i] = quant_level(y[i], s, -128.0f, 127.0f);
-            }
+            for (int i = 0; i < 16; ++i) y[i] = Elem<DT>::rnd(v[c][i] * inv);
+            quant_levels<16>(y, s, s_inv, s_rcp, -128.0f, 127.0f, q);      // the IEEE quotient only next to a half-integer (mq_common.h)
             v4i pk;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -140,10 +143,11 @@ extern "C" int mq_rmsn_quantize_i8(const void *x, int x_dtype, long M, long K, l
     p.scale0 = scale0; p.scale1 = row_sel ? scale1 : scale0; p.row_sel = row_sel;
     p.y = y_out; p.ldy = ldy; p.out = out; p.K_pad = K_pad; p.ldo = ldo;
     hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)(ldo == MQ_LD_TILED ? ceil_div(M, 128) * 128 : M);      // tiled: whole groups of 8 XCDs x 16 rows
     switch (x_dtype) {
-    case MQ_F16: hipLaunchKernelGGL(rmsn_quant_kernel<MQ_F16>, dim3((unsigned)M), dim3(RQ_THREADS), 0, st, p); break;
-    case MQ_F32: hipLaunchKernelGGL(rmsn_quant_kernel<MQ_F32>, dim3((unsigned)M), dim3(RQ_THREADS), 0, st, p); break;
-    case MQ_BF16: hipLaunchKernelGGL(rmsn_quant_kernel<MQ_BF16>, dim3((unsigned)M), dim3(RQ_THREADS), 0, st, p); break;
+    case MQ_F16: hipLaunchKernelGGL(rmsn_quant_kernel<MQ_F16>, dim3(grid), dim3(RQ_THREADS), 0, st, p); break;
+    case MQ_F32: hipLaunchKernelGGL(rmsn_quant_kernel<MQ_F32>, dim3(grid), dim3(RQ_THREADS), 0, st, p); break;
+    case MQ_BF16: hipLaunchKernelGGL(rmsn_quant_kernel<MQ_BF16>, dim3(grid), dim3(RQ_THREADS), 0, st, p); break;
     default: return fail(MQ_EINVAL, "mq_rmsn_quantize_i8: unknown dtype %d", x_dtype);
     }
     return check_launch("rmsn_quantize_i8");
