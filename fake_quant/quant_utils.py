@@ -439,12 +439,9 @@ class ActQuantWrapper(torch.nn.Module):
             width = wmod.weight.shape[1] if wmod.weight.dim() == 2 else 0
             return (bool(getattr(qz, "sym", False)) and not self.split and (g == 64 or g % 128 == 0) and g <= 1024
                     and (g & (g - 1)) == 0 and width > 0 and width % g == 0 and wq is not None and bool(getattr(wq, "sym", False)))
-        if getattr(qz, "act_per_tensor", False) and x_dtype != torch.float32:
-            # the reference keeps the per-tensor range, scale, zero point AND x / scale in x's dtype
-            # (quant_utils.py:214-231: ``torch.tensor(0).to(x)``, ``xmax / self.maxq``): on half / bf16
-            # activations its grid differs from an fp32 evaluation by up to 2^-9 relative, so those stay on the
-            # bit-faithful simulated path; the integer kernels compute the range in fp32 = the fp32 case
-            return False
+        # (per-tensor ranges on half / bf16 activations: the reference keeps range, scale, zero point, x / scale and the
+        #  level sum in x's dtype -- quant_utils.py:214-231, ``torch.tensor(0).to(x)``, the int64 maxq does not promote -- and
+        #  mq_quantize_act_range_i8 rounds exactly there; goldens wrapper_dynpt16_* from the reference on fp16 / bf16)
         return bool(getattr(qz, "sym", False)) or not self.split
 
     def _real_parts(self, device) -> dict:

@@ -219,7 +219,9 @@ int mq_quantize_act_dyn_asym_i8(const void *x, int x_dtype, long M, long K, long
  * skip_col0) -- no host round trip.  asym = 0: scale = max(|xmin|, xmax) / (2^(bits-1) - 1) (1 if 0);
  * asym = 1: a zero bound becomes -1 resp. +1 on its own, scale / zero / stored levels / shift as in
  * mq_quantize_act_dyn_asym_i8 (no skip_col0 then).  scale_out (and zero_out / shift_out, may be NULL when
- * asym = 0) are written per row for mq_gemm_w4a8_rowscale_ws. */
+ * asym = 0) are written per row for mq_gemm_w4a8_rowscale_ws.  For fp16 / bf16 inputs every step is rounded to
+ * x's dtype like the reference's (range * clip, scale, zero point, x / scale, level sum are 16-bit tensors there:
+ * `torch.tensor(0).to(x)`, the int64 maxq tensor does not promote); the per-token entry points promote to fp32 (:239). */
 int mq_quantize_act_range_i8(const void *x, int x_dtype, long M, long K, long ldx, int bits,
                              float clip_ratio, int asym, int skip_col0, const float *minmax,
                              float *x0_out, float *scale_out, float *zero_out, float *shift_out,

@@ -88,15 +88,20 @@ __global__ __launch_bounds__(DQ_THREADS) void act_quant_dyn_kernel(DqArgs p)
         mn = fminf(p.range_in[0], 0.0f);
         mx = fmaxf(p.range_in[1], 0.0f);
     }
-    float xmin = mn * p.clip, xmax0 = mx * p.clip;
+    // The per-TENSOR rule is evaluated in x's dtype upstream (quant_utils.py:214-231: torch.tensor(0).to(x), the int64
+    // maxq tensor does not promote): range * clip, the scale, the zero point, x / scale and the level sum are 16-bit
+    // tensors for a half model, each torch op rounding its fp32 result once.  The per-token rule promotes to fp32 (:239).
+    const bool faithful = (DT != MQ_F32) && p.range_in != nullptr;
+    auto rd = [&](float v) { return faithful ? Elem<DT>::rnd(v) : v; };
+    float xmin = rd(mn * p.clip), xmax0 = rd(mx * p.clip);
     float s, zero = 0.0f, lo, hi;
     if (ASYM) {                                         // quant_utils.py:255-268 + asym_quant :27-31
         if (p.range_in) {                               // the per-tensor rule fixes each bound on its own (:229-232)
             if (xmin == 0.0f) xmin = -1.0f;
             if (xmax0 == 0.0f) xmax0 = 1.0f;
         } else if (xmin == 0.0f && xmax0 == 0.0f) { xmin = -1.0f; xmax0 = 1.0f; }
-        s = (xmax0 - xmin) / p.maxq;
-        zero = rintf(-xmin / s);
+        s = rd(rd(xmax0 - xmin) / p.maxq);
+        zero = rintf(rd(-xmin / s));
         lo = 0.0f;
         hi = p.maxq;
         if (t == 0) {
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(DQ_THREADS) void act_quant_dyn_kernel(DqArgs p)
         }
     } else {
         const float xmax = fmaxf(fabsf(xmin), xmax0);
-        s = (xmax == 0.0f) ? 1.0f : xmax / p.maxq;
+        s = (xmax == 0.0f) ? 1.0f : rd(xmax / p.maxq);
         if (t == 0 && p.scale_out) p.scale_out[row] = s;
         lo = -(p.maxq + 1.0f);
         hi = p.maxq;
@@ -120,9 +125,12 @@ __global__ __launch_bounds__(DQ_THREADS) void act_quant_dyn_kernel(DqArgs p)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 if (ASYM) {      // clamp(rint(x / s) + zero, 0, maxq), stored minus 2^(bits-1); pad columns 0 (their weights are 0)
-                    float lv = rintf(v[c][i] / s) + zero;
+                    float lv = rd(rintf(rd(v[c][i] / s)) + zero);
                     lv = fminf(fmaxf(lv, lo), hi);
                     q[i] = (ch * 16 + i < p.K) ? (int)(lv - p.half) : 0;
+                } else if (faithful) {
+                    const float lv = fminf(fmaxf(rintf(Elem<DT>::rnd(v[c][i] / s)), lo), hi);
+                    q[i] = (ch * 16 + i < p.K) ? (int)lv : 0;
                 } else {
                     q[i] = (ch * 16 + i < p.K) ? quant_level(v[c][i], s, lo, hi) : 0;
                 }

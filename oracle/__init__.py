@@ -246,14 +246,15 @@ def quant_dyn_asym(x, bits=8, clip=1.0):
     return q, scale, zero, shift
 
 
-def quant_tensor(x, bits=8, clip=1.0, asym=False, skip_col0=False):
-    """quant_utils.py:214-237: dynamic per-tensor -> (stored int8 levels, scale, zero, shift)."""
+def quant_tensor(x, bits=8, clip=1.0, asym=False, skip_col0=False, mode=0):
+    """quant_utils.py:214-237: dynamic per-tensor -> (stored int8 levels, scale, zero, shift); mode = dtype of x
+    (0 fp32, 1 fp16, 2 bf16: the reference evaluates this mode in x's dtype)."""
     x = _f32(x)
     rows, cols = x.shape
     params = np.empty(3, dtype=np.float32)
     q = np.empty((rows, cols), dtype=np.int8)
     lib().orc_quant_tensor(_p(x, C.c_float), C.c_long(rows), C.c_long(cols), C.c_int(bits), C.c_float(clip),
-                           C.c_int(int(asym)), C.c_int(int(skip_col0)), _p(params, C.c_float), _p(q, C.c_int8))
+                           C.c_int(int(asym)), C.c_int(int(skip_col0)), C.c_int(mode), _p(params, C.c_float), _p(q, C.c_int8))
     return q, params[0], params[1], params[2]
 
 

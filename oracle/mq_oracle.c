@@ -242,9 +242,12 @@ void orc_quant_dyn_asym(const float *x, long rows, long cols, int bits, float cl
  *   asym: xmin == 0 -> -1; xmax == 0 -> +1 (each on its own, unlike the per-token rule);
  *         scale = (xmax - xmin) / maxq, zero = round(-xmin / scale), maxq = 2^bits - 1
  * Levels as in orc_quant_dyn / orc_quant_dyn_asym; params[0..2] = scale, zero, shift. */
-void orc_quant_tensor(const float *x, long rows, long cols, int bits, float clip, int asym, int skip_col0,
+void orc_quant_tensor(const float *x, long rows, long cols, int bits, float clip, int asym, int skip_col0, int mode,
                       float *params, int8_t *q)
 {
+    /* mode = dtype of x (0 fp32, 1 fp16, 2 bf16): the reference keeps the range, the scale, the zero point, x / scale and
+     * the level sum in x's dtype here (torch.tensor(0).to(x), the int64 maxq tensor does not promote; quant_utils.py:214-231),
+     * torch evaluating each op in fp32 and rounding once -- unlike the per-token rule, whose fp32 `tmp` promotes. */
     float mn = 0.0f, mx = 0.0f;
     for (long r = 0; r < rows; ++r)
         for (long k = skip_col0 ? 1 : 0; k < cols; ++k) {
@@ -252,24 +255,24 @@ void orc_quant_tensor(const float *x, long rows, long cols, int bits, float clip
             if (v < mn) mn = v;
             if (v > mx) mx = v;
         }
-    float xmin = mn * clip, xmax = mx * clip, s, z = 0.0f, lo, hi, half = 0.0f;
+    float xmin = round_mid(mn * clip, mode), xmax = round_mid(mx * clip, mode), s, z = 0.0f, lo, hi, half = 0.0f;
     if (asym) {
         const float maxq = (float)((1 << bits) - 1);
         if (xmin == 0.0f) xmin = -1.0f;
         if (xmax == 0.0f) xmax = 1.0f;
-        s = (xmax - xmin) / maxq;
-        z = rintf(-xmin / s);
+        s = round_mid(round_mid(xmax - xmin, mode) / maxq, mode);
+        z = rintf(round_mid(-xmin / s, mode));
         lo = 0.0f; hi = maxq; half = (float)(1 << (bits - 1));
     } else {
         const float maxq = (float)((1 << (bits - 1)) - 1);
         xmax = fmaxf(fabsf(xmin), xmax);
-        s = (xmax == 0.0f) ? 1.0f : xmax / maxq;
+        s = (xmax == 0.0f) ? 1.0f : round_mid(xmax / maxq, mode);
         lo = -(maxq + 1.0f); hi = maxq;
     }
     params[0] = s; params[1] = z; params[2] = s * (half - z);
     for (long r = 0; r < rows; ++r)
         for (long k = 0; k < cols; ++k) {
-            float v = rintf(x[r * cols + k] / s) + z;
+            float v = round_mid(rintf(round_mid(x[r * cols + k] / s, mode)) + z, mode);
             if (v < lo) v = lo;
             if (v > hi) v = hi;
             q[r * cols + k] = (skip_col0 && k == 0) ? 0 : (int8_t)(v - half);

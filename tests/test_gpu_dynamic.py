@@ -157,7 +157,8 @@ def test_per_tensor_kernel_matches_oracle(M, K, dtype, bits, clip, asym, skip):
     if M == 9:
         x = x.abs()                                                 # xmin == 0 alone: the per-tensor rule makes it -1
     q, s, z, sh, x0 = ops.quantize_act_tensor_i8(x, bits, clip, asym=asym, skip_col0=skip)
-    q_ref, s_ref, z_ref, sh_ref = oracle.quant_tensor(x.float().cpu().numpy(), bits=bits, clip=clip, asym=asym, skip_col0=skip)
+    mode = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[dtype]      # the reference evaluates this mode in x's dtype
+    q_ref, s_ref, z_ref, sh_ref = oracle.quant_tensor(x.float().cpu().numpy(), bits=bits, clip=clip, asym=asym, skip_col0=skip, mode=mode)
     np.testing.assert_array_equal(s.cpu().numpy(), np.full(M, s_ref, np.float32))
     np.testing.assert_array_equal(q.cpu().numpy()[:, :K], q_ref)
     if asym:
@@ -210,11 +211,9 @@ def test_modes_the_kernels_do_not_cover_stay_on_the_simulated_path():
     from fake_quant.gptq.rtn import rtn_module
     lin = torch.nn.Linear(256, 32).to(DEV).half()
     x = torch.from_numpy(make_x(1, (8, 256))).to(DEV).half()
-    # per-tensor ranges on HALF activations: the reference evaluates range, scale and x / scale in half precision
-    # (quant_utils.py:214-231); the integer kernels work in fp32, so only fp32 activations take them
-    # (symmetric group-wise scales with groups of 64 / 128 / 256 ... now run the integer kernels: tests/test_gpu_groupwise.py)
-    for kw in (dict(bits=8, sym=False, groupsize=64), dict(bits=8, sym=True, groupsize=32), dict(bits=16),
-               dict(bits=8, sym=True, act_per_tensor=True), dict(bits=8, sym=False, act_per_tensor=True)):
+    # (symmetric group-wise scales with groups of 64 / 128 / 256 ... run the integer kernels: tests/test_gpu_groupwise.py;
+    #  per-tensor ranges on half activations do too, in x's dtype like the reference: the test below)
+    for kw in (dict(bits=8, sym=False, groupsize=64), dict(bits=8, sym=True, groupsize=32), dict(bits=16)):
         wrap = qu.ActQuantWrapper(lin)
         rtn_module(wrap, "l", 4, True, False, [], {})
         wrap.quantizer.configure(**kw)
@@ -241,3 +240,50 @@ def test_empty_inputs_are_accepted_everywhere():
     ops.gptq_block(W, 0, 16, torch.eye(16, device=DEV), torch.empty((0,), device=DEV), 4, torch.empty((0, 16), device=DEV),
                    torch.empty((0, 16), device=DEV))
     torch.cuda.synchronize()
+
+
+PT16_CASES = ["sym_3584_f16", "sym_had_5120_split_f16", "asym_1280_bf16", "asym_down_19968_f16", "sym_2048_bf16_clip"]
+
+
+@pytest.mark.parametrize("case", PT16_CASES)
+def test_wrapper_per_tensor_mode_on_half_activations_runs_the_reference_grid(golden_dir, case):
+    """act_per_tensor on fp16 / bf16 activations: the reference evaluates range, scale, zero point, x / scale and the level
+    sum in x's dtype (quant_utils.py:214-231) and so do the kernels -- scale, zero point, int8 levels and integer
+    accumulators equal the reference's own (tools/gen_golden_pertensor_half.py); outputs within half-precision noise of its
+    floating-point evaluation (it rounds s * (q - z) to x's dtype per element and multiplies in half precision)."""
+    from fake_quant import hadamard_utils as hu, quant_utils as qu, utils
+    from fake_quant.gptq.rtn import rtn_module
+    from mquant_amd import ops
+    g = np.load(os.path.join(golden_dir, f"wrapper_dynpt16_{case}.npz"))
+    K_in, K_pad, N, M, seed, had, split, bias, a_bits, sym, dtc = [int(v) for v in g["meta"]]
+    dt = {1: torch.float16, 2: torch.bfloat16}[dtc]
+    lin = torch.nn.Linear(K_pad, N, bias=bool(bias))
+    lin.weight.data = torch.from_numpy(make_w(seed, (N, K_pad)))
+    if bias:
+        lin.bias.data = torch.from_numpy(make_w(seed + 1, (N,), std=0.1))
+    wrap = qu.ActQuantWrapper(lin.to(dt).to(DEV))
+    if had:
+        hadK, Kh = hu.get_hadK(K_pad)
+        wrap.online_full_had, wrap.had_K, wrap.K = True, hadK, Kh
+    if split:
+        wrap.split = True
+        wrap.split_weights()
+    if K_pad != K_in:
+        wrap.register_forward_pre_hook(functools.partial(utils.revise_down_input, new_size=K_pad))
+    rtn_module(wrap, "layer", 4, True, False, [], {})
+    wrap.quantizer.configure(bits=a_bits, sym=bool(sym), clip_ratio=float(g["clip"]), act_per_tensor=True)
+    x = torch.from_numpy(make_x(seed + 20, (M, K_in))).to(dt).to(DEV)
+    assert wrap._real_ready(x), "the per-tensor dynamic mode on half activations must run the real kernels"
+    y = wrap(x)
+    real = wrap._real
+    assert real is not None and real.dynamic["per_tensor"] and y.dtype == dt
+    tol = {1: 8e-3 if had else 4e-3, 2: 3e-2}[dtc] * float(np.abs(g["y"]).max())
+    np.testing.assert_allclose(y.float().cpu().numpy(), g["y"], rtol=0, atol=tol)
+    xr = ops.hadamard(x, real.had.n, real.had.K, real.had.bits) if had else x
+    a, s_rows, zero, _, _ = ops.quantize_act_tensor_i8(xr, a_bits, float(g["clip"]), asym=not sym, skip_col0=bool(split))
+    np.testing.assert_array_equal(s_rows.cpu().numpy(), np.full(M, g["scale"], np.float32))
+    if not sym:
+        np.testing.assert_array_equal(zero.cpu().numpy(), np.full(M, g["zero"], np.float32))
+    lv = a.cpu().numpy()[:, 1 if split else 0:K_pad]
+    np.testing.assert_array_equal(lv, g["qx"])
+    np.testing.assert_array_equal(ops.gemm_w4a8_i32(a, real.w_img, 4, N).cpu().numpy(), g["acc"])
