@@ -326,6 +326,9 @@ int mq_attn_prefill_fp8kv(const void *q, int dtype, long T, int heads, int kv_he
 int mq_attn_prefill(const void *q, int dtype, long T, int heads, int kv_heads, int head_dim, long ldq,
                     const void *k, const void *v, long ldkv, float softmax_scale, int causal, void *out, long ldo,
                     void *stream);
+/* TEST-ONLY, thread-local: force the waves per workgroup (= ways the keys are split) of the attention kernels: 2 or 4; 0 = by shape. */
+int mq_attn_debug_waves(int waves);
+
 /* Either attention with the NEXT Linear's static int8 activation quantizer fused into its store (the o_proj /
  * proj input): out[t][c] = clamp(rint(cast_dtype(o[t][c]) / s_t), -128, 127), s_t = scale1 where row_sel[t] != 0 else
  * scale0 -- the bytes mq_quantize_act_i8 writes for the 16-bit attention output, in the same activation layout (K_pad ==

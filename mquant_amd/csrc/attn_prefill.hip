@@ -73,7 +73,7 @@ template <> struct AttnMma<MQ_BF16> {
 };
 
 constexpr int AT_KB = 32;            // keys per block
-constexpr int AT_STATS = 4 * 32 * 2 * 4;
+constexpr int AT_STATS = 4 * 32 * 2 * 4;   // [waves <= 4][32 queries][m, l]
 // Per head dimension HD (128: Qwen2-VL decoder; 80: its vision tower, 16-bit K / V only): the V tile is [32 keys][HD] 16-bit
 // values, rows padded to whole 32-column d-tiles.  HD = 128: 256-byte rows, 32-byte groups XOR-ed by key & 3; HD = 80: 192-byte
 // rows (the four rows of a transpose read already fall into four different 64-byte bank slots).  The 16-bit K tile has rows
@@ -115,15 +115,17 @@ __device__ __forceinline__ void widen16(const v4i w, v4i &a, v4i &b)
 }
 
 // KV8: K / V are e4m3 bytes (widened here); else they are 16-bit values of q's dtype, used as they are.
-template <int DT, bool KV8, int HD>
-__global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p)
+// NW = waves per workgroup = ways the keys are split (4, or 2: half the LDS, so four workgroups fit a CU and a prefill whose
+// 4-wave grid needs a second round -- 672 workgroups on 512 slots at the 7B shape -- is resident at once).
+template <int DT, bool KV8, int HD, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_prefill_kernel(AttnArgs p)
 {
     typedef AttnGeo<HD> G;
     static_assert(HD == 128 || (HD == 80 && !KV8), "head dimensions built: 128, and 80 for 16-bit K / V");
     constexpr int NKS = G::NKS, NDT = G::NDT, AT_D = HD, AT_VROW = G::VROW, AT_KROW = G::KROW, AT_WAVE_LDS = G::WAVE_LDS;
     constexpr int NR = KV8 ? 4 : 8;                                   // 16-byte loads per lane and operand and block
     typedef AttnMma<DT> MM;
-    __shared__ __attribute__((aligned(16))) char smem[4 * AT_WAVE_LDS + AT_STATS];
+    __shared__ __attribute__((aligned(16))) char smem[NW * AT_WAVE_LDS + AT_STATS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int head = blockIdx.y, kvh = head / (p.heads / p.kv_heads);
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p)
     v4i kraw[NR], vraw[NR];
     if (wave < n_blocks) load_block(wave, kraw, vraw);
     const int t16 = lane & 15, g16 = (lane >> 4) & 1;
-    for (int kb = wave; kb < n_blocks; kb += 4) {
+    for (int kb = wave; kb < n_blocks; kb += NW) {
         // ---- K into MFMA operands, V into this wave's LDS tile (e4m3: widened on the way) ------------------------
         v4i Kf[KV8 ? 8 : 1];
         if (KV8) {
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-        if (kb + 4 < n_blocks) load_block(kb + 4, kraw, vraw);        // in flight during this block's arithmetic
+        if (kb + NW < n_blocks) load_block(kb + NW, kraw, vraw);      // in flight during this block's arithmetic
         const long key0 = (long)kb * AT_KB;
 
         // ---- S^T = K Q^T : [32 keys][32 queries] ----------------------------------------------------------------
@@ -289,9 +291,9 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p)
         __builtin_amdgcn_wave_barrier();
     }
 
-    // ---- merge the four waves' partial results: wave w finishes the 32 d of tile w ---------------------------------
+    // ---- merge the waves' partial results: wave w finishes the 32-row d-tiles w, w + NW, ... ----------------------------
     l_run += __shfl_xor(l_run, 32, 64);
-    float *stats = reinterpret_cast<float *>(smem + 4 * AT_WAVE_LDS);
+    float *stats = reinterpret_cast<float *>(smem + NW * AT_WAVE_LDS);
     float *mine = reinterpret_cast<float *>(vt);                      // [dt][e][lane]
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
@@ -302,60 +304,90 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p)
         stats[(wave * 32 + lane) * 2 + 1] = l_run;
     }
     __syncthreads();
-    if (wave >= NDT) return;                                          // HD = 80: three d-tiles, the fourth wave is done
     float M = -1.0e30f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) M = fmaxf(M, stats[(w * 32 + (lane & 31)) * 2]);
-    float L = 0.0f, acc[16];
+    for (int w = 0; w < NW; ++w) M = fmaxf(M, stats[(w * 32 + (lane & 31)) * 2]);
+    float L = 0.0f, fw[NW];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        const float f = __builtin_amdgcn_exp2f(stats[(w * 32 + (lane & 31)) * 2] - M);
-        L += stats[(w * 32 + (lane & 31)) * 2 + 1] * f;
-        const float *src = reinterpret_cast<const float *>(smem + w * AT_WAVE_LDS) + wave * 16 * 64 + lane;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] += src[e * 64] * f;
+    for (int w = 0; w < NW; ++w) {
+        fw[w] = __builtin_amdgcn_exp2f(stats[(w * 32 + (lane & 31)) * 2] - M);
+        L += stats[(w * 32 + (lane & 31)) * 2 + 1] * fw[w];
     }
     const float f = L > 0.0f ? s_v / L : 0.0f;
-    if (q_row < p.T && p.qout) {
-        const float s = (p.row_sel && p.row_sel[q_row]) ? p.qs1 : p.qs0;
-        const float inv = 1.0f / s;
-        const bool rcp = quant_rcp_ok(s);
+    const float qs = (p.qout && p.row_sel && q_row < p.T && p.row_sel[q_row]) ? p.qs1 : p.qs0;
+    const float qinv = 1.0f / qs;
+    const bool qrcp = quant_rcp_ok(qs);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (wave * 32 + 8 * g >= HD) break;
-            float v4[4];
-            int q4[4];
+    for (int dt0 = 0; dt0 < NDT; dt0 += NW) {
+        const int dt = dt0 + wave;                                    // wave-uniform
+        if (dt >= NDT) break;                                         // HD = 80: three d-tiles
+        float acc[16];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v4[e] = Elem<DT>::rnd(acc[4 * g + e] * f);      // the 16-bit value the unfused path stores
-            quant_levels<4>(v4, s, inv, rcp, -128.0f, 127.0f, q4);
-            const long col = (long)head * AT_D + wave * 32 + 8 * g + 4 * ko;
-            *reinterpret_cast<unsigned *>(p.qout + act_offset(q_row, col, p.q_kpad, p.q_ld)) =
-                (q4[0] & 0xff) | ((q4[1] & 0xff) << 8) | ((q4[2] & 0xff) << 16) | ((unsigned)(q4[3] & 0xff) << 24);
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const float *src = reinterpret_cast<const float *>(smem + w * AT_WAVE_LDS) + dt * 16 * 64 + lane;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] += src[e * 64] * fw[w];
         }
-    } else if (q_row < p.T) {
-        unsigned short *o = reinterpret_cast<unsigned short *>(p.out) + q_row * p.ldo + (long)head * AT_D + wave * 32;
+        if (q_row >= p.T) continue;
+        if (p.qout) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (wave * 32 + 8 * g >= HD) break;                       // HD = 80: the last tile holds d 64 .. 79 only
-            v4us h;
+            for (int g = 0; g < 4; ++g) {
+                if (dt * 32 + 8 * g >= HD) break;                     // HD = 80: the last tile holds d 64 .. 79 only
+                float v4[4];
+                int q4[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) h[e] = Elem<DT>::st(acc[4 * g + e] * f);
-            *reinterpret_cast<v4us *>(o + 8 * g + 4 * ko) = h;
+                for (int e = 0; e < 4; ++e) v4[e] = Elem<DT>::rnd(acc[4 * g + e] * f);      // the 16-bit value the unfused path stores
+                quant_levels<4>(v4, qs, qinv, qrcp, -128.0f, 127.0f, q4);
+                const long col = (long)head * AT_D + dt * 32 + 8 * g + 4 * ko;
+                *reinterpret_cast<unsigned *>(p.qout + act_offset(q_row, col, p.q_kpad, p.q_ld)) =
+                    (q4[0] & 0xff) | ((q4[1] & 0xff) << 8) | ((q4[2] & 0xff) << 16) | ((unsigned)(q4[3] & 0xff) << 24);
+            }
+        } else {
+            unsigned short *o = reinterpret_cast<unsigned short *>(p.out) + q_row * p.ldo + (long)head * AT_D + dt * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (dt * 32 + 8 * g >= HD) break;
+                v4us h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = Elem<DT>::st(acc[4 * g + e] * f);
+                *reinterpret_cast<v4us *>(o + 8 * g + 4 * ko) = h;
+            }
         }
     }
 }
 
 }  // namespace mq
 
+static thread_local int g_attn_waves = 0;      // TEST-ONLY (mq_attn_debug_waves): 0 = by shape, 2 / 4 = forced
+
 template <int HD, bool KV8>
 static void attn_launch_t(const mq::AttnArgs &a, int dtype, hipStream_t st)
 {
     using namespace mq;
     const dim3 grid((unsigned)((a.T + 31) / 32), (unsigned)a.heads);
-    if (dtype == MQ_F16) hipLaunchKernelGGL((attn_prefill_kernel<MQ_F16, KV8, HD>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn_prefill_kernel<MQ_BF16, KV8, HD>), grid, dim3(256), 0, st, a);
+    // 4-wave workgroups: two per CU (LDS, registers).  When their grid needs more than one round on those 512 slots, 2-wave
+    // workgroups (four per CU) keep more of a short prefill resident: measured on the e4m3 variant 23.3 -> 20.9 us at the 7B
+    // shape (672 workgroups) and 38.8 -> 36.6 us at the 72B shape (1536); level from ~1300 workgroups of 48 blocks on, behind
+    // at 4096 tokens; no difference on the 16-bit variant, and worse when the 4-wave grid fits one round (vision tower: 22.6 ->
+    // 32.1 us) -- tools/debug/attn_waves.py.
+    const long wgs = (long)grid.x * grid.y;
+    int nw = (KV8 && wgs > 512 && wgs <= 2048) ? 2 : 4;
+    if (g_attn_waves == 2 || g_attn_waves == 4) nw = g_attn_waves;
+    if (nw == 2) {
+        if (dtype == MQ_F16) hipLaunchKernelGGL((attn_prefill_kernel<MQ_F16, KV8, HD, 2>), grid, dim3(128), 0, st, a);
+        else hipLaunchKernelGGL((attn_prefill_kernel<MQ_BF16, KV8, HD, 2>), grid, dim3(128), 0, st, a);
+    } else {
+        if (dtype == MQ_F16) hipLaunchKernelGGL((attn_prefill_kernel<MQ_F16, KV8, HD, 4>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attn_prefill_kernel<MQ_BF16, KV8, HD, 4>), grid, dim3(256), 0, st, a);
+    }
+}
+
+extern "C" int mq_attn_debug_waves(int waves)
+{
+    g_attn_waves = waves;
+    return MQ_OK;
 }
 
 static int attn_launch(const mq::AttnArgs &a, int dtype, bool kv8, int head_dim, void *stream)

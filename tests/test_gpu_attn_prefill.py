@@ -182,3 +182,37 @@ def test_fused_output_quantizer_equals_attention_then_quantize(variant, T, H, HK
     assert a.shape == b.shape == (T, H * D)
     assert torch.equal(a, b)
     assert int(a.abs().max()) >= 127
+
+
+@pytest.mark.parametrize("waves", [2, 4])
+@pytest.mark.parametrize("variant,T,H,HKV,D,causal", [("fp8", 768, 28, 4, 128, True), ("fp16", 333, 8, 2, 128, True),
+                                                      ("fp16", 1024, 16, 16, 80, False), ("fp8", 65, 4, 4, 128, False)])
+def test_both_workgroup_widths_give_the_same_attention(waves, variant, T, H, HKV, D, causal):
+    """The keys are split over 4 or 2 waves of a workgroup (chosen by shape; forced here through the test hook): each split
+    against the float64 checker, and the two against each other within half-precision rounding (the partial softmax states
+    merge in a different grouping)."""
+    from mquant_amd import ops
+    from mquant_amd._lib import call
+    g = torch.Generator(device=DEV).manual_seed(T + D)
+    qkv = (torch.randn(T, (H + 2 * HKV) * D, generator=g, device=DEV) * 0.9).half()
+    q = qkv[:, :H * D].view(T, H, D)
+    k = qkv[:, H * D:(H + HKV) * D].view(T, HKV, D)
+    v = qkv[:, (H + HKV) * D:].view(T, HKV, D)
+    try:
+        call("mq_attn_debug_waves", waves)
+        if variant == "fp8":
+            kv = qkv[:, H * D:].view(T, 2 * HKV, D)
+            scale = ops.kv_scale_from_absmax(kv)
+            cache = ops.kv_quant_fp8(kv, scale)
+            got = ops.attn_prefill_fp8kv(q, cache, scale, causal=causal)
+            want = _ref(q, cache, scale, causal)
+        else:
+            got = ops.attn_prefill(q, k, v, causal=causal)
+            rep = H // HKV
+            s = torch.einsum("thd,hkd->htk", q.double(), k.double().repeat_interleave(rep, 1).permute(1, 0, 2)) * D ** -0.5
+            if causal:
+                s = s.masked_fill(torch.ones(T, T, device=DEV, dtype=torch.bool).triu(1), float("-inf"))
+            want = (torch.softmax(s, dim=-1) @ v.double().repeat_interleave(rep, 1).permute(1, 0, 2)).permute(1, 0, 2).reshape(T, H * D)
+    finally:
+        call("mq_attn_debug_waves", 0)
+    assert float((got.double() - want).abs().max() / want.abs().max()) < 2.5e-3
