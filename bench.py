@@ -179,7 +179,7 @@ def full_prefill_report(pf, dev, args):
                 fp.step()
                 torch.cuda.synchronize(dev)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     fp.step()
                 run = g.replay
             for _ in range(20):
@@ -347,7 +347,10 @@ def main():
         fn()                      # first-call allocations / attribute setup happen outside capture
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: the default (global) capture mode makes EVERY thread's event queries fail while this thread captures,
+        # and the RCCL watchdog thread polls its collectives' events at any time -- one bench in ~15 aborted with
+        # hipErrorStreamCaptureUnsupported in ProcessGroupNCCL's watchdog under torchrun (tools/debug/torchrun_loop.sh)
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             keep[0] = fn()
         return g.replay
 
