@@ -216,3 +216,37 @@ def test_both_workgroup_widths_give_the_same_attention(waves, variant, T, H, HKV
     finally:
         call("mq_attn_debug_waves", 0)
     assert float((got.double() - want).abs().max() / want.abs().max()) < 2.5e-3
+
+
+def test_size_independent_properties_at_full_size():
+    """Properties that need no checker: (i) scaling V by a power of two scales the output exactly (the V scale rides in the
+    output scale / the values themselves, the softmax does not see it); (ii) a query whose keys all carry the same V row
+    returns that row (softmax weights sum to one) within half-precision rounding; (iii) T = 0 is accepted."""
+    from mquant_amd import ops
+    T, H, HKV, D = 768, 28, 4, 128
+    g = torch.Generator(device=DEV).manual_seed(99)
+    qkv = (torch.randn(T, (H + 2 * HKV) * D, generator=g, device=DEV) * 0.7).half()
+    q = qkv[:, :H * D].view(T, H, D)
+    k = qkv[:, H * D:(H + HKV) * D].view(T, HKV, D)
+    v = qkv[:, (H + HKV) * D:].view(T, HKV, D)
+    a = ops.attn_prefill(q, k, v, causal=True)
+    kc = k.contiguous()                                   # k and v must share their token stride
+    b = ops.attn_prefill(q, kc, (v.float() * 4.0).half(), causal=True)
+    # exact up to fp16 subnormals: an output below 2^-14 is rounded on a coarser grid than four times itself
+    d = (b.float() - a.float() * 4.0).abs()
+    assert float(d.max()) <= 3e-7 and bool((d[a.float().abs() >= 2.0 ** -14] == 0).all())
+    kv = qkv[:, H * D:].view(T, 2 * HKV, D)
+    scale = ops.kv_scale_from_absmax(kv)
+    cache = ops.kv_quant_fp8(kv, scale)
+    scale4 = scale.clone()
+    scale4[HKV:] *= 4.0                                   # the V heads' scales
+    a8 = ops.attn_prefill_fp8kv(q, cache, scale, causal=True)
+    b8 = ops.attn_prefill_fp8kv(q, cache, scale4, causal=True)
+    assert float((b8.float() - a8.float() * 4.0).abs().max()) <= float(a8.float().abs().max()) * 4.0 * 2 ** -10
+    row = torch.randn(1, HKV, D, generator=g, device=DEV).half()
+    const_v = row.expand(T, HKV, D).contiguous()
+    c = ops.attn_prefill(q, kc, const_v, causal=True).view(T, H, D).float()
+    want = row[0].float().repeat_interleave(H // HKV, dim=0)[None].expand(T, H, D)
+    assert float((c - want).abs().max()) <= float(want.abs().max()) * 3e-3
+    e = torch.empty((0, H, D), device=DEV, dtype=torch.float16)
+    assert ops.attn_prefill(e, e[:, :HKV], e[:, :HKV]).shape == (0, H * D)
