@@ -32,6 +32,8 @@ namespace mq {
 
 template <int W_BITS, int EPI>
 int dispatch_ws(const GemmArgs &p, int tile, hipStream_t st);   // gemm_ws.hip (tiled activations only)
+template <int EPI>
+int launch_gemm_pp(const GemmArgs &p, int tile, hipStream_t st);   // gemm_pp.hip (ping-pong kernels, W4, tiled activations)
 
 // GROUPED (--a_groupsize): the int32 accumulators of one activation group (64 or a multiple of 128 k) are scaled by
 // the group's activation scale of their row and added to fp32 accumulators in ascending group order; the epilogue
@@ -472,6 +474,9 @@ static int launch_gemm(const GemmArgs &p, hipStream_t st)
 //     so that ~250 workgroups run, integer partials are combined by splitk_reduce_kernel;
 //   * everything else is latency bound (~8 us floor per launch + ~0.3 us per k-step): 64x128
 //     tiles put two or three workgroups on every CU and measured 10-30 % faster than 128x128.
+#ifndef MQ_PLAN_WIDE_TILE
+#define MQ_PLAN_WIDE_TILE 14   // A/B builds: -DMQ_PLAN_WIDE_TILE=13 (the software-pipelined kernel of rounds 1-3)
+#endif
 struct Plan {
     int tile;    // index into dispatch_tile
     int splits;
@@ -506,10 +511,10 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
         }
     }
     if (t256 >= 192) {
-        // gate|up: with tiled activations the software-pipelined 8-wave kernel (register double
-        // buffering of the fragments) is ~5 % ahead of the 16-wave one (104-107 vs 110-112 us), with
-        // row-major activations it is behind
-        pl.tile = (w4 && a_tiled) ? 13 : 3;
+        // gate|up: with tiled activations the 8-wave ping-pong kernel (gemm_pp.hip, round 4: 93-101 us against 108-116
+        // for the software-pipelined tile 13 and 110-112 for the 16-wave tile 3, profiles/r4_pp_ab.txt); with row-major
+        // activations the 16-wave kernel
+        pl.tile = (w4 && a_tiled) ? MQ_PLAN_WIDE_TILE : 3;
         // ... unless a handful of 256 x 256 tiles spill into one more round (Qwen-VL w1|w2: 258 tiles; InternVL2 wqkv at
         // batch 4: 288): a round of the 256^2 kernel is ~57 us whether 2 or 256 tiles run in it.  Then the 192 x 128
         // wave-specialised tile is compared on measured per-tile times (us: f0 + c per 128-deep k-step; a partial last
@@ -562,6 +567,16 @@ static int dispatch_tile(const GemmArgs &p, int tile, hipStream_t st)
     case 4: return launch_gemm<128, 256, 2, 4, 3, W_BITS, EPI>(p, st);
     case 5: return launch_gemm<256, 128, 2, 4, 3, W_BITS, EPI>(p, st);
     case 13: if constexpr (W_BITS == 4) return launch_gemm_pipe<EPI>(p, st); else break;
+    case 14: case 15: case 16: case 17: case 18: case 19:
+        if constexpr (W_BITS == 4) {
+            if (!p.a_tiled) return fail(MQ_EINVAL, "mq_gemm_w4a8: tile %d needs activations in the tiled layout (lda = MQ_LD_TILED)", tile);
+            const int rc = launch_gemm_pp<EPI>(p, tile, st);
+            if (rc != MQ_OK || p.splits == 1) return rc;
+            long blocks = ceil_div(p.M * ceil_div(p.N, 4), 256);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(splitk_reduce_kernel<EPI>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+            return check_launch("splitk_reduce");
+        } else break;
     case 10: return launch_gemm<64, 128, 2, 2, 3, W_BITS, EPI>(p, st);
     case 11: return launch_gemm<128, 64, 2, 2, 3, W_BITS, EPI>(p, st);
     case 12: return launch_gemm<128, 128, 4, 2, 3, W_BITS, EPI>(p, st);

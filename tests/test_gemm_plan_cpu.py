@@ -5,7 +5,7 @@ import ctypes as C
 
 import pytest
 
-PIPE, WS64, WS96, WS128, WS192 = 13, 43, 40, 41, 42
+PIPE, WS64, WS96, WS128, WS192 = 14, 43, 40, 41, 42   # PIPE: the 256 x 256 tile (ping-pong kernel since round 4)
 
 
 def _plan(M, N, K):

@@ -221,7 +221,7 @@ def test_symmetric_kernels_accept_the_tiled_layout():
     img = o.prepack(to_dev(w), 4)
     o.splitk_workspace(torch.device(DEV), 64 << 20)
     try:
-        for tile in (1, 3, 13, 10, 26, 31, 35, 2):
+        for tile in (1, 3, 13, 14, 15, 16, 17, 18, 19, 10, 26, 31, 35, 2):
             for splits in (1, 3):
                 o.gemm_debug_force(tile, splits)
                 np.testing.assert_array_equal(o.gemm_w4a8_i32(at, img, 4, N).cpu().numpy(), acc_ref,
@@ -301,7 +301,7 @@ def test_every_m_grouping_of_the_xcd_mapping_is_a_bijection(M, N, K):
     img = o.prepack(to_dev(w), 4)
     o.splitk_workspace(torch.device(DEV), 64 << 20)
     try:
-        for tile in (40, 41, 42, 43, 3, 1):
+        for tile in (40, 41, 42, 43, 3, 1, 14, 15, 16, 17, 18, 19):
             for xm in (1, 2, 3, 4, 6, 8):
                 for splits in (1, 2):
                     o.gemm_debug_force(tile, splits | (xm << 8))
@@ -316,11 +316,11 @@ def test_random_shapes_tiles_and_epilogues_against_the_oracle():
     epilogue terms: int32 accumulators and the dequantised output bit for bit against the oracle."""
     o = ops()
     rng = np.random.default_rng(20261002)
-    tiles_w4 = list(WS_TILES) + [1, 3, 13, 2, 10, 26, 31, 35]
+    tiles_w4 = list(WS_TILES) + [1, 3, 13, 14, 15, 16, 17, 18, 19, 2, 10, 26, 31, 35]
     tiles_w8 = [t for t in WS_TILES if t != 42] + [3, 2, 10, 26, 31]
     o.splitk_workspace(torch.device(DEV), 64 << 20)
     try:
-        for case in range(48):
+        for case in range(96):
             w_bits = 4 if case % 3 else 8
             M = int(rng.integers(1, 700))
             N = int(rng.integers(1, 90)) * 8
