@@ -257,6 +257,9 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
             __builtin_amdgcn_sched_barrier(0);
         };
         __builtin_amdgcn_s_barrier();                // B(0): stage 0 landed
+#ifdef MQ_WS_STAMP
+        const unsigned long long stamp0 = __builtin_readcyclecounter();
+#endif
         load_x(0, 0, 0);
         load_w(0, 0, 0);
         load_x(1, 0, 1);
@@ -274,6 +277,15 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
             substep(3, nxt, 1);
             cur = nxt;
         }
+#ifdef MQ_WS_STAMP
+        {
+            const unsigned long long stamp1 = __builtin_readcyclecounter();
+            if (tid == 0 && p.partial && p.splits == 1) {
+                p.partial[blockIdx.x * 2] = (int)(stamp1 - stamp0);
+                p.partial[blockIdx.x * 2 + 1] = nk;
+            }
+        }
+#endif
         if (NACC == 2) {
 #pragma unroll
             for (int i = 0; i < TN; ++i)

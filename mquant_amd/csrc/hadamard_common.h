@@ -122,6 +122,13 @@ __device__ __forceinline__ void had_butterfly_chunk(float (&v)[8], int lane, int
     }
 }
 
+// Byte distance between the int8 outputs (row, j * m + c) and (row, (j + 1) * m + c) for a co-factor m >= 64:
+// m in a row-major matrix; m / 64 pieces of 1 KiB in the tiled layout (act_offset, mq_common.h).
+__device__ __forceinline__ long had_out_stride(const HadArgs &p)
+{
+    return p.ldq == MQ_LD_TILED ? 16L * p.m : (long)p.m;
+}
+
 // hadamard_fast.hip: MQ_EUNSUPPORTED (no message) = shape / dtype outside the fast mode, run the exact kernel
 int hadamard_fast_dispatch(const HadArgs &p, int x_dtype, bool quant, hipStream_t st);
 

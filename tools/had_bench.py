@@ -30,7 +30,10 @@ threads = int(os.environ.get("HAD_THREADS", "0"))
 call("mq_hadamard_debug_threads", threads)
 fast = int(os.environ.get("HAD_FAST", "0"))
 ops.hadamard_fast_mode(bool(fast))
-print("threads per row:", threads, "fast mode:", fast)
+impl = int(os.environ.get("HAD_IMPL", "0"))          # 1: the matrix-core exact kernel even where the vector-ALU one applies
+ops.hadamard_debug_impl(impl)
+tiled = bool(int(os.environ.get("HAD_TILED", "1")))
+print("threads per row:", threads, "fast mode:", fast, "impl:", impl, "tiled out:", tiled)
 rows = [int(v) for v in os.environ.get("HAD_ROWS", "0").split(",")]
 shapes = [("vis.fc2", 1024, 5120, 5120), ("llm.down", 768, 18944, 19968),
           ("qwenvl.c_proj", 768, 11008, 11008), ("internvl.w2", 768, 14336, 14336), ("72b.down", 768, 29568, 30720),
@@ -45,7 +48,7 @@ for name, M, n_in, n in shapes:
     bits = hu.had_sign_bits(K, dev) if K > 1 else None
     for dt in ((torch.float16,) if only else (torch.float16, torch.float32)):
         x = torch.randn((M, n_in), device=dev, dtype=torch.float32).to(dt)
-        out = torch.empty((M, (n + 127) // 128 * 128), dtype=torch.int8, device=dev)
+        out = ops.TiledAct.empty(M, (n + 127) // 128 * 128, dev) if tiled else torch.empty((M, (n + 127) // 128 * 128), dtype=torch.int8, device=dev)
         us = bench(lambda: ops.hadamard_quant_i8(x, n, K, bits, 0.05, out=out))
         byts = M * n_in * x.element_size() + M * n
         print(f"{name:14s} {str(dt):14s} M={M} n={n} K={K}: {us:8.1f} us  {byts / us / 1e3:7.1f} GB/s")
