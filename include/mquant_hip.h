@@ -167,10 +167,6 @@ int mq_hadamard_get_mode(void);
 
 /* TEST-ONLY hook (thread-local, not part of the drop-in surface): 256 or 512 threads per row. */
 int mq_hadamard_debug_threads(int threads);
-/* TEST-ONLY hook (thread-local): impl = 1 makes the calling thread's later launches take the matrix-core exact kernel
- * (csrc/hadamard.hip) even where the vector-ALU exact kernel (csrc/hadamard_valu.hip: half-precision activations,
- * n/K = 128, prepared descriptor) applies; 0 = by shape.  The two are bit-identical; the tests hold one against the other. */
-int mq_hadamard_debug_impl(int impl);
 
 /* ---------------------------------------------------------------------------
  * Weight formats.

@@ -31,7 +31,6 @@ SIGNATURES = {
     "mq_hadamard": (_i, [_vp, _i, _l, _l, _l, _l, _i, _vp, _i, _vp, _l, _vp]),
     "mq_hadamard_quant_i8": (_i, [_vp, _i, _l, _l, _l, _l, _i, _vp, _i, _f, _f, _vp, _i, _vp, _vp, _l, _l, _vp]),
     "mq_hadamard_debug_threads": (_i, [_i]),
-    "mq_hadamard_debug_impl": (_i, [_i]),
     "mq_hadamard_prepared_bytes": (C.c_size_t, [_i]),
     "mq_hadamard_prepare": (_i, [_vp, _i, _vp, _vp]),
     "mq_pack_i4": (_i, [_vp, _l, _l, _vp, _vp]),

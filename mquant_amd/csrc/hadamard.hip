@@ -30,12 +30,6 @@ namespace mq {
 static size_t prepared_masks_offset(int K) { return ((size_t)K * ((K + 31) / 32) * 4 + 7) / 8 * 8; }
 static size_t prepared_half_offset(int K) { return (prepared_masks_offset(K) + (size_t)((K + 15) / 16) * (K / 4) * 8 + 15) / 16 * 16; }
 static size_t prepared_half_bytes(int K) { return (size_t)((K + 31) / 32) * ((K + 15) / 16) * 1024; }   // per dtype
-// ... | float sign table of the vector-ALU kernel (hadamard_valu.hip), 128-byte aligned, empty for factors it does not serve
-int hadamard_valu_jb(int K);
-size_t hadamard_valu_table_bytes(int K);
-void hadamard_valu_fill_table(const unsigned *words, int K, void *table, hipStream_t st);
-int hadamard_valu_dispatch(const HadArgs &p, const char *table, int x_dtype, bool quant, hipStream_t st);
-static size_t prepared_valu_offset(int K) { return (prepared_half_offset(K) + 2 * prepared_half_bytes(K) + 127) / 128 * 128; }
 
 // storage of the staged row in LDS: 16-bit when the values are exactly half-precision
 template <int DT, bool HALF_LDS> struct Stage;
@@ -272,9 +266,6 @@ __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
         const float s = (p.row_sel && p.row_sel[row]) ? p.s1 : p.s0;
         const RowScale rs = row_scale(s);
 
-#ifdef MQ_HAD_STAMP
-        const unsigned long long st0 = __builtin_readcyclecounter();
-#endif
         // ---------------- A: butterflies ------------------------------------------------
         if (m >= 8) {
             const long nchunks = ceil_div(n, 512);
@@ -379,9 +370,6 @@ __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
             __syncthreads();
         }
 
-#ifdef MQ_HAD_STAMP
-        const unsigned long long st1 = __builtin_readcyclecounter();
-#endif
         // ---------------- B/C: K x K stage, cast, store / quantize -----------------------
         if (UNIT == 0 && K == 1) {
             if ((n & 3) == 0 && (!QUANT || ((p.ldq & 3) == 0 && (((uintptr_t)p.qout) & 3) == 0))) {
@@ -481,13 +469,6 @@ __global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
                 had_emit1<DT, QUANT>(p, row, o, acc, s);
             }
         }
-#ifdef MQ_HAD_STAMP
-        if (p.x0_out && !p.skip_col0 && lane == 0) {
-            const unsigned long long st3 = __builtin_readcyclecounter();
-            float *o = p.x0_out + (row * HAD_WAVES + wave) * 4;
-            o[0] = (float)(st1 - st0); o[1] = (float)(st3 - st1); o[2] = 0.0f; o[3] = 0.0f;
-        }
-#endif
         if (QUANT) {
             for (long c = n + tid; c < p.K_pad; c += HAD_THREADS) p.qout[act_offset(row, c, p.K_pad, p.ldq)] = 0;
         }
@@ -563,7 +544,6 @@ __global__ __launch_bounds__(64) void hadamard_prepare_kernel(const unsigned *wo
 
 static int g_had_fast = 0;        // process-wide SETTING (mq_hadamard_set_mode), read by every launch
 static thread_local int g_had_threads = 0;   // test hook (mq_hadamard_debug_threads); 0: choose by shape
-static thread_local int g_had_impl = 0;      // test hook (mq_hadamard_debug_impl): 1 = matrix-core exact kernel even where the vector-ALU one applies
 
 template <int DT, bool QUANT, bool HALF_LDS>
 static int launch_hadamard(const HadArgs &p, hipStream_t st)
@@ -645,10 +625,6 @@ static int hadamard_common(HadArgs p, int x_dtype, bool quant, void *stream)
         const int rc = hadamard_fast_dispatch(p, x_dtype, quant, st);
         if (rc != MQ_EUNSUPPORTED) return rc;
     }
-    if (prepared && p.K > 1 && g_had_impl != 1 && hadamard_valu_jb(p.K)) {   // exact, K x K stage on the packed-fp32 vector ALU (hadamard_valu.hip)
-        const int rc = hadamard_valu_dispatch(p, reinterpret_cast<const char *>(p.had_bits) + prepared_valu_offset(p.K), x_dtype, quant, st);
-        if (rc != MQ_EUNSUPPORTED) return rc;
-    }
     if (quant) {
         switch (x_dtype) {
         case MQ_F16: return launch_hadamard_dt<MQ_F16, true>(p, st);
@@ -671,7 +647,7 @@ static int hadamard_common(HadArgs p, int x_dtype, bool quant, void *stream)
 extern "C" size_t mq_hadamard_prepared_bytes(int K)
 {
     if (K <= 1 || K % 4 != 0) return 0;
-    return mq::prepared_valu_offset(K) + mq::hadamard_valu_table_bytes(K);
+    return mq::prepared_half_offset(K) + 2 * mq::prepared_half_bytes(K);
 }
 
 extern "C" int mq_hadamard_prepare(const uint32_t *had_words, int K, void *descriptor, void *stream)
@@ -683,7 +659,6 @@ extern "C" int mq_hadamard_prepare(const uint32_t *had_words, int K, void *descr
     hipLaunchKernelGGL(hadamard_prepare_kernel, dim3(64), dim3(64), 0, (hipStream_t)stream, had_words, K,
                        reinterpret_cast<unsigned *>(d), reinterpret_cast<unsigned long long *>(d + prepared_masks_offset(K)),
                        reinterpret_cast<v4i *>(d + prepared_half_offset(K)));
-    hadamard_valu_fill_table(had_words, K, d + prepared_valu_offset(K), (hipStream_t)stream);
     return check_launch("hadamard_prepare");
 }
 
@@ -696,14 +671,6 @@ extern "C" int mq_hadamard_set_mode(int fast)
 extern "C" int mq_hadamard_get_mode(void)
 {
     return mq::g_had_fast;
-}
-
-extern "C" int mq_hadamard_debug_impl(int impl)
-{
-    // TEST-ONLY: 1 = the matrix-core exact kernel for the calling thread's later launches even where the vector-ALU kernel
-    // (hadamard_valu.hip) applies; 0: by shape.  Both are bit-identical; the tests hold one against the other.
-    mq::g_had_impl = impl == 1 ? 1 : 0;
-    return MQ_OK;
 }
 
 extern "C" int mq_hadamard_debug_threads(int threads)

@@ -559,11 +559,6 @@ def hadamard_fast_mode(on: bool = True) -> bool:
     return prev
 
 
-def hadamard_debug_impl(impl: int = 0) -> None:
-    """Test hook: 1 = the matrix-core exact Hadamard kernel even where the vector-ALU exact kernel applies (bit-identical)."""
-    call("mq_hadamard_debug_impl", int(impl))
-
-
 def gemm_debug_force(tile: int = -1, splits: int = 0) -> None:
     """Tuning hook: force the tile shape (ids: csrc/gemm_w4a8.hip dispatch_tile) / split-K."""
     call("mq_gemm_debug_force", tile, splits)

@@ -30,10 +30,8 @@ threads = int(os.environ.get("HAD_THREADS", "0"))
 call("mq_hadamard_debug_threads", threads)
 fast = int(os.environ.get("HAD_FAST", "0"))
 ops.hadamard_fast_mode(bool(fast))
-impl = int(os.environ.get("HAD_IMPL", "0"))          # 1: the matrix-core exact kernel even where the vector-ALU one applies
-ops.hadamard_debug_impl(impl)
 tiled = bool(int(os.environ.get("HAD_TILED", "1")))
-print("threads per row:", threads, "fast mode:", fast, "impl:", impl, "tiled out:", tiled)
+print("threads per row:", threads, "fast mode:", fast, "tiled out:", tiled)
 rows = [int(v) for v in os.environ.get("HAD_ROWS", "0").split(",")]
 shapes = [("vis.fc2", 1024, 5120, 5120), ("llm.down", 768, 18944, 19968),
           ("qwenvl.c_proj", 768, 11008, 11008), ("internvl.w2", 768, 14336, 14336), ("72b.down", 768, 29568, 30720),
