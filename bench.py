@@ -199,16 +199,16 @@ def full_prefill_report(pf, dev, args):
             return med, p90, len(times), bool(torch.isfinite(fp.logits.float()).all().item())
         med_u, p90_u, _, _ = measure(False)
         med, p90, iters, finite = measure(True)
-        # informational: the same prefill with the NON-DEFAULT fast Hadamard mode (K x K stage on the half-precision matrix
-        # core; ~1e-7 of the int8 levels differ from the exact mode -- DESIGN 4.2); the mode is restored before returning
+        # informational: the same prefill with the NON-DEFAULT fast Hadamard stage (K x K stage on the half-precision matrix
+        # core; ~1e-7 of the int8 levels differ from the exact kernel -- DESIGN 4.2).  The flag lives in the layer descriptors
+        # of THIS model object (workload.set_had_fast); it is cleared again before returning, and nothing process-wide exists.
         med_fast = None
         try:
-            from mquant_amd import ops as _ops
-            prev = _ops.hadamard_fast_mode(True)
+            pf.set_had_fast(True)
             try:
                 med_fast = measure(True)[0]
             finally:
-                _ops.hadamard_fast_mode(prev)
+                pf.set_had_fast(bool(args.had_fast))
         except Exception:
             med_fast = None
         return {"what": "whole synthetic prefill: W4A8 Linears (this repo's kernels) + attention (mq_attn_prefill on the q|k|v GEMM "
@@ -301,8 +301,6 @@ def main():
 
     from mquant_amd import ops, workload
 
-    if args.had_fast:
-        ops.hadamard_fast_mode(True)     # process-wide switch of the K x K stage (include/mquant_hip.h)
     headline = args.workload == "qwen2vl_7b" and not args.tiny
     build_specs, workload_desc = workload.WORKLOADS[args.workload]
     specs = workload.tiny_specs() if args.tiny else build_specs(args.batch)
@@ -316,6 +314,8 @@ def main():
             torch.cuda.empty_cache()
     if pf is None:
         pf = workload.Prefill(specs, device=dev, dtype=torch.float16, share_groups=not args.no_fuse)
+    if args.had_fast:
+        pf.set_had_fast(True)            # NON-DEFAULT, labelled secondary line: per-layer flag MQ_HAD_FAST (include/mquant_hip.h)
     tokens_per_step = workload.M_LLM * args.batch if not args.tiny else specs[-1].M
     hidden = specs[-1].n
     vocab = VOCAB if not args.tiny else 1024

@@ -14,9 +14,9 @@
  *   - stream is a hipStream_t passed as void* (NULL = default stream); all work is
  *     stream-ordered, nothing synchronises, nothing allocates.  Re-entrant: the entry points
  *     keep no mutable process state except (i) a per-device cache of kernel attributes behind
- *     a mutex and (ii) the TEST-ONLY override mq_gemm_debug_force, which is thread-local.
- *     mq_hadamard_set_mode is a process-wide SETTING (like an environment variable): choose it
- *     once before the first launch, not concurrently with launches.
+ *     a mutex and (ii) the TEST-ONLY overrides mq_gemm_debug_force / mq_hadamard_debug_threads, which are
+ *     thread-local.  Nothing process-wide changes numerics: the non-default fast Hadamard stage is a flag of
+ *     the call (MQ_HAD_FAST).
  *   - return value: 0 on success; >0 a hipError_t; <0 an argument error
  *     (MQ_EINVAL...).  mq_last_error() returns a thread-local message.
  *   - dtype codes: MQ_F16 / MQ_BF16 / MQ_F32 for activations and outputs.
@@ -122,10 +122,18 @@ int mq_fakequant_act(const void *x, int x_dtype, long M, long K, long ldx,
  * descriptor written by mq_hadamard_prepare (16-byte aligned, mq_hadamard_prepared_bytes(K) bytes): the sign
  * words, followed by the 64-lane masks of the fp32 MFMA sign operand (one VALU instruction per operand instead
  * of three -- the fp32 MFMA shares the vector ALU's datapath, every VALU instruction beside it is lost matrix
- * time) and by the +-1 half-precision operand images of the fast mode (mq_hadamard_set_mode).  Results are
+ * time) and by the +-1 half-precision operand images of the fast stage (MQ_HAD_FAST).  Results are
  * identical with and without the descriptor. */
 #define MQ_HAD_FP32 1
 #define MQ_HAD_PREPARED 2
+/* NON-DEFAULT accuracy / speed flag of ONE call (there is no process-wide mode): without it the K x K stage is the sequential
+ * fp32 add chain of the reference's CPU run, bit-identical to the goldens.  With MQ_HAD_FAST, half-precision activations
+ * (x_dtype MQ_F16 / MQ_BF16, MQ_HAD_FP32 off, 64 <= n/K <= 512) run that stage on the fp16 / bf16 matrix core
+ * (V_MFMA_F32_32X32X16): the products +-1 * y are exact, only the ORDER of the fp32 accumulation differs -- what the
+ * reference's own GPU run does with a half-precision cuBLAS GEMM (hadamard_utils.py:127).  Not bit-identical to the exact
+ * kernel: DESIGN.md 4.2 gives the measured int8 level flip rate and the verdict against the reference goldens
+ * (tests/test_gpu_hadamard_fast.py).  Shapes / dtypes outside the fast kernel take the exact one. */
+#define MQ_HAD_FAST 4
 size_t mq_hadamard_prepared_bytes(int K);
 int mq_hadamard_prepare(const uint32_t *had_words, int K, void *descriptor, void *stream);
 
@@ -153,17 +161,6 @@ int mq_act_hadamard_quant_i8(const void *x, const void *x2, int act, int x_dtype
                              int fp32_had, float scale0, float scale1, const uint8_t *row_sel,
                              int skip_col0, float *x0_out, int8_t *out, long K_pad, long ldo,
                              void *stream);
-
-/* NON-DEFAULT accuracy / speed setting of the three entry points above (process-wide, like an environment
- * variable: choose it once, before launching).  fast = 0 (default): the K x K stage is the sequential fp32
- * add chain of the reference's CPU run, bit-identical to the goldens.  fast = 1: half-precision activations
- * (x_dtype MQ_F16 / MQ_BF16, fp32_had off, 64 <= n/K <= 512) run that stage on the fp16 / bf16 matrix core
- * (V_MFMA_F32_32X32X16): the products +-1 * y are exact, only the ORDER of the fp32 accumulation differs --
- * what the reference's own GPU run does with a half-precision cuBLAS GEMM (hadamard_utils.py:127).  Not
- * bit-identical to the exact mode: DESIGN.md 4.2 gives the measured int8 level flip rate.  Shapes / dtypes
- * outside the fast mode silently take the exact kernel. */
-int mq_hadamard_set_mode(int fast);
-int mq_hadamard_get_mode(void);
 
 /* TEST-ONLY hook (thread-local, not part of the drop-in surface): 256 or 512 threads per row. */
 int mq_hadamard_debug_threads(int threads);

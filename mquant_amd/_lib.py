@@ -66,8 +66,6 @@ SIGNATURES = {
     "mq_gemm_w4a8_i32_ws": (_i, [_vp, _l, _vp, _i, _l, _l, _l, _vp, _l, _vp, C.c_size_t, _vp]),
     "mq_gemm_debug_force": (_i, [_i, _i]),
     "mq_gemm_debug_plan": (_i, [_l, _l, _l, _i, _i, _i, _vp, _vp]),
-    "mq_hadamard_set_mode": (_i, [_i]),
-    "mq_hadamard_get_mode": (_i, []),
     "mq_minmax_channels": (_i, [_vp, _i, _l, _l, _l, _l, _vp, _vp, _vp]),
     "mq_minmax_tensor": (_i, [_vp, _i, _l, _l, _l, _l, _vp, _vp]),
 }

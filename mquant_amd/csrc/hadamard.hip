@@ -542,7 +542,6 @@ __global__ __launch_bounds__(64) void hadamard_prepare_kernel(const unsigned *wo
     }
 }
 
-static int g_had_fast = 0;        // process-wide SETTING (mq_hadamard_set_mode), read by every launch
 static thread_local int g_had_threads = 0;   // test hook (mq_hadamard_debug_threads); 0: choose by shape
 
 template <int DT, bool QUANT, bool HALF_LDS>
@@ -587,8 +586,10 @@ static int hadamard_common(HadArgs p, int x_dtype, bool quant, void *stream)
     p.inv_sqrt_n = 1.0f / sqrtf((float)p.n);
     MQ_REQUIRE((p.m & (p.m - 1)) == 0, "mq_hadamard: n/K=%d is not a power of two", p.m);
     MQ_REQUIRE(p.K == 1 || (p.K % 4 == 0 && p.had_bits && ((uintptr_t)p.had_bits) % 4 == 0), "mq_hadamard: K=%d needs 4-byte aligned had_words and K %% 4 == 0", p.K);
-    // fp32_had carries flags: bit 0 = --fp32_had, bit 1 = had_words is a prepared descriptor (mq_hadamard_prepare)
+    // fp32_had carries flags: bit 0 = --fp32_had, bit 1 = had_words is a prepared descriptor (mq_hadamard_prepare),
+    // bit 2 = THIS call may take the non-default fast K x K stage (MQ_HAD_FAST)
     const bool prepared = (p.fp32_had & MQ_HAD_PREPARED) != 0;
+    const bool fast = (p.fp32_had & MQ_HAD_FAST) != 0;
     p.fp32_had &= MQ_HAD_FP32;
     p.masks = nullptr;
     p.hfrag = nullptr;
@@ -621,7 +622,7 @@ static int hadamard_common(HadArgs p, int x_dtype, bool quant, void *stream)
     } else {
         MQ_REQUIRE(p.out && p.ldo >= p.n, "mq_hadamard: bad output geometry");
     }
-    if (g_had_fast) {        // non-default mode (mq_hadamard_set_mode): K x K stage on the half-precision matrix core
+    if (fast) {              // non-default per-call flag MQ_HAD_FAST: K x K stage on the half-precision matrix core
         const int rc = hadamard_fast_dispatch(p, x_dtype, quant, st);
         if (rc != MQ_EUNSUPPORTED) return rc;
     }
@@ -660,17 +661,6 @@ extern "C" int mq_hadamard_prepare(const uint32_t *had_words, int K, void *descr
                        reinterpret_cast<unsigned *>(d), reinterpret_cast<unsigned long long *>(d + prepared_masks_offset(K)),
                        reinterpret_cast<v4i *>(d + prepared_half_offset(K)));
     return check_launch("hadamard_prepare");
-}
-
-extern "C" int mq_hadamard_set_mode(int fast)
-{
-    mq::g_had_fast = fast ? 1 : 0;
-    return MQ_OK;
-}
-
-extern "C" int mq_hadamard_get_mode(void)
-{
-    return mq::g_had_fast;
 }
 
 extern "C" int mq_hadamard_debug_threads(int threads)

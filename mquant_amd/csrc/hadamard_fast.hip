@@ -1,4 +1,4 @@
-// hadamard_fast.hip -- NON-DEFAULT mode of the online Hadamard rotation (mq_hadamard_set_mode(1)): the K x K
+// hadamard_fast.hip -- NON-DEFAULT mode of the online Hadamard rotation (per-call flag MQ_HAD_FAST): the K x K
 // +-1 stage on the half-precision matrix core instead of the exact fp32 one.
 //
 // Reference: fake_quant/hadamard_utils.py:115-128 -- on a GPU the reference itself evaluates this stage as a

@@ -25,6 +25,10 @@ class HadamardSpec:
     K: int                      # special factor (1 for a pure power of two)
     bits: Optional[torch.Tensor]  # K*K packed sign bits on the device (None when K == 1)
     fp32_had: bool = False
+    #: NON-DEFAULT: this layer's online rotation may take the fast K x K stage (MQ_HAD_FAST, include/mquant_hip.h): same exact
+    #: products, another fp32 accumulation order -- not bit-identical to the reference's CPU run.  A field of the layer's own
+    #: descriptor, set by whoever builds the engine (bench.py --had-fast, FullPrefill(had_fast=True)); nothing process-wide.
+    fast: bool = False
 
 
 #: layout of the int8 activations between the quantizer and the GEMM: "tiled" (MQ_LD_TILED: one
@@ -122,7 +126,7 @@ class W4A8Linear:
         if self.had is not None:
             ops.hadamard_quant_i8(x2, self.had.n, self.had.K, self.had.bits, self.s_x0, self.s_x1,
                                   fp32_had=self.had.fp32_had, row_sel=row_sel,
-                                  skip_col0=self.split, out=a, x0_out=x0)
+                                  skip_col0=self.split, out=a, x0_out=x0, fast=self.had.fast)
         else:
             ops.quantize_act_i8(x2, self.s_x0, self.s_x1, row_sel=row_sel, skip_col0=self.split,
                                 out=a, x0_out=x0)
@@ -150,7 +154,7 @@ class W4A8Linear:
         x0 = WORKSPACE.x0(x.device, M) if self.split else None
         ops.act_hadamard_quant_i8(x, x2, act, self.had.n, self.had.K, self.had.bits, self.s_x0, self.s_x1,
                                   fp32_had=self.had.fp32_had, row_sel=row_sel, skip_col0=self.split,
-                                  out=a, x0_out=x0)
+                                  out=a, x0_out=x0, fast=self.had.fast)
         return a, x0
 
     def gemm(self, a: torch.Tensor, x0: Optional[torch.Tensor], out_dtype: torch.dtype,
@@ -175,7 +179,7 @@ class W4A8Linear:
         """[Hadamard ->] dynamic per-token quantize -> GEMM with per-row scales.  The row maximum
         needs the whole rotated row, so the Hadamard runs as its own launch here."""
         if self.had is not None:
-            x2 = ops.hadamard(x2, self.had.n, self.had.K, self.had.bits, self.had.fp32_had)
+            x2 = ops.hadamard(x2, self.had.n, self.had.K, self.had.bits, self.had.fp32_had, fast=self.had.fast)
         a = WORKSPACE.act(x2.device, x2.shape[0], self.K_pad)
         g = int(self.dynamic.get("groupsize", -1) or -1)
         if g > 0:

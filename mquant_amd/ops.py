@@ -200,7 +200,7 @@ def fakequant_act(x: torch.Tensor, scale0: float = 1.0, scale1: Optional[float] 
 
 
 # --------------------------------------------------------------------------- Hadamard
-HAD_FP32, HAD_PREPARED = 1, 2      # include/mquant_hip.h MQ_HAD_*
+HAD_FP32, HAD_PREPARED, HAD_FAST = 1, 2, 4      # include/mquant_hip.h MQ_HAD_*
 
 
 @_on_device
@@ -216,20 +216,24 @@ def hadamard_prepare(words: torch.Tensor, K: int) -> torch.Tensor:
     return out
 
 
-def _had_flags(had_bits: Optional[torch.Tensor], fp32_had: bool) -> int:
-    return (HAD_FP32 if fp32_had else 0) | (HAD_PREPARED if had_bits is not None and had_bits.dtype == torch.int64 else 0)
+def _had_flags(had_bits: Optional[torch.Tensor], fp32_had: bool, fast: bool = False) -> int:
+    """Flag word of the Hadamard entry points.  ``fast`` = MQ_HAD_FAST: THIS call may run the K x K stage on the
+    half-precision matrix core (same exact +-1 products, another fp32 accumulation order: NOT bit-identical to the
+    reference's CPU run).  Never set by default; there is no process-wide switch."""
+    return ((HAD_FP32 if fp32_had else 0) | (HAD_PREPARED if had_bits is not None and had_bits.dtype == torch.int64 else 0)
+            | (HAD_FAST if fast else 0))
 
 
 @_on_device
 def hadamard(x: torch.Tensor, n: int, K: int, had_bits: Optional[torch.Tensor],
-             fp32_had: bool = False) -> torch.Tensor:
+             fp32_had: bool = False, fast: bool = False) -> torch.Tensor:
     """Rotated activations in x's dtype, last dim zero-padded from x.shape[-1] to n."""
     x2 = _rows(x)
     _need_cuda(x2, had_bits)
     M, n_in = x2.shape
     out = torch.empty((M, n), dtype=x.dtype, device=x.device)
     call("mq_hadamard", x2.data_ptr(), dtype_code(x2.dtype), M, n_in, x2.stride(0), n, K,
-         _ptr(had_bits), _had_flags(had_bits, fp32_had), out.data_ptr(), out.stride(0), _stream())
+         _ptr(had_bits), _had_flags(had_bits, fp32_had, fast), out.data_ptr(), out.stride(0), _stream())
     return out.reshape(*x.shape[:-1], n)
 
 
@@ -237,7 +241,7 @@ def hadamard(x: torch.Tensor, n: int, K: int, had_bits: Optional[torch.Tensor],
 def hadamard_quant_i8(x: torch.Tensor, n: int, K: int, had_bits: Optional[torch.Tensor],
                       scale0: float, scale1: Optional[float] = None, *, fp32_had: bool = False,
                       row_sel: Optional[torch.Tensor] = None, skip_col0: bool = False,
-                      out=None, x0_out: Optional[torch.Tensor] = None, tiled: bool = False):
+                      out=None, x0_out: Optional[torch.Tensor] = None, tiled: bool = False, fast: bool = False):
     x2 = _rows(x)
     _need_cuda(x2, had_bits, row_sel, out)
     M, n_in = x2.shape
@@ -245,7 +249,7 @@ def hadamard_quant_i8(x: torch.Tensor, n: int, K: int, had_bits: Optional[torch.
     if skip_col0 and x0_out is None:
         x0_out = torch.empty((M,), dtype=torch.float32, device=x.device)
     call("mq_hadamard_quant_i8", x2.data_ptr(), dtype_code(x2.dtype), M, n_in, x2.stride(0), n, K,
-         _ptr(had_bits), _had_flags(had_bits, fp32_had), float(scale0), float(scale0 if scale1 is None else scale1),
+         _ptr(had_bits), _had_flags(had_bits, fp32_had, fast), float(scale0), float(scale0 if scale1 is None else scale1),
          _ptr(row_sel), int(skip_col0), _ptr(x0_out), optr, K_pad, ldo, _stream())
     return out, x0_out
 
@@ -270,7 +274,7 @@ def act_hadamard_quant_i8(x: torch.Tensor, x2: Optional[torch.Tensor], act: int,
                           had_bits: Optional[torch.Tensor], scale0: float, scale1: Optional[float] = None, *,
                           fp32_had: bool = False, row_sel: Optional[torch.Tensor] = None,
                           skip_col0: bool = False, out=None,
-                          x0_out: Optional[torch.Tensor] = None, tiled: bool = False):
+                          x0_out: Optional[torch.Tensor] = None, tiled: bool = False, fast: bool = False):
     """silu(x) * x2 (ACT_SILU_MUL) or quick_gelu(x) (ACT_QUICK_GELU) -> [pad] -> Hadamard -> int8,
     one launch.  x and x2 may be column slices of one tensor (same row stride)."""
     a = _rows(x)
@@ -283,7 +287,7 @@ def act_hadamard_quant_i8(x: torch.Tensor, x2: Optional[torch.Tensor], act: int,
     if skip_col0 and x0_out is None:
         x0_out = torch.empty((M,), dtype=torch.float32, device=x.device)
     call("mq_act_hadamard_quant_i8", a.data_ptr(), _ptr(b), int(act), dtype_code(a.dtype), M, n_in, a.stride(0),
-         n, K, _ptr(had_bits), _had_flags(had_bits, fp32_had), float(scale0), float(scale0 if scale1 is None else scale1),
+         n, K, _ptr(had_bits), _had_flags(had_bits, fp32_had, fast), float(scale0), float(scale0 if scale1 is None else scale1),
          _ptr(row_sel), int(skip_col0), _ptr(x0_out), optr, K_pad, ldo, _stream())
     return out, x0_out
 
@@ -547,16 +551,6 @@ def splitk_workspace(device, nbytes: int = 64 << 20) -> torch.Tensor:
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
         _SPLITK_WS[key] = ws
     return ws
-
-
-def hadamard_fast_mode(on: bool = True) -> bool:
-    """NON-DEFAULT setting of the online Hadamard kernels (``mq_hadamard_set_mode``): K x K stage on the
-    half-precision matrix core -- same exact products, another fp32 accumulation order, NOT bit-identical to
-    the reference's CPU run.  Returns the previous setting.  Process-wide; the default is the exact mode."""
-    from ._lib import load
-    prev = bool(load().mq_hadamard_get_mode())
-    call("mq_hadamard_set_mode", 1 if on else 0)
-    return prev
 
 
 def gemm_debug_force(tile: int = -1, splits: int = 0) -> None:

@@ -275,6 +275,14 @@ class _HotPath:
         for L in self.layers:
             L.lin.quantize(L.x, L.row_sel)
 
+    def set_had_fast(self, on: bool) -> None:
+        """NON-DEFAULT: the online rotations of THIS model's layers take (or stop taking) the fast K x K stage -- the
+        per-call flag MQ_HAD_FAST, carried by each layer's HadamardSpec (engine.py).  Nothing process-wide changes; a
+        captured hipGraph keeps the flags it was captured with."""
+        for L in self.layers:
+            if L.lin.had is not None:
+                L.lin.had.fast = bool(on)
+
     # -- accounting --------------------------------------------------------------------
     def gemm_launches(self) -> int:
         return len(self.layers)

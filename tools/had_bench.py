@@ -29,7 +29,6 @@ dev = torch.device("cuda:0")
 threads = int(os.environ.get("HAD_THREADS", "0"))
 call("mq_hadamard_debug_threads", threads)
 fast = int(os.environ.get("HAD_FAST", "0"))
-ops.hadamard_fast_mode(bool(fast))
 tiled = bool(int(os.environ.get("HAD_TILED", "1")))
 print("threads per row:", threads, "fast mode:", fast, "tiled out:", tiled)
 rows = [int(v) for v in os.environ.get("HAD_ROWS", "0").split(",")]
@@ -47,6 +46,6 @@ for name, M, n_in, n in shapes:
     for dt in ((torch.float16,) if only else (torch.float16, torch.float32)):
         x = torch.randn((M, n_in), device=dev, dtype=torch.float32).to(dt)
         out = ops.TiledAct.empty(M, (n + 127) // 128 * 128, dev) if tiled else torch.empty((M, (n + 127) // 128 * 128), dtype=torch.int8, device=dev)
-        us = bench(lambda: ops.hadamard_quant_i8(x, n, K, bits, 0.05, out=out))
+        us = bench(lambda: ops.hadamard_quant_i8(x, n, K, bits, 0.05, out=out, fast=bool(fast)))
         byts = M * n_in * x.element_size() + M * n
         print(f"{name:14s} {str(dt):14s} M={M} n={n} K={K}: {us:8.1f} us  {byts / us / 1e3:7.1f} GB/s")

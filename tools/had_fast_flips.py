@@ -43,16 +43,14 @@ for name, M, n_in, n in shapes:
         x = x.to(dt)
         res = {}
         for fast in (0, 1):
-            ops.hadamard_fast_mode(bool(fast))
-            y = ops.hadamard(x, n, K, bits)
+            y = ops.hadamard(x, n, K, bits, fast=bool(fast))
             s = float(y.float().abs().max()) / 127.0
             if fast == 0:
                 s_exact = s
-            q, _ = ops.hadamard_quant_i8(x, n, K, bits, s_exact)
+            q, _ = ops.hadamard_quant_i8(x, n, K, bits, s_exact, fast=bool(fast))
             out = ops.TiledAct.empty(M, (n + 127) // 128 * 128, dev)
-            us = bench(lambda: ops.hadamard_quant_i8(x, n, K, bits, s_exact, out=out))
+            us = bench(lambda: ops.hadamard_quant_i8(x, n, K, bits, s_exact, out=out, fast=bool(fast)))
             res[fast] = (y.float(), q.to_rows()[:, :n].to(torch.int16) if hasattr(q, "to_rows") else q[:, :n].to(torch.int16), us)
-        ops.hadamard_fast_mode(False)
         (y0, q0, t0), (y1, q1, t1) = res[0], res[1]
         flips = int((q0 != q1).sum())
         print(f"{name} (K = {K} x {n // K}) | {str(dt).replace('torch.', '')} | {t0:7.1f} | {t1:7.1f} | {flips} of {q0.numel()} = {flips / q0.numel():.2e} | "
