@@ -30,6 +30,7 @@ if ROOT not in sys.path:
 
 PEAK_INT8_TOPS = 5000.0   # dense int8 MFMA, 2 x the 2.5 PF bf16 dense peak (MI355X_MICROARCH.md)
 VOCAB = 152064
+VOCABS = {"qwen2vl_7b": 152064, "qwen2vl_72b": 152064, "qwenvl_7b": 151936, "internvl2_8b": 92553}   # lm_head rows (public configs)
 
 
 def cpu_baseline_reference(budget_s: float = 40.0):
@@ -304,7 +305,7 @@ def main():
     headline = args.workload == "qwen2vl_7b" and not args.tiny
     build_specs, workload_desc = workload.WORKLOADS[args.workload]
     specs = workload.tiny_specs() if args.tiny else build_specs(args.batch)
-    via_wrappers = (headline or args.via_wrappers) and not args.direct_engines
+    via_wrappers = not args.direct_engines and not args.tiny      # every workload is built through the drop-in API (round 4: the secondary lines too)
     pf, via_error = None, None
     if via_wrappers:
         try:
@@ -318,7 +319,8 @@ def main():
         pf.set_had_fast(True)            # NON-DEFAULT, labelled secondary line: per-layer flag MQ_HAD_FAST (include/mquant_hip.h)
     tokens_per_step = workload.M_LLM * args.batch if not args.tiny else specs[-1].M
     hidden = specs[-1].n
-    vocab = VOCAB if not args.tiny else 1024
+    vocab = VOCABS.get(args.workload, VOCAB) if not args.tiny else 1024
+    B_local = args.batch if not args.tiny else 1      # samples per rank and step: each ends in its own last-position logits
 
     # Per-step logits: the rank's sample ends in logits = lm_head(rms_norm(last position)) -- fp16, lm_head is not
     # wrapped (reference quant_utils.py:560-564) -- computed from the step's final Linear output INSIDE the step
@@ -331,10 +333,10 @@ def main():
     if with_logits:
         g = torch.Generator(device=dev).manual_seed(7)
         lm_head = (torch.randn((vocab, hidden), generator=g, device=dev) * 0.02).to(torch.float16)
-        logits_step = torch.zeros((1, vocab), dtype=torch.float16, device=dev)
+        logits_step = torch.zeros((B_local, vocab), dtype=torch.float16, device=dev)
         if distributed:
-            logits_send = [torch.zeros((1, vocab), dtype=torch.float16, device=dev) for _ in range(2)]
-            logits_all = [torch.zeros((world, vocab), dtype=torch.float16, device=dev) for _ in range(2)]
+            logits_send = [torch.zeros((B_local, vocab), dtype=torch.float16, device=dev) for _ in range(2)]
+            logits_all = [torch.zeros((world * B_local, vocab), dtype=torch.float16, device=dev) for _ in range(2)]
 
     # N > 1: sample i runs on rank i; static scales are replicated constants (every rank calibrates on
     # sample 0 with the same seeds).  The whole-prefill logits of this rank's sample, for the parity check:
@@ -367,10 +369,16 @@ def main():
             keep[0] = fn()
         return g.replay
 
+    # the samples of a step are stacked along the rows: sample b ends at row (b + 1) * M / B_local - 1
+    last_rows = None
+    if with_logits and B_local > 1:
+        per = specs[-1].M // B_local
+        last_rows = torch.arange(1, B_local + 1, device=dev) * per - 1
+
     def hot_path_and_logits():
         y = pf.step()                    # [M, hidden]: output of the last Linear of the step (down_proj)
         if with_logits:
-            h = torch.nn.functional.rms_norm(y[-1:], (hidden,), eps=1e-6)
+            h = torch.nn.functional.rms_norm(y[-1:] if last_rows is None else y.index_select(0, last_rows), (hidden,), eps=1e-6)
             torch.matmul(h, lm_head.t(), out=logits_step)
         return y
 
@@ -424,10 +432,19 @@ def main():
     if distributed and with_logits:
         # what the timed steps exchanged: row r of the gathered tensor is rank r's logits of that step
         par = (counter[0] - 1) & 1
-        mine = logits_all[par][rank]
-        logits_check = {"step_exchange": {"all_gather_bytes": int(world * vocab * 2), "own_row_intact":
-                                          bool(torch.equal(mine, logits_step[0])),
+        mine = logits_all[par][rank * B_local:(rank + 1) * B_local]
+        logits_check = {"step_exchange": {"all_gather_bytes": int(world * B_local * vocab * 2), "samples_per_rank": B_local,
+                                          "own_row_intact": bool(torch.equal(mine, logits_step)),
                                           "finite": bool(torch.isfinite(logits_all[par].float()).all().item())}}
+        if B_local > 1:
+            # the B_local > 1 path of shard.gather_logits (sample i lives on rank i % world): this rank's rows come back at
+            # the positions of its samples, in sample order
+            from mquant_amd import shard
+            n_samples = world * B_local
+            ordered = shard.gather_logits(logits_step.clone(), n_samples)
+            mine_idx = shard.shard_indices(n_samples, rank, world)
+            logits_check["gather_logits"] = {"samples": n_samples, "shape": list(ordered.shape),
+                                             "own_samples_in_place": bool(torch.equal(ordered[torch.tensor(mine_idx, device=dev)], logits_step))}
     if fp_logits is not None:
         from mquant_amd import shard
         gathered = shard.gather_logits(logits_local, world)
@@ -476,8 +493,8 @@ def main():
             torch.matmul(h, lm_head.t(), out=logits_step)
         lm_ms = timed(lm_only)
     launches = pf.gemm_launches()
-    traffic, traffic_note, traffic_source = None, "no PMC traffic file for this workload", None
-    tpath = next((pth for pth in (os.path.join(ROOT, "profiles", nm) for nm in ("r3_traffic.json", "r2_traffic.json"))
+    traffic, traffic_note, traffic_source, traffic_stale = None, "no PMC traffic file for this workload", None, None
+    tpath = next((pth for pth in (os.path.join(ROOT, "profiles", nm) for nm in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json"))
                   if os.path.exists(pth)), None)
     if tpath and headline and args.batch == 1 and not args.no_fuse:
         # HBM bytes per GEMM launch from the PMC passes (tools/pmc_traffic.py); counters cannot be
@@ -487,11 +504,20 @@ def main():
             tj = json.load(fh)
         traffic = tj["kernels"].get("gemm", {}).get("hbm_bytes_per_launch")
         traffic_note = tj["corrections"]
+        # stale = any kernel source changed since the counters were taken (digest over mquant_amd/csrc/*.hip, *.h recorded by
+        # tools/pmc_traffic.py; files measured before round 4 carry none and count as stale)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        try:
+            from pmc_traffic import csrc_digest
+            digest_now = csrc_digest()
+        except Exception:
+            digest_now = None
+        traffic_stale = not (digest_now is not None and tj.get("csrc_sha16") == digest_now)
         traffic_source = {"file": os.path.relpath(tpath, ROOT), "measured_at_commit": tj.get("commit"),
-                          "command": tj.get("command")}
+                          "command": tj.get("command"), "csrc_sha16": tj.get("csrc_sha16"), "csrc_sha16_now": digest_now}
     achieved = pf.gemm_ops() / (gemm_ms * 1e-3) / 1e12
     step_tops = pf.gemm_ops() / (ms_per_step * 1e-3) / 1e12
-    roofline = {"bound": "mfma", "kernel": "gemm_ws_kernel (V_MFMA_I32_32X32X32_I8) / gemm_w4a8_pipe_kernel 256x256 (V_MFMA_I32_16X16X64_I8)",
+    roofline = {"bound": "mfma", "kernel": "gemm_ws_kernel (V_MFMA_I32_32X32X32_I8) / gemm_w4a8_pp_kernel 256x256 (V_MFMA_I32_16X16X64_I8)",
                 "achieved": round(achieved, 2), "peak": PEAK_INT8_TOPS, "unit": "TOP/s",
                 "frac": round(achieved / PEAK_INT8_TOPS, 4),
                 "step_frac": round(step_tops / PEAK_INT8_TOPS, 4),
@@ -499,7 +525,7 @@ def main():
                                   "where frac covers the GEMM launches alone",
                 "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_note": traffic_note,
-                "traffic_source": traffic_source,
+                "traffic_source": traffic_source, "traffic_stale": traffic_stale,
                 "algorithmic_bytes_per_launch": round(pf.gemm_bytes() / launches),
                 "launches_per_step": launches,
                 "avg_launch_us": round(gemm_ms * 1e3 / launches, 3),

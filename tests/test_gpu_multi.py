@@ -86,3 +86,28 @@ def test_bench_as_a_single_torchrun_rank_initialises_rccl_and_exchanges_logits_o
     assert chk["step_exchange"]["own_row_intact"] is True and chk["step_exchange"]["finite"] is True
     assert chk["samples"] == 1 and chk["equal_to_single_gpu"] is True
     assert line["roofline"]["launches_per_step"] == 243
+
+
+def test_bench_single_torchrun_rank_with_four_samples_per_gpu_on_internvl2():
+    """BASELINE configuration 4's per-GPU share (batch 32 over 8 GPUs = 4 samples per rank, InternVL2-8B): every step ends in
+    4 x 92 553 last-position logits per rank, the all_gather on the side stream exchanges [world x 4, vocab], and
+    shard.gather_logits restores sample order for B_local > 1 -- executed on this box's one GPU under torch.distributed.run."""
+    import socket
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--batch", "4", "--workload", "internvl2_8b", "--no-cpu-baseline", "--no-full-prefill"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    chk = line["logits_check"]
+    ex = chk["step_exchange"]
+    assert ex["samples_per_rank"] == 4 and ex["all_gather_bytes"] == 4 * 92553 * 2
+    assert ex["own_row_intact"] is True and ex["finite"] is True
+    assert chk["gather_logits"] == {"samples": 4, "shape": [4, 92553], "own_samples_in_place": True}

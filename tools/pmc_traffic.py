@@ -38,11 +38,24 @@ def collect(path, counter, by_grid=False):
     return out
 
 
+def csrc_digest():
+    import glob, hashlib, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "mquant_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "mquant_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
     res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python3 bench.py --no-graph",
            "corrections": "KiB -> bytes; FETCH_SIZE x2 (gfx950 counts 128 B requests as 64 B); WRITE_SIZE as read",
            "commit": sys.argv[4] if len(sys.argv) > 4 else None,
+           # digest of the kernel sources the measured binary was built from (bench.py recomputes it: a later edit of any
+           # file under mquant_amd/csrc/ makes the line say traffic_stale: true)
+           "csrc_sha16": csrc_digest(),
            "command": sys.argv[5] if len(sys.argv) > 5 else None,
            "kernels": {}}
     for fam in sorted(set(fetch) | set(write)):
