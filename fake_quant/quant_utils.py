@@ -406,11 +406,14 @@ class ActQuantWrapper(torch.nn.Module):
         wq = self.weight_quantizers.get(name)
         if wq is None or wq.bits not in (4, 8):
             return False
-        if not getattr(wq, "sym", False):
-            # asymmetric weights (--w_asym): their zero points use the rank-1 epilogue term, which the split
-            # column and asymmetric activations need for themselves; per-channel only
-            if self.split or not getattr(wq, "perchannel", False) or (not qz.static and not getattr(qz, "sym", False)):
-                return False
+        # the epilogue has two rank-1 slots (mq_gemm_w4a8_rank2_ws): the split column, the zero points of asymmetric
+        # weights (--w_asym, per-channel only) and those of asymmetric dynamic activations (--a_asym) take one each
+        w_asym = not getattr(wq, "sym", False)
+        a_asym = (not qz.static) and not getattr(qz, "sym", False)
+        if w_asym and not getattr(wq, "perchannel", False):
+            return False
+        if int(bool(self.split)) + int(w_asym) + int(a_asym) > 2:
+            return False
         if qz.static and (qz.quantizer.scale is None or qz.quantizer.scale.numel() != 1):
             return False                                   # channel_wise scales: simulated path
         mod = self.module
@@ -423,8 +426,8 @@ class ActQuantWrapper(torch.nn.Module):
 
     def _dynamic_real_ok(self, x_dtype=torch.float32) -> bool:
         """Dynamic per-token int8 (the reference's default activation mode, quant_utils.py:205-268) also
-        has real-integer kernels: symmetric, and asymmetric (``--a_asym``) when the wrapper is not split
-        (the zero point travels through the same rank-1 epilogue term as the split column); per token,
+        has real-integer kernels: symmetric, and asymmetric (``--a_asym``; the zero point travels through a rank-1
+        epilogue term like the split column -- two such terms fit, ``_real_ready`` counts them); per token,
         per tensor (``act_per_tensor``) or group-wise (``groupsize``: symmetric, groups of 64 / 128 / 256 ... channels)."""
         qz = self.quantizer
         if not (2 <= qz.bits <= 8):
@@ -442,7 +445,7 @@ class ActQuantWrapper(torch.nn.Module):
         # (per-tensor ranges on half / bf16 activations: the reference keeps range, scale, zero point, x / scale and the
         #  level sum in x's dtype -- quant_utils.py:214-231, ``torch.tensor(0).to(x)``, the int64 maxq does not promote -- and
         #  mq_quantize_act_range_i8 rounds exactly there; goldens wrapper_dynpt16_* from the reference on fp16 / bf16)
-        return bool(getattr(qz, "sym", False)) or not self.split
+        return True
 
     def _real_parts(self, device) -> dict:
         """Everything the integer backend needs from this wrapper, on ``device``: weight levels and
@@ -482,15 +485,19 @@ class ActQuantWrapper(torch.nn.Module):
                                f"(mean distance {float(dev_steps):.3g} quantization steps); refusing to build the integer backend")
         w0 = None
         bias = wmod.bias
+        qz = self.quantizer
+        # asymmetric dynamic activations with the split column: the asymmetric quantizer kernels have no column to skip, so
+        # the engine quantizes the view x[:, 1:] and keeps the levels of columns 1.. only (engine.W4A8Linear.split_slice)
+        split_slice = bool(self.split) and (not qz.static) and not getattr(qz, "sym", False)
         if self.split:
-            levels = torch.cat((torch.zeros_like(levels[:, :1]), levels), dim=1).contiguous()
+            if not split_slice:
+                levels = torch.cat((torch.zeros_like(levels[:, :1]), levels), dim=1).contiguous()
             w0 = self.L1.weight.data.to(device).reshape(-1).float()
         had = None
         if self.online_full_had:
-            n = levels.shape[1]
+            n = levels.shape[1] + (1 if split_slice else 0)
             had = HadamardSpec(n, self.K, hadamard_utils._bits_for(self.had_K, self.K, device),
                                bool(self.fp32_had))
-        qz = self.quantizer
         dynamic = None
         s0, s1 = 1.0, None
         if qz.static:
@@ -503,13 +510,14 @@ class ActQuantWrapper(torch.nn.Module):
                            groupsize=(int(qz.groupsize) if getattr(qz, "groupsize", -1) > 0 and not qz.act_per_tensor else -1))
         return dict(levels=levels, scale=scale, bits=wq.bits,
                     bias=None if bias is None else bias.data.to(device), s0=s0, s1=s1,
-                    had=had, w0=w0, dynamic=dynamic, w_shift=w_shift)
+                    had=had, w0=w0, dynamic=dynamic, w_shift=w_shift, split_slice=split_slice)
 
     def _build_real(self, device):
         from mquant_amd.engine import W4A8Linear
         p = self._real_parts(device)
         self._real = W4A8Linear(p["levels"], p["scale"], p["bits"], p["bias"], p["s0"], p["s1"],
-                                had=p["had"], w0=p["w0"], dynamic=p["dynamic"], w_shift=p["w_shift"])
+                                had=p["had"], w0=p["w0"], dynamic=p["dynamic"], w_shift=p["w_shift"],
+                                split_slice=p["split_slice"])
         return self._real
 
     def _forward_real(self, x):

@@ -389,6 +389,20 @@ int mq_gemm_w4a8_rowscale_ws(const int8_t *a, long lda, const void *w, int w_bit
                              const float *x0, const float *w0, void *out, int out_dtype, long ldo,
                              void *workspace, size_t workspace_bytes, void *stream);
 
+/* Same GEMM with TWO rank-1 epilogue terms, for the flag combinations whose integer evaluation needs the slot twice
+ * (reference quant_utils.py:205-268 asymmetric activations, :367-376 split column, :446-509 asymmetric weights):
+ *   y[m][n] = ((float(acc) * s_x[m]) * s_w[n]) + bias[n] + x0[m]*w0[n] + x1[m]*w1[n]      (one rounding per operation, in that order)
+ * s_x[m] = s_x_rows[m] when s_x_rows is given (dynamic quantizers), else the static scale set(s) with row_sel.
+ *   --w_asym + --visual_split:  (x[m][0], L1 weight)                       and (s_x sum_k a[m][k], s_w (2^(b-1) - z_w))
+ *   --a_asym + --visual_split:  (x[m][0], L1 weight)                       and (s_x (2^(b-1) - z_x)[m], s_w sum_k q_w[n][k])
+ *   --w_asym + --a_asym:        (s_x (2^(b-1) - z_x)[m], s_w (sum_k q_w[n][k] + K (2^(b-1) - z_w)))  and (s_x sum_k a[m][k], s_w (2^(b-1) - z_w))
+ * (stored levels are q - 2^(bits-1) on an asymmetric side; goldens tests/golden/wrapper_rank2_*.npz from the reference's forward). */
+int mq_gemm_w4a8_rank2_ws(const int8_t *a, long lda, const void *w, int w_bits, long M, long N, long K_pad,
+                          float s_x0, float s_x1, const uint8_t *row_sel, const float *s_x_rows,
+                          const float *s_w, const float *bias, const float *x0, const float *w0,
+                          const float *x1, const float *w1, void *out, int out_dtype, long ldo,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
 int mq_gemm_w4a8_i32(const int8_t *a, long lda, const void *w, int w_bits,
                      long M, long N, long K_pad, int32_t *acc, long ldacc, void *stream);
 

@@ -45,6 +45,7 @@ struct GemmArgs {
     const void *residual = nullptr;  // [M, ldr] in the output dtype: out = cast(cast(y) + residual)
     long ldr = 0;
     const float *s_w, *bias, *x0, *w0;
+    const float *x1 = nullptr, *w1 = nullptr;   // second rank-1 term y += x1[m] * w1[n] (flag combinations that need the slot twice)
     void *out;
     long ldo;
     int splits;        // split-K factor (1 = none)
@@ -131,10 +132,10 @@ __device__ __forceinline__ void k_range_of_split(const GemmArgs &p, int split, i
     nk = p.kq + (split < p.kr ? 1 : 0);
 }
 
-// y = ((float(acc) * sx) * s_w[n]) + bias[n] + x0 * w0[n]; one rounding per operation.
+// y = ((float(acc) * sx) * s_w[n]) + bias[n] + x0 * w0[n] + x1 * w1[n]; one rounding per operation.
 template <int EPI>
 __device__ __forceinline__ void store_quad(const GemmArgs &p, long m, long n, v4i a, float sx,
-                                           float xz)
+                                           float xz, float x1v = 0.0f)
 {
     const bool full = (n + 4 <= p.N) && (p.ldo % 4 == 0);
     if (EPI == EPI_I32) {
@@ -157,6 +158,10 @@ __device__ __forceinline__ void store_quad(const GemmArgs &p, long m, long n, v4
         if (p.bias) t = t + p.bias[nn];
         if (p.x0) {
             const float pr = xz * p.w0[nn];
+            t = t + pr;
+        }
+        if (p.x1) {
+            const float pr = x1v * p.w1[nn];
             t = t + pr;
         }
         y[r] = t;
@@ -213,10 +218,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][
     constexpr int WN_COLS = TN * 16;                 // columns of the wave's sub-tile
     constexpr int SLAB_LD = WN_COLS * 4 + 16;        // bytes per slab row (+16: conflict-free)
     constexpr int PASS_MT =                          // m-tiles parked per pass (slab must fit)
-        (TM % 4 == 0 && NWAVES * 64 * (SLAB_LD + 8) <= RING_BYTES) ? 4
-        : (TM % 2 == 0 && NWAVES * 32 * (SLAB_LD + 8) <= RING_BYTES) ? 2 : 1;
+        (TM % 4 == 0 && NWAVES * 64 * (SLAB_LD + 16) <= RING_BYTES) ? 4
+        : (TM % 2 == 0 && NWAVES * 32 * (SLAB_LD + 16) <= RING_BYTES) ? 2 : 1;
     constexpr int PASS_ROWS = PASS_MT * 16;
-    constexpr int SLAB_BYTES = PASS_ROWS * SLAB_LD + PASS_ROWS * 8;
+    constexpr int SLAB_BYTES = PASS_ROWS * SLAB_LD + PASS_ROWS * 16;
     constexpr int LANES_PER_ROW = WN_COLS / 8;       // 8 outputs per lane
     constexpr int ROWS_PER_IT = 64 / LANES_PER_ROW;
     static_assert(NWAVES * SLAB_BYTES <= RING_BYTES, "epilogue slab must fit the ring");
@@ -232,18 +237,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][
     const bool n_full = (n + 8 <= p.N) && p.vec_ok;
 
     // per-channel parameters of this lane's 8 outputs: two 16-byte loads each when aligned
-    float swv[8], bsv[8], wzv[8];
+    float swv[8], bsv[8], wzv[8], w1v[8];
     if (EPI != EPI_I32 && !to_partial) {
         if (n_full && p.par_ok) {
             const v4f s0 = *reinterpret_cast<const v4f *>(p.s_w + n), s1 = *reinterpret_cast<const v4f *>(p.s_w + n + 4);
-            v4f b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0, z0 = b0, z1 = b0;
+            v4f b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0, z0 = b0, z1 = b0, u0 = b0, u1 = b0;
             if (p.bias) { b0 = *reinterpret_cast<const v4f *>(p.bias + n); b1 = *reinterpret_cast<const v4f *>(p.bias + n + 4); }
             if (p.w0) { z0 = *reinterpret_cast<const v4f *>(p.w0 + n); z1 = *reinterpret_cast<const v4f *>(p.w0 + n + 4); }
+            if (p.w1) { u0 = *reinterpret_cast<const v4f *>(p.w1 + n); u1 = *reinterpret_cast<const v4f *>(p.w1 + n + 4); }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 swv[e] = s0[e]; swv[4 + e] = s1[e];
                 bsv[e] = b0[e]; bsv[4 + e] = b1[e];
                 wzv[e] = z0[e]; wzv[4 + e] = z1[e];
+                w1v[e] = u0[e]; w1v[4 + e] = u1[e];
             }
         } else {
 #pragma unroll
@@ -252,12 +259,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][
                 swv[e] = (n < p.N) ? p.s_w[nn] : 0.0f;
                 bsv[e] = (p.bias && n < p.N) ? p.bias[nn] : 0.0f;
                 wzv[e] = (p.w0 && n < p.N) ? p.w0[nn] : 0.0f;
+                w1v[e] = (p.w1 && n < p.N) ? p.w1[nn] : 0.0f;
             }
         }
     }
     // per-row parameters (activation scale set, split term) are fetched once per pass, one row
     // per lane, and parked behind the slab so the store loop never waits on global memory
-    float *rowpar = reinterpret_cast<float *>(slab + PASS_ROWS * SLAB_LD);   // [PASS_ROWS][2]
+    float *rowpar = reinterpret_cast<float *>(slab + PASS_ROWS * SLAB_LD);   // [PASS_ROWS][4]: s_x, x0, x1, unused
 
 #pragma unroll
     for (int pass = 0; pass < TM / PASS_MT; ++pass) {
@@ -269,14 +277,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][
                     acc[i][pass * PASS_MT + jj];
         if (EPI != EPI_I32 && !to_partial && lane < PASS_ROWS) {
             const long mr = m0 + (wm * TM + pass * PASS_MT) * 16 + lane;
-            float sxl = p.sx0, xzl = 0.0f;
+            float sxl = p.sx0, xzl = 0.0f, x1l = 0.0f;
             if (mr < p.M) {
                 if (p.sx_vec) sxl = p.sx_vec[mr];
                 else if (p.row_sel && p.row_sel[mr]) sxl = p.sx1;
                 if (p.x0) xzl = p.x0[mr];
+                if (p.x1) x1l = p.x1[mr];
             }
-            rowpar[lane * 2] = sxl;
-            rowpar[lane * 2 + 1] = xzl;
+            rowpar[lane * 4] = sxl;
+            rowpar[lane * 4 + 1] = xzl;
+            rowpar[lane * 4 + 2] = x1l;
         }
         // the slab is wave-private: LDS operations of one wave complete in order
 #pragma unroll 1
@@ -305,8 +315,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][
             }
             // int4 weights: the accumulator carries a factor 16; float(16 a) * (s_x / 16) is the same real
             // product as float(a) * s_x (exact power-of-two rescale on both sides): same bits, no shift
-            const float sx = p.acc_float ? 1.0f : ((W_BITS == 4) ? rowpar[row * 2] * 0.0625f : rowpar[row * 2]);
-            const float xz = rowpar[row * 2 + 1];
+            const float sx = p.acc_float ? 1.0f : ((W_BITS == 4) ? rowpar[row * 4] * 0.0625f : rowpar[row * 4]);
+            const float xz = rowpar[row * 4 + 1], x1r = rowpar[row * 4 + 2];
             float res[8];
             if (p.residual) {   // issued ahead of the arithmetic below
                 if (EPI == EPI_F32) {
@@ -331,7 +341,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][
             }
             float y[8];
             typedef float v2f __attribute__((ext_vector_type(2)));   // v_pk_mul_f32 / v_pk_add_f32: two outputs per instruction
-            const v2f sx2 = v2f{sx, sx}, xz2 = v2f{xz, xz};
+            const v2f sx2 = v2f{sx, sx}, xz2 = v2f{xz, xz}, x12 = v2f{x1r, x1r};
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
                 v2f t = p.acc_float ? v2f{__int_as_float(a[e]), __int_as_float(a[e + 1])} : v2f{(float)a[e], (float)a[e + 1]};
@@ -340,6 +350,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][
                 if (p.bias) t = t + v2f{bsv[e], bsv[e + 1]};
                 if (p.x0) {
                     const v2f pr = xz2 * v2f{wzv[e], wzv[e + 1]};
+                    t = t + pr;
+                }
+                if (p.x1) {
+                    const v2f pr = x12 * v2f{w1v[e], w1v[e + 1]};
                     t = t + pr;
                 }
                 y[e] = t[0];

@@ -250,13 +250,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p)
                     if (n + r < p.N) a[r] += src[r];
             }
         }
-        float sx = p.sx0, xz = 0.0f;
+        float sx = p.sx0, xz = 0.0f, x1v = 0.0f;
         if (EPI != EPI_I32) {
             if (p.sx_vec) sx = p.sx_vec[m];
             else if (p.row_sel && p.row_sel[m]) sx = p.sx1;
             if (p.x0) xz = p.x0[m];
+            if (p.x1) x1v = p.x1[m];
         }
-        store_quad<EPI>(p, m, n, a, sx, xz);
+        store_quad<EPI>(p, m, n, a, sx, xz, x1v);
     }
 }
 
@@ -598,7 +599,8 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
                        const float *s_w, const float *bias, const float *x0, const float *w0,
                        void *out, int epi, long ldo, void *workspace, size_t workspace_bytes,
                        void *stream, const float *sx_vec = nullptr, const void *residual = nullptr,
-                       long ldr = 0, const float *sx_groups = nullptr, long n_groups = 0, int group_k = 0)
+                       long ldr = 0, const float *sx_groups = nullptr, long n_groups = 0, int group_k = 0,
+                       const float *x1 = nullptr, const float *w1 = nullptr)
 {
     MQ_REQUIRE(M >= 0 && N >= 0 && K_pad >= 0, "mq_gemm_w4a8: negative shape");
     if (M == 0 || N == 0) return MQ_OK;
@@ -612,6 +614,7 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
     MQ_REQUIRE(ldo >= N, "mq_gemm_w4a8: ldo < N");
     MQ_REQUIRE(epi == EPI_I32 || s_w, "mq_gemm_w4a8: s_w is required");
     MQ_REQUIRE((x0 == nullptr) == (w0 == nullptr), "mq_gemm_w4a8: x0 and w0 go together");
+    MQ_REQUIRE((x1 == nullptr) == (w1 == nullptr) && (x1 == nullptr || epi != EPI_I32), "mq_gemm_w4a8: x1 and w1 go together (floating-point outputs)");
     // int32 headroom: |acc| <= K * 128 * 8 * 16 (int4 in the high nibble) or K * 128 * 128
     MQ_REQUIRE(K_pad <= 131072L, "mq_gemm_w4a8: K too large for int32 accumulation");
     MQ_REQUIRE(!workspace || ((uintptr_t)workspace) % 16 == 0, "mq_gemm_w4a8: workspace must be 16-byte aligned");
@@ -621,13 +624,14 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
     p.n_pairs = ceil_div(N, 32);
     p.sx0 = s_x0; p.sx1 = s_x1; p.row_sel = row_sel; p.s_w = s_w; p.bias = bias; p.x0 = x0; p.w0 = w0;
     p.sx_vec = sx_vec;
+    p.x1 = x1; p.w1 = w1;
     p.residual = residual; p.ldr = ldr;
     MQ_REQUIRE(!residual || (epi != EPI_I32 && ldr >= N), "mq_gemm_w4a8: bad residual geometry");
     p.res_vec = residual && (((uintptr_t)residual) % 16 == 0) && ((ldr * ((epi == EPI_F32) ? 4 : 2)) % 16 == 0);
     p.out = out; p.ldo = ldo;
     if (sx_groups) {
         // group-wise activation scales: the symmetric 128 x 128 kernel, no split-K, floating-point outputs only
-        MQ_REQUIRE(epi != EPI_I32 && group_k > 0 && (group_k == 64 || group_k % 128 == 0) && K_pad % 64 == 0 && !sx_vec,
+        MQ_REQUIRE(epi != EPI_I32 && group_k > 0 && (group_k == 64 || group_k % 128 == 0) && K_pad % 64 == 0 && !sx_vec && !x1,
                    "mq_gemm_w4a8_groupscale: group size %d (64 or a multiple of 128)", group_k);
         p.sx_groups = sx_groups; p.n_groups = n_groups; p.group_k = group_k; p.acc_float = 1;
         p.splits = 1; p.partial = nullptr;
@@ -655,7 +659,7 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
     auto al16 = [](const void *q) { return q == nullptr || ((uintptr_t)q) % 16 == 0; };
     const size_t osz = (epi == EPI_F16 || epi == EPI_BF16) ? 2 : 4;
     p.vec_ok = (N % 8 == 0) && (ldo % 8 == 0) && (((uintptr_t)out) % 16 == 0);
-    p.par_ok = al16(s_w) && al16(bias) && al16(w0);
+    p.par_ok = al16(s_w) && al16(bias) && al16(w0) && al16(w1);
     (void)osz;
     if (p.splits > 1)
         MQ_REQUIRE((size_t)p.splits * M * N * 4 <= workspace_bytes, "mq_gemm_w4a8: workspace too small for split-K");
@@ -738,6 +742,21 @@ extern "C" int mq_gemm_w4a8_rowscale_ws(const int8_t *a, long lda, const void *w
     if (!s_x_rows) return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_rowscale_ws: s_x_rows is required");
     return mq::gemm_common(a, lda, w, w_bits, M, N, K_pad, 1.0f, 1.0f, nullptr, s_w, bias, x0, w0,
                            out, out_dtype, ldo, workspace, workspace_bytes, stream, s_x_rows);
+}
+
+extern "C" int mq_gemm_w4a8_rank2_ws(const int8_t *a, long lda, const void *w, int w_bits, long M, long N, long K_pad,
+                                     float s_x0, float s_x1, const uint8_t *row_sel, const float *s_x_rows,
+                                     const float *s_w, const float *bias, const float *x0, const float *w0,
+                                     const float *x1, const float *w1, void *out, int out_dtype, long ldo,
+                                     void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (out_dtype != MQ_F16 && out_dtype != MQ_BF16 && out_dtype != MQ_F32)
+        return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_rank2_ws: unknown output dtype %d", out_dtype);
+    if (M == 0 || N == 0) return MQ_OK;
+    if (!x0 || !w0 || !x1 || !w1) return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_rank2_ws: both rank-1 terms are required (one term: mq_gemm_w4a8_ws)");
+    return mq::gemm_common(a, lda, w, w_bits, M, N, K_pad, s_x_rows ? 1.0f : s_x0, s_x_rows ? 1.0f : s_x1, s_x_rows ? nullptr : row_sel,
+                           s_w, bias, x0, w0, out, out_dtype, ldo, workspace, workspace_bytes, stream, s_x_rows, nullptr, 0,
+                           nullptr, 0, 0, x1, w1);
 }
 
 extern "C" int mq_gemm_w4a8_groupscale(const int8_t *a, long lda, const void *w, int w_bits, long M, long N,

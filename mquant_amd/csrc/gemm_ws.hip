@@ -56,6 +56,8 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
     float *par_wz = par_bs + BN;                                  // [BN] w0 (split term)
     float *par_sx = par_wz + BN;                                  // [BM] activation scale of the row
     float *par_xz = par_sx + BM;                                  // [BM] x0 of the row
+    float *par_w1 = par_xz + BM;                                  // [BN] w1 (second rank-1 term)
+    float *par_x1 = par_w1 + BN;                                  // [BM] x1 of the row
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -161,7 +163,7 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
         const int wm = wave / MW_N, wn = wave % MW_N;
         // Epilogue parameters: straight-line loads at clamped indices now (no use before the k-loop ends,
         // so B(0) does not wait for these cold misses), selected and parked in LDS after the loop.
-        float pr_sw = 0.0f, pr_bs = 0.0f, pr_wz = 0.0f, pr_sx = 0.0f, pr_xz = 0.0f;
+        float pr_sw = 0.0f, pr_bs = 0.0f, pr_wz = 0.0f, pr_sx = 0.0f, pr_xz = 0.0f, pr_w1 = 0.0f, pr_x1 = 0.0f;
         unsigned pr_rs = 0;
         if (EPI != EPI_I32) {
             const int tn = tid < BN ? tid : BN - 1, tm = tid < BM ? tid : BM - 1;
@@ -172,6 +174,8 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
             pr_wz = (p.w0 ? p.w0 : p.s_w)[nc];
             pr_sx = (p.sx_vec ? p.sx_vec : p.s_w)[p.sx_vec ? mc : 0];
             pr_xz = (p.x0 ? p.x0 : p.s_w)[p.x0 ? mc : 0];
+            pr_w1 = (p.w1 ? p.w1 : p.s_w)[nc];
+            pr_x1 = (p.x1 ? p.x1 : p.s_w)[p.x1 ? mc : 0];
             pr_rs = (p.row_sel ? p.row_sel : reinterpret_cast<const uint8_t *>(p.s_w))[p.row_sel ? mc : 0];
         }
 #pragma unroll
@@ -298,6 +302,7 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
                 par_sw[tid] = ok ? pr_sw : 0.0f;
                 par_bs[tid] = (ok && p.bias) ? pr_bs : 0.0f;
                 par_wz[tid] = (ok && p.w0) ? pr_wz : 0.0f;
+                par_w1[tid] = (ok && p.w1) ? pr_w1 : 0.0f;
             }
             if (tid < BM) {
                 const bool ok = m0 + tid < p.M;
@@ -308,6 +313,7 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
                 }
                 par_sx[tid] = sx;
                 par_xz[tid] = (ok && p.x0) ? pr_xz : 0.0f;
+                par_x1[tid] = (ok && p.x1) ? pr_x1 : 0.0f;
             }
         }
     }
@@ -337,13 +343,14 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
     const long n = n0 + c8;
     const bool n_full = (n + 8 <= p.N) && p.vec_ok;
     const bool to_partial = p.splits > 1;
-    float swv[8], bsv[8], wzv[8];
+    float swv[8], bsv[8], wzv[8], w1v[8];
     if (EPI != EPI_I32 && !to_partial) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             swv[e] = par_sw[c8 + e];
             bsv[e] = par_bs[c8 + e];
             wzv[e] = par_wz[c8 + e];
+            w1v[e] = par_w1[c8 + e];
         }
     }
     // Fast path (what every Linear of the prefill takes): whole 8-channel groups, fp16 / bf16 / fp32
@@ -354,7 +361,7 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
         constexpr int ITERS = (BM + RPI - 1) / RPI;
         const int lrow = tid / LPR;
         v4i q0[ITERS], q1[ITERS];
-        float sxr[ITERS], xzr[ITERS];
+        float sxr[ITERS], xzr[ITERS], x1r[ITERS];
 #pragma unroll
         for (int t = 0; t < ITERS; ++t) {
             const int row = (t * RPI + lrow < BM) ? t * RPI + lrow : BM - 1;
@@ -362,6 +369,7 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
             q1[t] = *reinterpret_cast<const v4i *>(smem + row * PITCH + c8 * 4 + 16);
             sxr[t] = par_sx[row];
             xzr[t] = par_xz[row];
+            x1r[t] = par_x1[row];
         }
         // Packed fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32: two outputs per instruction, each lane
         // element rounded like the scalar form).  int4 weights: the accumulator carries a factor 16
@@ -369,20 +377,21 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
         // float(a) * s_x with an exact power-of-two rescale on both sides, so one rounding, same bits,
         // and the shift is gone.
         typedef float v2f __attribute__((ext_vector_type(2)));
-        const bool has_bias = p.bias != nullptr, has_x0 = p.x0 != nullptr;
-        v2f sw2[4], bs2[4], wz2[4];
+        const bool has_bias = p.bias != nullptr, has_x0 = p.x0 != nullptr, has_x1 = p.x1 != nullptr;
+        v2f sw2[4], bs2[4], wz2[4], w12[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             sw2[e] = v2f{swv[2 * e], swv[2 * e + 1]};
             bs2[e] = v2f{bsv[2 * e], bsv[2 * e + 1]};
             wz2[e] = v2f{wzv[2 * e], wzv[2 * e + 1]};
+            w12[e] = v2f{w1v[2 * e], w1v[2 * e + 1]};
         }
 #pragma unroll
         for (int t = 0; t < ITERS; ++t) {
             const long m = m0 + t * RPI + lrow;
             const int a[8] = {q0[t][0], q0[t][1], q0[t][2], q0[t][3], q1[t][0], q1[t][1], q1[t][2], q1[t][3]};
             const float sxe = (W_BITS == 4) ? sxr[t] * 0.0625f : sxr[t];
-            const v2f sx2 = v2f{sxe, sxe}, xz2 = v2f{xzr[t], xzr[t]};
+            const v2f sx2 = v2f{sxe, sxe}, xz2 = v2f{xzr[t], xzr[t]}, x12 = v2f{x1r[t], x1r[t]};
             float y[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -392,6 +401,10 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
                 if (has_bias) v = v + bs2[e];
                 if (has_x0) {
                     const v2f pr = xz2 * wz2[e];
+                    v = v + pr;
+                }
+                if (has_x1) {
+                    const v2f pr = x12 * w12[e];
                     v = v + pr;
                 }
                 y[2 * e] = v[0];
@@ -436,7 +449,7 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
             }
             continue;
         }
-        const float sx = par_sx[row], xz = par_xz[row];
+        const float sx = par_sx[row], xz = par_xz[row], x1s = par_x1[row];
         float res[8];
         if (p.residual) {
             if (EPI == EPI_F32) {
@@ -467,6 +480,10 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
             if (p.bias) t = t + bsv[e];
             if (p.x0) {
                 const float pr = xz * wzv[e];
+                t = t + pr;
+            }
+            if (p.x1) {
+                const float pr = x1s * w1v[e];
                 t = t + pr;
             }
             if (p.residual) {   // torch: hidden + linear(x), the Linear's output rounded first
@@ -506,7 +523,7 @@ static int launch_ws(const GemmArgs &p, hipStream_t st)
 {
     constexpr int PIECES = (BM / 16) * 2 + ((W_BITS == 4) ? (BN / 32) * 2 : (BN / 16) * 2);
     constexpr int RING = S * PIECES * 1024, SLAB = BM * (BN * 4 + 16);
-    constexpr int SMEM = (RING > SLAB ? RING : SLAB) + (3 * BN + 2 * BM) * 4;
+    constexpr int SMEM = (RING > SLAB ? RING : SLAB) + (4 * BN + 3 * BM) * 4;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
     auto kern = gemm_ws_kernel<BM, BN, MW_M, MW_N, NL, S, W_BITS, EPI>;
     int rc = ensure_dynamic_lds((const void *)kern, SMEM);

@@ -74,21 +74,24 @@ class W4A8Linear:
                  bias: Optional[torch.Tensor], s_x0: float, s_x1: Optional[float] = None,
                  had: Optional[HadamardSpec] = None, w0: Optional[torch.Tensor] = None,
                  in_features: Optional[int] = None, dynamic: Optional[dict] = None,
-                 w_shift: Optional[torch.Tensor] = None):
+                 w_shift: Optional[torch.Tensor] = None, split_slice: bool = False):
         assert levels.is_cuda and levels.dtype == torch.int8 and levels.dim() == 2
         self.N, self.K = levels.shape
         self.K_pad = ops.ceil_to(self.K, 128)
         self.w_bits = w_bits
         self.split = w0 is not None
-        self.w_img = ops.prepack(levels, w_bits, zero_col0=self.split)
+        #: the split column with ASYMMETRIC dynamic activations: ``levels`` holds the quantized columns 1.. only (no zero
+        #: column), the quantizer runs on the view x[:, 1:] and column 0 is gathered in floating point
+        self.split_slice = bool(split_slice)
+        assert not self.split_slice or (self.split and dynamic is not None and not dynamic.get("sym", True))
+        self.w_img = ops.prepack(levels, w_bits, zero_col0=self.split and not self.split_slice)
         self.s_w = s_w.reshape(-1).to(torch.float32).contiguous()
         self.bias = None if bias is None else bias.reshape(-1).to(torch.float32).contiguous()
         self.w0 = None if w0 is None else w0.reshape(-1).to(torch.float32).contiguous()
         #: asymmetric weights (--w_asym): levels are stored minus 2^(bits-1) and w_shift[n] = s_w[n] (2^(bits-1) -
-        #: z_w[n]); the zero points come back as the rank-1 term (s_x sum_k a[m][k]) * w_shift[n] -- the slot of
-        #: the split column, so not both
+        #: z_w[n]); the zero points come back as the rank-1 term (s_x sum_k a[m][k]) * w_shift[n].  The epilogue has TWO
+        #: rank-1 slots (mq_gemm_w4a8_rank2_ws): any two of {split column, asymmetric weights, asymmetric activations}
         self.w_shift = None if w_shift is None else w_shift.reshape(-1).to(torch.float32).contiguous()
-        assert not (self.split and self.w_shift is not None), "asymmetric weights and the split column share the rank-1 epilogue term"
         self.s_x0 = float(s_x0)
         self.s_x1 = None if s_x1 is None else float(s_x1)
         self.had = had
@@ -98,11 +101,17 @@ class W4A8Linear:
         self.dynamic = dynamic
         self.w_colsum = None
         if dynamic is not None and not dynamic.get("sym", True):
-            assert not self.split and self.w_shift is None, "asymmetric activations need the rank-1 epilogue term for themselves"
+            # s_x (2^(b-1) - z_x)[m] multiplies s_w sum_k W~-levels[n][k]; with asymmetric weights the level of column k is
+            # p + (2^(bw-1) - z_w): the constant part adds Kq * w_shift[n] (Kq = quantized columns)
             self.w_colsum = (levels.to(torch.int32).sum(dim=1).to(torch.float32) * self.s_w).contiguous()
+            if self.w_shift is not None:
+                kq = levels.shape[1] - (1 if self.split and not self.split_slice else 0)
+                self.w_colsum = (self.w_colsum + float(kq) * self.w_shift).contiguous()
+        n_terms = int(self.split) + int(self.w_shift is not None) + int(self.w_colsum is not None)
+        assert n_terms <= 2, "the epilogue has two rank-1 slots: split column, asymmetric weights and asymmetric activations do not fit together"
         self.in_features = self.K if in_features is None else in_features
         if had is not None:
-            assert had.n == self.K, "Hadamard size must equal the (padded) reduction dim"
+            assert had.n == self.K + (1 if self.split_slice else 0), "Hadamard size must equal the (padded) reduction dim"
 
     @classmethod
     def from_float(cls, w: torch.Tensor, w_bits: int, s_x0: float, s_x1: Optional[float] = None,
@@ -161,7 +170,12 @@ class W4A8Linear:
              row_sel: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
         w0 = self.w0
         if self.w_shift is not None:
-            x0, w0 = ops.act_rowsum_scaled(a, self.s_x0, self.s_x1, row_sel), self.w_shift
+            xs = ops.act_rowsum_scaled(a, self.s_x0, self.s_x1, row_sel)
+            if self.split:                   # --w_asym + --visual_split: both rank-1 slots
+                return ops.gemm_w4a8_rank2(a, self.w_img, self.w_bits, self.N, self.s_w, x0, self.w0, xs, self.w_shift,
+                                           s_x0=self.s_x0, s_x1=self.s_x1, row_sel=row_sel, bias=self.bias,
+                                           out_dtype=out_dtype, out=out)
+            x0, w0 = xs, self.w_shift
         return ops.gemm_w4a8(a, self.w_img, self.w_bits, self.N, self.s_x0, self.s_w,
                              s_x1=self.s_x1, row_sel=row_sel, bias=self.bias, x0=x0, w0=w0,
                              out_dtype=out_dtype, out=out)
@@ -171,6 +185,7 @@ class W4A8Linear:
         """residual + Linear in one launch (same rounding as torch's `hidden + linear(x)`)."""
         w0 = self.w0
         if self.w_shift is not None:
+            assert not self.split, "the residual epilogue carries one rank-1 term"
             x0, w0 = ops.act_rowsum_scaled(a, self.s_x0, self.s_x1, row_sel), self.w_shift
         return ops.gemm_w4a8_residual(a, self.w_img, self.w_bits, self.N, self.s_x0, self.s_w, residual,
                                       s_x1=self.s_x1, row_sel=row_sel, bias=self.bias, x0=x0, w0=w0, out=out)
@@ -187,27 +202,36 @@ class W4A8Linear:
             a, s_groups = ops.quantize_act_group_i8(x2, g, self.dynamic["bits"], self.dynamic["clip_ratio"], out=a)
             return ops.gemm_w4a8_groupscale(a, self.w_img, self.w_bits, self.N, s_groups, g, self.s_w, bias=self.bias,
                                             out_dtype=x2.dtype, out=out)
+        asym = self.w_colsum is not None
+        xq, x0 = x2, None
+        if self.split_slice:                 # asymmetric activations + split column: quantize the view x[:, 1:]
+            xq, x0 = x2[:, 1:], x2[:, 0].float().contiguous()
         if self.dynamic.get("per_tensor", False):
-            asym = self.w_colsum is not None
-            a, s_rows, _, shift, x0 = ops.quantize_act_tensor_i8(x2, self.dynamic["bits"], self.dynamic["clip_ratio"],
-                                                                 asym=asym, skip_col0=self.split, out=a)
-            w0 = self.w_colsum if asym else self.w0
-            x0 = shift if asym else x0
-            if self.w_shift is not None:
-                x0, w0 = ops.act_rowsum_scaled(a, s_x_rows=s_rows), self.w_shift
-            return ops.gemm_w4a8_rowscale(a, self.w_img, self.w_bits, self.N, s_rows, self.s_w, bias=self.bias,
-                                          x0=x0, w0=w0, out_dtype=x2.dtype, out=out)
-        if self.w_colsum is not None:
-            a, s_rows, _, shift = ops.quantize_act_dyn_asym_i8(x2, self.dynamic["bits"], self.dynamic["clip_ratio"], out=a)
-            return ops.gemm_w4a8_rowscale(a, self.w_img, self.w_bits, self.N, s_rows, self.s_w, bias=self.bias,
-                                          x0=shift, w0=self.w_colsum, out_dtype=x2.dtype, out=out)
-        a, s_rows, x0 = ops.quantize_act_dyn_i8(x2, self.dynamic["bits"], self.dynamic["clip_ratio"],
-                                                skip_col0=self.split, out=a)
-        w0 = self.w0
+            a, s_rows, _, shift, x0q = ops.quantize_act_tensor_i8(xq, self.dynamic["bits"], self.dynamic["clip_ratio"],
+                                                                  asym=asym, skip_col0=self.split and not self.split_slice, out=a)
+        elif asym:
+            a, s_rows, _, shift = ops.quantize_act_dyn_asym_i8(xq, self.dynamic["bits"], self.dynamic["clip_ratio"], out=a)
+            x0q = None
+        else:
+            a, s_rows, x0q = ops.quantize_act_dyn_i8(xq, self.dynamic["bits"], self.dynamic["clip_ratio"],
+                                                     skip_col0=self.split, out=a)
+            shift = None
+        if x0 is None:
+            x0 = x0q
+        # the rank-1 epilogue terms (row factor, channel factor) of this layer, at most two
+        terms = []
+        if self.split:
+            terms.append((x0, self.w0))
+        if asym:
+            terms.append((shift, self.w_colsum))
         if self.w_shift is not None:
-            x0, w0 = ops.act_rowsum_scaled(a, s_x_rows=s_rows), self.w_shift
+            terms.append((ops.act_rowsum_scaled(a, s_x_rows=s_rows), self.w_shift))
+        if len(terms) == 2:
+            return ops.gemm_w4a8_rank2(a, self.w_img, self.w_bits, self.N, self.s_w, terms[0][0], terms[0][1], terms[1][0],
+                                       terms[1][1], s_x_rows=s_rows, bias=self.bias, out_dtype=x2.dtype, out=out)
+        xt, wt = terms[0] if terms else (None, None)
         return ops.gemm_w4a8_rowscale(a, self.w_img, self.w_bits, self.N, s_rows, self.s_w, bias=self.bias,
-                                      x0=x0, w0=w0, out_dtype=x2.dtype, out=out)
+                                      x0=xt, w0=wt, out_dtype=x2.dtype, out=out)
 
     def forward(self, x: torch.Tensor, row_sel: Optional[torch.Tensor] = None,
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:

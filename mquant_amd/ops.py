@@ -697,6 +697,33 @@ def gemm_w4a8_rowscale(a: torch.Tensor, w_img: torch.Tensor, w_bits: int, N: int
 
 
 @_on_device
+def gemm_w4a8_rank2(a: torch.Tensor, w_img: torch.Tensor, w_bits: int, N: int, s_w: torch.Tensor, x0: torch.Tensor, w0: torch.Tensor,
+                    x1: torch.Tensor, w1: torch.Tensor, *, s_x0: float = 1.0, s_x1: Optional[float] = None,
+                    row_sel: Optional[torch.Tensor] = None, s_x_rows: Optional[torch.Tensor] = None,
+                    bias: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.float16,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The GEMM with TWO rank-1 epilogue terms, y += x0[m] * w0[n] + x1[m] * w1[n] (``mq_gemm_w4a8_rank2_ws``): the flag
+    combinations that need the slot twice (asymmetric weights / asymmetric activations / the split column, two at a time).
+    ``s_x_rows`` (one scale per row, dynamic quantizers) overrides the static scale set."""
+    _need_cuda(a, w_img, s_w, x0, w0, x1, w1, row_sel, s_x_rows, bias, out)
+    aptr, lda, M, K_pad = _a_args(a)
+    for t in (x0, x1):
+        assert t.dtype == torch.float32 and t.numel() == M and t.is_contiguous()
+    for t in (w0, w1):
+        assert t.dtype == torch.float32 and t.numel() == N and t.is_contiguous()
+    if s_x_rows is not None:
+        assert s_x_rows.dtype == torch.float32 and s_x_rows.numel() == M and s_x_rows.is_contiguous()
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    ws = splitk_workspace(a.device)
+    call("mq_gemm_w4a8_rank2_ws", aptr, lda, w_img.data_ptr(), w_bits, M, N, K_pad, float(s_x0),
+         float(s_x0 if s_x1 is None else s_x1), _ptr(row_sel), _ptr(s_x_rows), s_w.data_ptr(), _ptr(bias),
+         x0.data_ptr(), w0.data_ptr(), x1.data_ptr(), w1.data_ptr(), out.data_ptr(), dtype_code(out.dtype), out.stride(0),
+         _ptr(ws), 0 if ws is None else ws.numel(), _stream())
+    return out
+
+
+@_on_device
 def gemm_w4a8_residual(a: torch.Tensor, w_img: torch.Tensor, w_bits: int, N: int, s_x0: float, s_w: torch.Tensor,
                        residual: torch.Tensor, *, s_x1: Optional[float] = None, row_sel: Optional[torch.Tensor] = None,
                        bias: Optional[torch.Tensor] = None, x0: Optional[torch.Tensor] = None,

@@ -163,7 +163,12 @@ def gemm_i32(a, w) -> np.ndarray:
     return acc
 
 
-def epilogue(acc, sx0, s_w, bias=None, sx1=None, row_sel=None, x0=None, w0=None):
+def epilogue(acc, sx0, s_w, bias=None, sx1=None, row_sel=None, x0=None, w0=None, x1=None, w1=None):
+    """y = ((float(acc) * s_x) * s_w[n]) + bias[n] + x0[m] * w0[n] [+ x1[m] * w1[n]], one fp32 rounding per operation, the terms
+    added in that order (the second rank-1 term: flag combinations that need the epilogue slot twice, csrc/gemm_common.h)."""
+    if x1 is not None:
+        y = epilogue(acc, sx0, s_w, bias=bias, sx1=sx1, row_sel=row_sel, x0=x0, w0=w0)
+        return (y + (_f32(x1).reshape(-1, 1) * _f32(w1)[None, :]).astype(np.float32)).astype(np.float32)
     acc = np.ascontiguousarray(acc, dtype=np.int32)
     M, N = acc.shape
     s_w = _f32(s_w).reshape(-1)

@@ -139,13 +139,21 @@ def test_wrapper_asymmetric_dynamic_mode_matches_reference_forward(golden_dir, c
     np.testing.assert_array_equal(zero.cpu().numpy(), g["zero"])
     np.testing.assert_array_equal(a.cpu().numpy()[:, :64], g["qx_head"])
     np.testing.assert_array_equal(ops.gemm_w4a8_i32(a, real.w_img, 4, N).cpu().numpy(), g["acc"])
-    # a split wrapper keeps the simulated path in this mode (one rank-1 epilogue slot)
+    # a split wrapper runs the integer kernels in this mode too (two rank-1 epilogue slots, tests/test_gpu_rank2.py); split
+    # column + asymmetric weights + asymmetric activations would need three and stays simulated
     wrap2 = qu.ActQuantWrapper(torch.nn.Linear(256, 32).to(DEV))
     wrap2.split = True
     wrap2.split_weights()
     rtn_module(wrap2, "layer", 4, True, False, [], {})
     wrap2.quantizer.configure(bits=8, sym=False)
-    assert not wrap2._real_ready(torch.zeros(4, 256, device=DEV))
+    assert wrap2._real_ready(torch.zeros(4, 256, device=DEV))
+    wrap3 = qu.ActQuantWrapper(torch.nn.Linear(256, 32).to(DEV))
+    wrap3.split = True
+    wrap3.split_weights()
+    rtn_module(wrap3, "layer", 4, False, False, [], {})
+    wrap3.quantizer.configure(bits=8, sym=False)
+    assert not wrap3._real_ready(torch.zeros(4, 256, device=DEV))
+    assert torch.isfinite(wrap3(torch.from_numpy(make_x(3, (4, 256))).to(DEV))).all()
 
 
 @pytest.mark.parametrize("M,K,dtype,bits,clip,asym,skip", [(768, 3584, torch.float16, 8, 1.0, False, False), (33, 1000, torch.float16, 8, 0.9, True, False),

@@ -263,8 +263,8 @@ def test_wrapper_with_asymmetric_weights_matches_reference_forward(golden_dir, c
     else:
         a, _ = ops.quantize_act_i8(xr, float(g["s_x"]))
     np.testing.assert_array_equal(ops.gemm_w4a8_i32(a, real.w_img, w_bits, N).cpu().numpy(), g["acc"])
-    # combinations that need the rank-1 slot twice keep the simulated path
+    # combinations that need the rank-1 slot twice run the integer kernels as well (tests/test_gpu_rank2.py)
     wrap2 = qu.ActQuantWrapper(torch.nn.Linear(256, 32).to(DEV))
     rtn_module(wrap2, "layer", 4, False, False, [], {})
     wrap2.quantizer.configure(bits=8, sym=False)
-    assert not wrap2._real_ready(torch.zeros(4, 256, device=DEV))
+    assert wrap2._real_ready(torch.zeros(4, 256, device=DEV))

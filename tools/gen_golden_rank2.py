@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Goldens for the flag combinations whose integer evaluation needs the rank-1 epilogue term TWICE
+(VERDICT r3 "missing" #3): asymmetric weights with the split column (--w_asym + --visual_split), asymmetric weights
+with asymmetric dynamic activations (--w_asym + --a_asym, per token and per tensor), asymmetric dynamic activations
+with the split column (--a_asym + --visual_split).  The REFERENCE's ActQuantWrapper.forward
+(fake_quant/quant_utils.py:330-391) after an RTN pass with its own WeightQuantizer (quant_utils.py:446-518), on CPU.
+Writes tests/golden/wrapper_rank2_<case>.npz: outputs, scales, zero points, and the integer accumulators / row sums
+restated from the reference's own quantizers.  Build-container only."""
+import functools
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import gen_golden  # noqa: E402
+from golden_inputs import make_w, make_x  # noqa: E402
+
+# tag: (K_in, K_pad, N, M, seed, had, split, bias, w_sym, act)  act: "static" | "dyn_sym" | "dyn_asym" | "pt_asym"
+CASES = {
+    "wasym_split_had_5120": (5120, 5120, 32, 12, 2100, True, True, True, False, "static"),
+    "wasym_split_3584": (3584, 3584, 40, 16, 2110, False, True, False, False, "dyn_sym"),
+    "wasym_aasym_3584": (3584, 3584, 48, 16, 2120, False, False, True, False, "dyn_asym"),
+    "wasym_aasym_down_19968": (18944, 19968, 24, 6, 2130, True, False, False, False, "dyn_asym"),
+    "wasym_ptasym_1280": (1280, 1280, 40, 24, 2140, False, False, True, False, "pt_asym"),
+    "aasym_split_had_5120": (5120, 5120, 32, 12, 2150, True, True, True, True, "dyn_asym"),
+    "ptasym_split_2048": (2048, 2048, 32, 10, 2160, False, True, False, True, "pt_asym"),
+}
+
+
+class Args:
+    skip_names = []
+
+
+def main():
+    gen_golden._install_shims()
+    torch.set_grad_enabled(False)
+    from fake_quant import hadamard_utils as hu
+    from fake_quant import quant_utils as qu
+    from fake_quant import utils as ru
+    assert qu.__file__.startswith(gen_golden.REF)
+    for tag, (K_in, K_pad, N, M, seed, had, split, bias, w_sym, act) in CASES.items():
+        lin = torch.nn.Linear(K_pad, N, bias=bias)
+        lin.weight.data = torch.from_numpy(make_w(seed, (N, K_pad)))
+        if bias:
+            lin.bias.data = torch.from_numpy(make_w(seed + 1, (N,), std=0.1))
+        wrap = qu.ActQuantWrapper(lin)
+        if had:
+            hadK, Kh = hu.get_hadK(K_pad)
+            wrap.online_full_had, wrap.had_K, wrap.K = True, hadK, Kh
+        if split:
+            wrap.split = True
+            wrap.split_weights()
+        if K_pad != K_in:
+            wrap.register_forward_pre_hook(functools.partial(ru.revise_down_input, new_size=K_pad))
+        s_w = z_w = None
+        for name, sub in qu.find_qlayers(wrap, layers=[torch.nn.Linear]).items():
+            if "L1" in name:
+                continue
+            wq = qu.WeightQuantizer()
+            wq.configure(4, perchannel=True, sym=w_sym, mse=False)
+            wq.find_params(sub.weight.data)
+            sub.weight.data = wq.quantize(sub.weight.data)
+            if name in ("module", "L2"):
+                s_w = wq.scale.float().numpy().reshape(-1)
+                z_w = wq.zero.float().numpy().reshape(-1) if not w_sym else np.zeros_like(s_w)
+        out = dict(s_w=s_w, z_w=z_w)
+        a_sym = act in ("static", "dyn_sym")
+        per_tensor = act == "pt_asym"
+        if act == "static":
+            wrap.quantizer.configure(bits=8, sym=True, static=True, observer_type="minmax")
+            args = Args()
+            qu.model_open_calibrate(wrap, args)
+            calib = [make_x(seed + 10 + i, (M, K_in)) for i in range(3)]
+            for i, c in enumerate(calib):
+                if i == len(calib) - 1:
+                    qu.model_open_last_calibrate(wrap, args)
+                wrap(torch.from_numpy(c.copy()))
+            qu.model_close_calibrate(wrap, args)
+            qu.model_quant(wrap, args)
+            out["s_x"] = np.asarray(wrap.quantizer.quantizer.scale.numpy(), dtype=np.float32)
+        else:
+            wrap.quantizer.configure(bits=8, sym=a_sym, clip_ratio=1.0, act_per_tensor=per_tensor)
+        x = make_x(seed + 20, (M, K_in))
+        out["y"] = wrap(torch.from_numpy(x.copy())).numpy()
+        # integer restatement from the reference's own quantizers
+        xt = torch.from_numpy(x.copy())
+        if K_pad != K_in:
+            xt = torch.nn.functional.pad(xt, (0, K_pad - K_in))
+        if had:
+            xt = hu.matmul_hadU_cuda(xt, wrap.had_K, wrap.K)
+        xq_in = xt[..., 1:] if split else xt
+        zero = None
+        if act == "static":
+            qx = wrap.quantizer.quantizer.quant(xq_in.float()).to(torch.int64)
+        else:
+            aq = qu.ActQuantizer()
+            aq.configure(bits=8, sym=a_sym, clip_ratio=1.0, act_per_tensor=per_tensor)
+            aq.find_params(xq_in)
+            if a_sym:
+                qx, s_rows = aq.quantize(xq_in)
+            else:
+                qx, s_rows, zero = aq.quantize(xq_in)
+                qx = qx - 128.0                     # the int8 GEMM stores the levels minus 2^(bits-1)
+            if per_tensor:
+                s_rows = torch.as_tensor(s_rows, dtype=torch.float32).reshape(1, 1).expand(xq_in.shape[0], 1)
+                if zero is not None:
+                    zero = torch.as_tensor(zero, dtype=torch.float32).reshape(1, 1).expand(xq_in.shape[0], 1)
+            out["s_rows"] = s_rows[:, 0].numpy().astype(np.float32)
+            if zero is not None:
+                out["zero"] = zero[:, 0].numpy().astype(np.float32)
+            qx = qx.to(torch.int64)
+        Wq = (wrap.L2.weight.data if split else wrap.module.weight.data).float()
+        q_w = torch.round(Wq / torch.from_numpy(s_w).reshape(-1, 1)) + torch.from_numpy(z_w).reshape(-1, 1)
+        stored = (q_w - (0 if w_sym else 8)).to(torch.int64)       # asymmetric weights: levels 0..15 stored minus 8
+        assert stored.min() >= -8 and stored.max() <= 7
+        out["acc"] = (qx @ stored.T).numpy().astype(np.int32)
+        out["qx_sum"] = qx.sum(dim=1).numpy()
+        out["qw_sum"] = stored.sum(dim=1).numpy()
+        out["qx_head"] = qx[:, :64].numpy().astype(np.int8)
+        if split:
+            out["x0"] = xt[..., 0].numpy()
+            out["w0"] = wrap.L1.weight.data.float().numpy().reshape(-1)
+        out["meta"] = np.array([K_in, K_pad, N, M, seed, int(had), int(split), int(bias), int(w_sym),
+                                {"static": 0, "dyn_sym": 1, "dyn_asym": 2, "pt_asym": 3}[act]], np.int64)
+        gen_golden.save(f"wrapper_rank2_{tag}", **out)
+
+
+if __name__ == "__main__":
+    main()
