@@ -434,13 +434,13 @@ class ActQuantWrapper(torch.nn.Module):
             return False
         g = getattr(qz, "groupsize", -1)
         if g > 0 and not getattr(qz, "act_per_tensor", False):
-            # group-wise scales: symmetric levels, a group = 64 or a multiple of 128 consecutive channels (the k-steps of
+            # group-wise scales: symmetric or asymmetric levels, a group = 64 or a multiple of 128 consecutive channels (the k-steps of
             # the GEMM), whole groups in the (padded) input width, no split column (the reference's reshape of the
             # K - 1 quantized columns fails there too) and symmetric weights (no rank-1 epilogue term in this kernel)
             name, wmod = self._weight_module()
             wq = self.weight_quantizers.get(name)
             width = wmod.weight.shape[1] if wmod.weight.dim() == 2 else 0
-            return (bool(getattr(qz, "sym", False)) and not self.split and (g == 64 or g % 128 == 0) and g <= 1024
+            return (not self.split and (g == 64 or g % 128 == 0) and g <= 1024
                     and (g & (g - 1)) == 0 and width > 0 and width % g == 0 and wq is not None and bool(getattr(wq, "sym", False)))
         # (per-tensor ranges on half / bf16 activations: the reference keeps range, scale, zero point, x / scale and the
         #  level sum in x's dtype -- quant_utils.py:214-231, ``torch.tensor(0).to(x)``, the int64 maxq does not promote -- and

@@ -432,6 +432,15 @@ int mq_gemm_w4a8_i32_ws(const int8_t *a, long lda, const void *w, int w_bits,
 int mq_quantize_act_group_i8(const void *x, int x_dtype, long M, long K, long ldx, int groupsize, int bits,
                              float clip_ratio, float *scales_out, int8_t *out, long K_pad, long ldo, void *stream);
 
+/* The same with ASYMMETRIC levels (--a_groupsize g + --a_asym; the sym = False branch of quant_utils.py:181-203 + asym_quant
+ * :27-31): per row and group  range = [amin, amax] * clip (0 need not be inside; (-1, +1) for an all-zero group),
+ * scale = (xmax - xmin) / (2^bits - 1), zero = round(-xmin / scale), q = clamp(round(x / scale) + zero, 0, 2^bits - 1), every
+ * intermediate rounded to x_dtype like the reference's tensors.  out holds q - 2^(bits-1); shift_out[m][g] = scale (2^(bits-1) -
+ * zero) in fp32: x_hat = scale * out + shift.  zero_out may be NULL.  Pair with mq_gemm_w4a8_groupscale_asym. */
+int mq_quantize_act_group_asym_i8(const void *x, int x_dtype, long M, long K, long ldx, int groupsize, int bits,
+                                  float clip_ratio, float *scales_out, float *zero_out, float *shift_out, int8_t *out,
+                                  long K_pad, long ldo, void *stream);
+
 /* The GEMM for group-wise activation scales: y[m][n] = (sum_g (float(acc_g[m][n]) * s_x_groups[m][g])) * s_w[n] + bias[n],
  * acc_g = the exact int32 sum over the group's k, groups added in ascending order in fp32 (one rounding per group).
  * Replaces F.linear on the group-wise fake-quantized activations (quant_utils.py:384 after :181-203; the reference
@@ -440,6 +449,14 @@ int mq_quantize_act_group_i8(const void *x, int x_dtype, long M, long K, long ld
 int mq_gemm_w4a8_groupscale(const int8_t *a, long lda, const void *w, int w_bits, long M, long N, long K_pad,
                             const float *s_x_groups, long n_groups, int group_k, const float *s_w,
                             const float *bias, void *out, int out_dtype, long ldo, void *stream);
+
+/* ... for asymmetric groups: y[m][n] = (sum_g (float(acc_g) * s_x_groups[m][g] + shift_groups[m][g] * wsum_groups[g][n])) * s_w[n] + bias[n],
+ * wsum_groups[g * N + n] = sum_{k in group g} q_w[n][k] as fp32 (the constant part s (2^(b-1) - z) of a group's dequantised levels
+ * meets the group's weight sum); the two products of a group are added to the fp32 accumulator in that order. */
+int mq_gemm_w4a8_groupscale_asym(const int8_t *a, long lda, const void *w, int w_bits, long M, long N, long K_pad,
+                                 const float *s_x_groups, const float *shift_groups, const float *wsum_groups,
+                                 long n_groups, int group_k, const float *s_w, const float *bias, void *out,
+                                 int out_dtype, long ldo, void *stream);
 
 /* Scaled row sums of the int8 activation levels, for ASYMMETRIC weights (--w_asym; WeightQuantizer with
  * sym = False, quant_utils.py:446-509).  With the weight levels stored as q - 2^(b-1) the fake-quantized

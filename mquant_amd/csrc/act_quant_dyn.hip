@@ -274,14 +274,16 @@ struct GqArgs {
     long M, K, ldx;
     int lanes_per_group;           // g / 16: 1 .. 64, a power of two
     float clip, maxq;
+    float half = 0.0f;             // asymmetric levels: 2^(bits-1), maxq = 2^bits - 1
     float *scale_out;
+    float *zero_out = nullptr, *shift_out = nullptr;
     long n_groups;
     int8_t *out;
     long K_pad, ldo;
     int vec_ok;
 };
 
-template <int DT>
+template <int DT, bool ASYM = false>
 __global__ __launch_bounds__(256) void act_quant_group_kernel(GqArgs p)
 {
     typedef typename Elem<DT>::T T;
@@ -320,17 +322,36 @@ __global__ __launch_bounds__(256) void act_quant_group_kernel(GqArgs p)
             mn = fminf(mn, __shfl_xor(mn, st, 64));
             mx = fmaxf(mx, __shfl_xor(mx, st, 64));
         }
-        const float xmin = Elem<DT>::rnd(mn * p.clip), xmax0 = Elem<DT>::rnd(mx * p.clip);
-        const float xmax = fmaxf(fabsf(xmin), xmax0);
-        const float s = (xmax == 0.0f) ? 1.0f : Elem<DT>::rnd(xmax / p.maxq);
+        float xmin = Elem<DT>::rnd(mn * p.clip), xmax0 = Elem<DT>::rnd(mx * p.clip);
+        float s, z = 0.0f;
+        if (ASYM) {      // quant_utils.py:181-203, sym = False: the range is [amin, amax] * clip (0 need not be inside), (-1, +1) when both are 0
+            if (xmin == 0.0f && xmax0 == 0.0f) { xmin = -1.0f; xmax0 = 1.0f; }
+            s = Elem<DT>::rnd(Elem<DT>::rnd(xmax0 - xmin) / p.maxq);
+            z = rintf(Elem<DT>::rnd(-xmin / s));
+        } else {
+            const float xmax = fmaxf(fabsf(xmin), xmax0);
+            s = (xmax == 0.0f) ? 1.0f : Elem<DT>::rnd(xmax / p.maxq);
+        }
         if (!live) continue;
         const long chunk = cc - row * cpr;
-        if ((chunk % p.lanes_per_group) == 0 && col < p.K) p.scale_out[row * p.n_groups + chunk / p.lanes_per_group] = s;
+        if ((chunk % p.lanes_per_group) == 0 && col < p.K) {
+            const long gi = row * p.n_groups + chunk / p.lanes_per_group;
+            p.scale_out[gi] = s;
+            if (ASYM) {
+                if (p.zero_out) p.zero_out[gi] = z;
+                p.shift_out[gi] = s * (p.half - z);
+            }
+        }
         int q[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             float t = rintf(Elem<DT>::rnd(v[i] / s));
-            t = fminf(fmaxf(t, -(p.maxq + 1.0f)), p.maxq);
+            if (ASYM) {
+                t = Elem<DT>::rnd(t + z);
+                t = fminf(fmaxf(t, 0.0f), p.maxq) - p.half;        // stored for the int8 GEMM: q - 2^(bits-1)
+            } else {
+                t = fminf(fmaxf(t, -(p.maxq + 1.0f)), p.maxq);
+            }
             q[i] = (col + i < p.K) ? (int)t : 0;
         }
         v4i pk;
@@ -343,12 +364,13 @@ __global__ __launch_bounds__(256) void act_quant_group_kernel(GqArgs p)
 
 }  // namespace mq
 
-extern "C" int mq_quantize_act_group_i8(const void *x, int x_dtype, long M, long K, long ldx, int groupsize, int bits,
-                                        float clip_ratio, float *scale_out, int8_t *out, long K_pad, long ldo, void *stream)
+static int quantize_act_group(const void *x, int x_dtype, long M, long K, long ldx, int groupsize, int bits, float clip_ratio,
+                              bool asym, float *scale_out, float *zero_out, float *shift_out, int8_t *out, long K_pad, long ldo,
+                              void *stream)
 {
     using namespace mq;
     if (M == 0) return MQ_OK;
-    MQ_REQUIRE(x && out && scale_out && M >= 0 && K > 0 && ldx >= K, "mq_quantize_act_group_i8: bad shape");
+    MQ_REQUIRE(x && out && scale_out && (!asym || shift_out) && M >= 0 && K > 0 && ldx >= K, "mq_quantize_act_group_i8: bad shape");
     MQ_REQUIRE(bits >= 2 && bits <= 8, "mq_quantize_act_group_i8: bits must be 2..8");
     MQ_REQUIRE(groupsize >= 16 && groupsize <= 1024 && (groupsize & (groupsize - 1)) == 0 && K % groupsize == 0,
                "mq_quantize_act_group_i8: groupsize=%d must be a power of two in 16..1024 that divides K=%ld", groupsize, K);
@@ -357,18 +379,39 @@ extern "C" int mq_quantize_act_group_i8(const void *x, int x_dtype, long M, long
                "mq_quantize_act_group_i8: bad K_pad / ldo / alignment (K_pad must hold whole groups)");
     GqArgs p;
     p.x = x; p.M = M; p.K = K; p.ldx = ldx; p.lanes_per_group = groupsize / 16; p.clip = clip_ratio;
-    p.maxq = (float)((1 << (bits - 1)) - 1);
+    p.maxq = asym ? (float)((1 << bits) - 1) : (float)((1 << (bits - 1)) - 1);
+    p.half = (float)(1 << (bits - 1));
+    p.zero_out = zero_out; p.shift_out = shift_out;
     p.scale_out = scale_out; p.n_groups = K / groupsize; p.out = out; p.K_pad = K_pad; p.ldo = ldo;
     const size_t esz = (x_dtype == MQ_F32) ? 4 : 2;
     p.vec_ok = (((uintptr_t)x) % 16 == 0) && ((ldx * esz) % 16 == 0);
     long blocks = ceil_div(M * (K_pad / 16), 256);
     if (blocks > 256L * 16) blocks = 256L * 16;
     hipStream_t st = (hipStream_t)stream;
+#define MQ_GQ_LAUNCH(DTC) \
+    do { \
+        if (asym) hipLaunchKernelGGL((act_quant_group_kernel<DTC, true>), dim3((unsigned)blocks), dim3(256), 0, st, p); \
+        else hipLaunchKernelGGL((act_quant_group_kernel<DTC, false>), dim3((unsigned)blocks), dim3(256), 0, st, p); \
+    } while (0)
     switch (x_dtype) {
-    case MQ_F16: hipLaunchKernelGGL(act_quant_group_kernel<MQ_F16>, dim3((unsigned)blocks), dim3(256), 0, st, p); break;
-    case MQ_BF16: hipLaunchKernelGGL(act_quant_group_kernel<MQ_BF16>, dim3((unsigned)blocks), dim3(256), 0, st, p); break;
-    case MQ_F32: hipLaunchKernelGGL(act_quant_group_kernel<MQ_F32>, dim3((unsigned)blocks), dim3(256), 0, st, p); break;
+    case MQ_F16: MQ_GQ_LAUNCH(MQ_F16); break;
+    case MQ_BF16: MQ_GQ_LAUNCH(MQ_BF16); break;
+    case MQ_F32: MQ_GQ_LAUNCH(MQ_F32); break;
     default: return fail(MQ_EINVAL, "mq_quantize_act_group_i8: unknown dtype %d", x_dtype);
     }
+#undef MQ_GQ_LAUNCH
     return check_launch("quantize_act_group_i8");
+}
+
+extern "C" int mq_quantize_act_group_i8(const void *x, int x_dtype, long M, long K, long ldx, int groupsize, int bits,
+                                        float clip_ratio, float *scale_out, int8_t *out, long K_pad, long ldo, void *stream)
+{
+    return quantize_act_group(x, x_dtype, M, K, ldx, groupsize, bits, clip_ratio, false, scale_out, nullptr, nullptr, out, K_pad, ldo, stream);
+}
+
+extern "C" int mq_quantize_act_group_asym_i8(const void *x, int x_dtype, long M, long K, long ldx, int groupsize, int bits,
+                                             float clip_ratio, float *scale_out, float *zero_out, float *shift_out, int8_t *out,
+                                             long K_pad, long ldo, void *stream)
+{
+    return quantize_act_group(x, x_dtype, M, K, ldx, groupsize, bits, clip_ratio, true, scale_out, zero_out, shift_out, out, K_pad, ldo, stream);
 }

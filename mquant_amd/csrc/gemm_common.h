@@ -39,6 +39,9 @@ struct GemmArgs {
     // group_k consecutive k (64 or a multiple of 128).  The grouped kernel folds them into fp32 accumulators group by
     // group; the epilogue then receives FLOAT bits in the accumulator registers (acc_float) and skips the row scale.
     const float *sx_groups = nullptr;
+    // asymmetric groups: x~ = s_g a + shift_g with shift_groups[m * n_groups + g] = s_g (2^(b-1) - z_g); the constant part meets
+    // the group's weight sum wsum_groups[g * N + n] = sum_{k in g} q_w[n][k] (as fp32): facc += shift_g * wsum_g
+    const float *shift_groups = nullptr, *wsum_groups = nullptr;
     long n_groups = 0;
     int group_k = 0;
     int acc_float = 0;

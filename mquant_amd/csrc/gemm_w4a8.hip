@@ -135,12 +135,21 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
             if (row >= p.M) row = p.M - 1;
             float sg = p.sx_groups[row * p.n_groups + gi];
             if (W_BITS == 4) sg = sg * 0.0625f;                // the int4 levels sit in the high nibble: exact rescale
+            const float sh = p.shift_groups ? p.shift_groups[row * p.n_groups + gi] : 0.0f;
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
+                // D layout: register r of the tile = channel 16 (nt0 + wn TN + i) + 4 (lane >> 4) + r
+                const long nb = (nt0 + wn * TN + i) * 16 + (lane >> 4) * 4;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float t = (float)acc[i][j][r] * sg;
-                    facc[GROUPED ? i : 0][GROUPED ? j : 0][r] = facc[GROUPED ? i : 0][GROUPED ? j : 0][r] + t;
+                    float f = facc[GROUPED ? i : 0][GROUPED ? j : 0][r] + t;
+                    if (p.shift_groups) {                      // asymmetric groups: the constant part of the group's levels
+                        const long nn = nb + r < p.N ? nb + r : p.N - 1;
+                        const float u = sh * p.wsum_groups[gi * p.N + nn];
+                        f = f + u;
+                    }
+                    facc[GROUPED ? i : 0][GROUPED ? j : 0][r] = f;
                 }
                 acc[i][j] = v4i{0, 0, 0, 0};
             }
@@ -600,7 +609,8 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
                        void *out, int epi, long ldo, void *workspace, size_t workspace_bytes,
                        void *stream, const float *sx_vec = nullptr, const void *residual = nullptr,
                        long ldr = 0, const float *sx_groups = nullptr, long n_groups = 0, int group_k = 0,
-                       const float *x1 = nullptr, const float *w1 = nullptr)
+                       const float *x1 = nullptr, const float *w1 = nullptr, const float *shift_groups = nullptr,
+                       const float *wsum_groups = nullptr)
 {
     MQ_REQUIRE(M >= 0 && N >= 0 && K_pad >= 0, "mq_gemm_w4a8: negative shape");
     if (M == 0 || N == 0) return MQ_OK;
@@ -633,7 +643,9 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
         // group-wise activation scales: the symmetric 128 x 128 kernel, no split-K, floating-point outputs only
         MQ_REQUIRE(epi != EPI_I32 && group_k > 0 && (group_k == 64 || group_k % 128 == 0) && K_pad % 64 == 0 && !sx_vec && !x1,
                    "mq_gemm_w4a8_groupscale: group size %d (64 or a multiple of 128)", group_k);
+        MQ_REQUIRE((shift_groups == nullptr) == (wsum_groups == nullptr), "mq_gemm_w4a8_groupscale: shift_groups and wsum_groups go together");
         p.sx_groups = sx_groups; p.n_groups = n_groups; p.group_k = group_k; p.acc_float = 1;
+        p.shift_groups = shift_groups; p.wsum_groups = wsum_groups;
         p.splits = 1; p.partial = nullptr;
         p.vec_ok = (N % 8 == 0) && (ldo % 8 == 0) && (((uintptr_t)out) % 16 == 0);
         auto al = [](const void *q) { return q == nullptr || ((uintptr_t)q) % 16 == 0; };
@@ -771,6 +783,23 @@ extern "C" int mq_gemm_w4a8_groupscale(const int8_t *a, long lda, const void *w,
         return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_groupscale: %ld groups of %d do not cover K_pad=%ld", n_groups, group_k, K_pad);
     return mq::gemm_common(a, lda, w, w_bits, M, N, K_pad, 1.0f, 1.0f, nullptr, s_w, bias, nullptr, nullptr,
                            out, out_dtype, ldo, nullptr, 0, stream, nullptr, nullptr, 0, s_x_groups, n_groups, group_k);
+}
+
+extern "C" int mq_gemm_w4a8_groupscale_asym(const int8_t *a, long lda, const void *w, int w_bits, long M, long N, long K_pad,
+                                            const float *s_x_groups, const float *shift_groups, const float *wsum_groups,
+                                            long n_groups, int group_k, const float *s_w, const float *bias, void *out,
+                                            int out_dtype, long ldo, void *stream)
+{
+    if (out_dtype != MQ_F16 && out_dtype != MQ_BF16 && out_dtype != MQ_F32)
+        return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_groupscale_asym: unknown output dtype %d", out_dtype);
+    if (M == 0 || N == 0) return MQ_OK;
+    if (!s_x_groups || !shift_groups || !wsum_groups || n_groups <= 0)
+        return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_groupscale_asym: s_x_groups, shift_groups and wsum_groups are required");
+    if ((long)group_k * n_groups > K_pad || (long)group_k * n_groups + 127 < K_pad)
+        return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_groupscale_asym: %ld groups of %d do not cover K_pad=%ld", n_groups, group_k, K_pad);
+    return mq::gemm_common(a, lda, w, w_bits, M, N, K_pad, 1.0f, 1.0f, nullptr, s_w, bias, nullptr, nullptr,
+                           out, out_dtype, ldo, nullptr, 0, stream, nullptr, nullptr, 0, s_x_groups, n_groups, group_k,
+                           nullptr, nullptr, shift_groups, wsum_groups);
 }
 
 extern "C" int mq_gemm_w4a8_i32(const int8_t *a, long lda, const void *w, int w_bits, long M,

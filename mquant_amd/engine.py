@@ -100,7 +100,13 @@ class W4A8Linear:
         #: shift[m] * (s_w[n] * sum_k q_w[n][k]), which is the slot the split column uses -- not both)
         self.dynamic = dynamic
         self.w_colsum = None
-        if dynamic is not None and not dynamic.get("sym", True):
+        self.wsum_groups = None
+        gsz = int(dynamic.get("groupsize", -1) or -1) if dynamic is not None else -1
+        if gsz > 0 and not dynamic.get("sym", True):
+            # asymmetric group-wise activations: fp32 [K / g, N] sums of the weight levels per group
+            assert not self.split and self.w_shift is None and self.K % gsz == 0
+            self.wsum_groups = levels.to(torch.int32).reshape(self.N, self.K // gsz, gsz).sum(dim=2).t().to(torch.float32).contiguous()
+        elif dynamic is not None and not dynamic.get("sym", True):
             # s_x (2^(b-1) - z_x)[m] multiplies s_w sum_k W~-levels[n][k]; with asymmetric weights the level of column k is
             # p + (2^(bw-1) - z_w): the constant part adds Kq * w_shift[n] (Kq = quantized columns)
             self.w_colsum = (levels.to(torch.int32).sum(dim=1).to(torch.float32) * self.s_w).contiguous()
@@ -197,6 +203,12 @@ class W4A8Linear:
             x2 = ops.hadamard(x2, self.had.n, self.had.K, self.had.bits, self.had.fp32_had, fast=self.had.fast)
         a = WORKSPACE.act(x2.device, x2.shape[0], self.K_pad)
         g = int(self.dynamic.get("groupsize", -1) or -1)
+        if g > 0 and not self.dynamic.get("sym", True):
+            # asymmetric group-wise scales (--a_groupsize + --a_asym): the constant part of a group's levels meets the group's
+            # weight sum (wsum_groups, built once)
+            a, s_groups, _, sh_groups = ops.quantize_act_group_asym_i8(x2, g, self.dynamic["bits"], self.dynamic["clip_ratio"], out=a)
+            return ops.gemm_w4a8_groupscale_asym(a, self.w_img, self.w_bits, self.N, s_groups, sh_groups, self.wsum_groups, g,
+                                                 self.s_w, bias=self.bias, out_dtype=x2.dtype, out=out)
         if g > 0:
             # group-wise scales (--a_groupsize): exact int32 sums inside a group, fp32 across groups
             a, s_groups = ops.quantize_act_group_i8(x2, g, self.dynamic["bits"], self.dynamic["clip_ratio"], out=a)

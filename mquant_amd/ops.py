@@ -628,6 +628,42 @@ def gemm_w4a8_groupscale(a, w_img: torch.Tensor, w_bits: int, N: int, s_groups: 
 
 
 @_on_device
+def quantize_act_group_asym_i8(x: torch.Tensor, groupsize: int, bits: int = 8, clip_ratio: float = 1.0, *, out=None,
+                               tiled: bool = False):
+    """Dynamic ASYMMETRIC group-wise quantizer (``--a_groupsize`` + ``--a_asym``; reference quant_utils.py:181-203, sym = False),
+    every intermediate in x's dtype like the reference.  Returns (stored int8 levels q - 2^(bits-1) [M, ceil128(K)], scales,
+    zero points, shift = scale * (2^(bits-1) - zero): fp32 [M, K / groupsize] each)."""
+    x2 = _rows(x)
+    _need_cuda(x2, out)
+    M, K = x2.shape
+    out, optr, K_pad, ldo = _out_act(out, tiled, M, ceil_to(K, 128), x.device)
+    scales, zero, shift = (torch.empty((M, K // groupsize), dtype=torch.float32, device=x.device) for _ in range(3))
+    call("mq_quantize_act_group_asym_i8", x2.data_ptr(), dtype_code(x2.dtype), M, K, x2.stride(0), int(groupsize), int(bits),
+         float(clip_ratio), scales.data_ptr(), zero.data_ptr(), shift.data_ptr(), optr, K_pad, ldo, _stream())
+    return out, scales, zero, shift
+
+
+@_on_device
+def gemm_w4a8_groupscale_asym(a, w_img: torch.Tensor, w_bits: int, N: int, s_groups: torch.Tensor, shift_groups: torch.Tensor,
+                              wsum_groups: torch.Tensor, group_k: int, s_w: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
+                              out_dtype: torch.dtype = torch.float16, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = (sum_g (float(acc_g) * s_groups[m][g] + shift_groups[m][g] * wsum_groups[g][n])) * s_w[n] + bias[n]
+    (``mq_gemm_w4a8_groupscale_asym``); wsum_groups: fp32 [K / group_k, N], the per-group sums of the weight levels."""
+    _need_cuda(a, w_img, s_groups, shift_groups, wsum_groups, s_w, bias, out)
+    aptr, lda, M, K_pad = _a_args(a)
+    G = s_groups.shape[1]
+    for t in (s_groups, shift_groups):
+        assert t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (M, G)
+    assert wsum_groups.dtype == torch.float32 and wsum_groups.is_contiguous() and tuple(wsum_groups.shape) == (G, N)
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=w_img.device)
+    call("mq_gemm_w4a8_groupscale_asym", aptr, lda, w_img.data_ptr(), w_bits, M, N, K_pad, s_groups.data_ptr(),
+         shift_groups.data_ptr(), wsum_groups.data_ptr(), G, int(group_k), s_w.data_ptr(), _ptr(bias), out.data_ptr(),
+         dtype_code(out.dtype), out.stride(0), _stream())
+    return out
+
+
+@_on_device
 def quantize_act_dyn_asym_i8(x: torch.Tensor, bits: int = 8, clip_ratio: float = 1.0, *, out=None, tiled: bool = False):
     """Dynamic ASYMMETRIC per-token quantizer (``--a_asym``).  Returns (stored int8 levels q - 2^(bits-1)
     [M, ceil128(K)], scale [M], zero [M], shift [M] = scale * (2^(bits-1) - zero)); dequantised value =

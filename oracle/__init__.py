@@ -239,6 +239,18 @@ def quant_group(x, groupsize, bits=8, clip=1.0, mode=0):
     return q, scale
 
 
+def quant_group_asym(x, g, bits=8, clip=1.0, mode=0):
+    """quant_utils.py:181-203, sym = False: (stored int8 levels q - 2^(bits-1), scale [rows, cols/g], zero, shift)."""
+    x = _f32(x)
+    rows, cols = x.shape
+    G = cols // g
+    scale, zero, shift = (np.empty((rows, G), dtype=np.float32) for _ in range(3))
+    q = np.empty((rows, cols), dtype=np.int8)
+    lib().orc_quant_group_asym(_p(x, C.c_float), C.c_long(rows), C.c_long(cols), C.c_long(g), C.c_int(bits), C.c_float(clip),
+                               C.c_int(mode), _p(scale, C.c_float), _p(zero, C.c_float), _p(shift, C.c_float), _p(q, C.c_int8))
+    return q, scale, zero, shift
+
+
 def quant_dyn_asym(x, bits=8, clip=1.0):
     """quant_utils.py:239-268 (asymmetric branch): dynamic per-token -> (stored int8 levels q - 2^(bits-1),
     scale, zero, shift = scale * (2^(bits-1) - zero)) per row."""

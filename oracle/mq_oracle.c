@@ -204,6 +204,36 @@ void orc_quant_group(const float *x, long rows, long cols, long g, int bits, flo
         }
 }
 
+/* The same with ASYMMETRIC levels (sym = False branch of quant_utils.py:181-203 + asym_quant :27-31, maxq = 2^bits - 1): per
+ * (row, group)  xmax = amax * clip, xmin = amin * clip (the range need not include 0); both 0 -> (-1, +1);
+ * scale = (xmax - xmin) / maxq; zero = round(-xmin / scale); q = clamp(round(x / scale) + zero, 0, maxq) -- every operation
+ * rounded to x's dtype (mode).  Stored for the int8 GEMM as q - 2^(bits-1); shift = scale * (2^(bits-1) - zero) in fp32. */
+void orc_quant_group_asym(const float *x, long rows, long cols, long g, int bits, float clip, int mode,
+                          float *scale, float *zero, float *shift, int8_t *q)
+{
+    const float maxq = (float)((1 << bits) - 1), half = (float)(1 << (bits - 1));
+    const long G = cols / g;
+    for (long r = 0; r < rows; ++r)
+        for (long gi = 0; gi < G; ++gi) {
+            const float *h = x + r * cols + gi * g;
+            float mn = h[0], mx = h[0];
+            for (long k = 1; k < g; ++k) { if (h[k] < mn) mn = h[k]; if (h[k] > mx) mx = h[k]; }
+            float xmin = round_mid(mn * clip, mode), xmax = round_mid(mx * clip, mode);
+            if (xmin == 0.0f && xmax == 0.0f) { xmin = -1.0f; xmax = 1.0f; }
+            const float s = round_mid(round_mid(xmax - xmin, mode) / maxq, mode);
+            const float z = rintf(round_mid(-xmin / s, mode));
+            scale[r * G + gi] = s;
+            zero[r * G + gi] = z;
+            shift[r * G + gi] = s * (half - z);
+            for (long k = 0; k < g; ++k) {
+                float v = round_mid(rintf(round_mid(h[k] / s, mode)) + z, mode);
+                if (v < 0.0f) v = 0.0f;
+                if (v > maxq) v = maxq;
+                q[r * cols + gi * g + k] = (int8_t)(v - half);
+            }
+        }
+}
+
 /* Dynamic ASYMMETRIC per-token quantizer (--a_asym), quant_utils.py:239-268 (else-branch) +
  * asym_quant :27-31, maxq = 2^bits - 1:
  *   xmin = min(min_k x, 0)*clip; xmax = max(max_k x, 0)*clip; both 0 -> (-1, +1)

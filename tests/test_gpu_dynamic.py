@@ -219,9 +219,9 @@ def test_modes_the_kernels_do_not_cover_stay_on_the_simulated_path():
     from fake_quant.gptq.rtn import rtn_module
     lin = torch.nn.Linear(256, 32).to(DEV).half()
     x = torch.from_numpy(make_x(1, (8, 256))).to(DEV).half()
-    # (symmetric group-wise scales with groups of 64 / 128 / 256 ... run the integer kernels: tests/test_gpu_groupwise.py;
+    # (symmetric AND asymmetric group-wise scales with groups of 64 / 128 / 256 ... run the integer kernels: tests/test_gpu_groupwise.py;
     #  per-tensor ranges on half activations do too, in x's dtype like the reference: the test below)
-    for kw in (dict(bits=8, sym=False, groupsize=64), dict(bits=8, sym=True, groupsize=32), dict(bits=16)):
+    for kw in (dict(bits=8, sym=False, groupsize=32), dict(bits=8, sym=True, groupsize=32), dict(bits=16)):
         wrap = qu.ActQuantWrapper(lin)
         rtn_module(wrap, "l", 4, True, False, [], {})
         wrap.quantizer.configure(**kw)
