@@ -257,7 +257,11 @@ def main():
     args = ap.parse_args()
 
     # ---- rank launcher: before torch.cuda / HIP is touched, and never by re-exec ---------------------
-    if "WORLD_SIZE" not in os.environ:
+    # a rank of torch.distributed.run (any world size, 1 included) carries the whole rendezvous environment; a scheduler that only
+    # exports WORLD_SIZE must not push a plain `python bench.py` into init_process_group (it runs as a single process, noted)
+    torchrun_env = all(k in os.environ for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")) or "TORCHELASTIC_RUN_ID" in os.environ
+    stray_world = (not torchrun_env) and "WORLD_SIZE" in os.environ
+    if not torchrun_env:
         if args.gpus > 1:
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))
@@ -272,12 +276,12 @@ def main():
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1")) if torchrun_env else 1
+    rank = int(os.environ.get("RANK", "0")) if torchrun_env else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if torchrun_env else 0
     # under torch.distributed.run the process group exists at EVERY world size, 1 included: the RCCL
     # initialisation and the all_gather then run on a one-GPU box too (tests/test_gpu_multi.py)
-    distributed = "WORLD_SIZE" in os.environ
+    distributed = torchrun_env
     if args.cpu_selftest:
         from mquant_amd import shard
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -411,7 +415,8 @@ def main():
 
     # settle clocks / caches before the contract's W warm-up steps: ~0.3 s of untimed replays of the captured step (the
     # sustained run of profiles/r3_soak.txt is ~0.8 % faster once warm; a fresh box's first process has been seen slower)
-    for _ in range(0 if args.tiny else 30):
+    settle_replays = 0 if args.tiny else 30
+    for _ in range(settle_replays):
         run_step()
     for _ in range(args.warmup):
         step()
@@ -566,11 +571,15 @@ def main():
                        "ttft_hot_path_ms": round(hot_ms, 4),
                        "lm_head_ms": None if lm_ms is None else round(lm_ms, 4),
                        "gemm_TOP_per_step": round(pf.gemm_ops() / 1e12, 3),
-                       "hip_graph": not args.no_graph,
+                       "hip_graph": not args.no_graph, "settle_replays": settle_replays,
+                       "settle_replays_note": "untimed replays of the captured step before the contract's warm-up steps",
                        "weights_GB": round(pf.weight_bytes() / 1e9, 3)},
             "roofline": roofline}
     if headline and not (args.no_full_prefill or args.no_fuse or args.batch != 1):
         line["full_prefill"] = full_prefill_report(pf, dev, args)
+    if stray_world:
+        line["config"]["launcher_note"] = ("WORLD_SIZE was set without RANK / LOCAL_RANK / MASTER_PORT (not a torch.distributed.run "
+                                           "rank): ran as a single process")
     if logits_check is not None:
         line["logits_check"] = logits_check
     if rank == 0 and world == 1 and not args.no_cpu_baseline and headline:

@@ -619,6 +619,32 @@ class _GroupResult:
         self.key, self.rows, self.sel, self.y, self.consumed = key, rows, sel, y, {first}
 
 
+def _no_pass_hook(*_):
+    return None
+
+
+class _GroupPassHook:
+    """Forward-pre-hook on a group's parent module: a new forward pass empties the group's cache.  Holds the group weakly and
+    pickles / deep-copies as a no-op (the copy's wrappers have no group: ``_group`` is dropped like ``_real``)."""
+
+    def __init__(self, group):
+        import weakref
+        self._ref = weakref.ref(group)
+
+    def __call__(self, *_):
+        grp = self._ref()
+        if grp is not None:
+            grp.new_pass()
+        return None
+
+    def __reduce__(self):
+        return (_no_pass_hook_factory, ())
+
+
+def _no_pass_hook_factory():
+    return _no_pass_hook
+
+
 class SiblingGroup:
     """Wrappers under one parent that quantize the same input with the same static scale set run as ONE
     quantize + ONE GEMM over their concatenated output channels; each member's ``forward`` returns its
@@ -643,6 +669,16 @@ class SiblingGroup:
         self._result = None
         self._unused = 0
         self.launches = 0                                  # fused GEMMs issued (tests, bench accounting)
+        #: forward passes of the parent module seen so far (a forward-pre-hook on the parent, ``group_siblings``): a cached
+        #: product never survives into the next pass -- version counters miss writes through ``.data``, through this
+        #: repository's own in-place kernels and into inference tensors, so a partially consumed product could otherwise
+        #: be handed out for a refilled buffer
+        self._epoch = 0
+        self._hook = None
+
+    def new_pass(self, *_):
+        self._epoch += 1
+        self._result = None
 
     def reset(self):
         self.engine, self.offsets, self._result = None, None, None
@@ -653,6 +689,9 @@ class SiblingGroup:
         for _, w in self.members:
             if w.__dict__.get("_group") is self:
                 w._group = None
+        if self._hook is not None:
+            self._hook.remove()
+            self._hook = None
 
     def _build(self, rows) -> bool:
         from mquant_amd.engine import W4A8Linear
@@ -681,7 +720,9 @@ class SiblingGroup:
     def forward(self, wrapper, rows, sel):
         """The column slice of ``wrapper`` in the shared product for ``rows``, or None (caller runs alone)."""
         i = self.index[id(wrapper)]
-        key = (rows.data_ptr(), utils.tensor_version(rows), tuple(rows.shape), rows.stride(), rows.dtype,
+        if self._hook is None and rows.is_inference():
+            return None            # no version counter and no parent pass boundary to tell a refilled buffer by: run alone
+        key = (self._epoch, rows.data_ptr(), utils.tensor_version(rows), tuple(rows.shape), rows.stride(), rows.dtype,
                None if sel is None else (sel.data_ptr(), utils.tensor_version(sel)))
         res = self._result
         if res is not None and res.key == key and i not in res.consumed:
@@ -759,12 +800,16 @@ def group_siblings(model, args=None) -> list:
             continue
         cand.setdefault((parent, fam) + _scale_signature(w), []).append((leaf, w))
     groups = []
+    modules = dict(model.named_modules())
     for key, members in cand.items():
         if len(members) < 2:
             continue
         grp = SiblingGroup(key[0], members)
         for _, w in members:
             w._group = grp
+        parent_mod = modules.get(key[0])
+        if parent_mod is not None:       # every forward pass of the parent starts with an empty cache
+            grp._hook = parent_mod.register_forward_pre_hook(_GroupPassHook(grp))
         groups.append(grp)
     return groups
 

@@ -62,8 +62,10 @@ def revise_down_input(m, i, new_size):
 
 
 def tensor_version(t) -> int:
-    """``t._version`` (the in-place write counter); inference tensors keep none -- they cannot be written in
-    place outside inference mode either -- and count as version 0."""
+    """``t._version`` (the in-place write counter); inference tensors keep none and count as version 0 -- they CAN be
+    rewritten in place inside ``torch.inference_mode()``, and writes through ``.data`` or through this repository's own
+    in-place kernels bump no counter either, so callers must not rely on the counter alone (``SiblingGroup`` also drops its
+    cache at every forward pass of the parent module)."""
     try:
         return t._version
     except RuntimeError:

@@ -440,6 +440,25 @@ def kv_dequant_fp8(q: torch.Tensor, scale: torch.Tensor, dtype: torch.dtype = to
     return out
 
 
+_KV_SCALE_OK = {}
+
+
+def _check_kv_scale(kv_scale: torch.Tensor, kv_heads: int) -> None:
+    """kv_heads K scales then kv_heads V scales, fp32, positive and finite (the attention kernels apply them AFTER the running
+    maximum over raw scores: a zero / negative scale silently gives wrong probabilities).  The value check reads the tensor back
+    once per (storage, version) and never during stream capture."""
+    assert kv_scale.dtype == torch.float32 and kv_scale.is_contiguous() and kv_scale.numel() == 2 * kv_heads, \
+        f"kv_scale must hold 2 * kv_heads = {2 * kv_heads} fp32 values (got {tuple(kv_scale.shape)})"
+    key = (kv_scale.data_ptr(), kv_scale._version if not kv_scale.is_inference() else -1)
+    if _KV_SCALE_OK.get(key) or torch.cuda.is_current_stream_capturing():
+        return
+    ok = bool((torch.isfinite(kv_scale) & (kv_scale > 0)).all().item())
+    assert ok, "kv_scale entries must be positive and finite"
+    if len(_KV_SCALE_OK) > 256:
+        _KV_SCALE_OK.clear()
+    _KV_SCALE_OK[key] = True
+
+
 @_on_device
 def attn_prefill_fp8kv(q: torch.Tensor, kv_cache: torch.Tensor, kv_scale: torch.Tensor, causal: bool = True,
                        softmax_scale: float = None, out: torch.Tensor = None) -> torch.Tensor:
@@ -451,7 +470,7 @@ def attn_prefill_fp8kv(q: torch.Tensor, kv_cache: torch.Tensor, kv_scale: torch.
     T2, H2, D2 = kv_cache.shape
     assert T2 == T and D2 == D and H2 % 2 == 0 and kv_cache.dtype == torch.float8_e4m3fn
     assert q.stride(2) == 1 and q.stride(1) == D and kv_cache.stride(2) == 1 and kv_cache.stride(1) == D
-    assert kv_scale.dtype == torch.float32 and kv_scale.numel() == H2 and kv_scale.is_contiguous()
+    _check_kv_scale(kv_scale, H2 // 2)
     if out is None:
         out = torch.empty((T, H * D), dtype=q.dtype, device=q.device)
     assert out.dtype == q.dtype and out.shape == (T, H * D) and out.stride(1) == 1
@@ -504,7 +523,8 @@ def attn_prefill_quant_i8(q: torch.Tensor, scale0: float, scale1: Optional[float
         softmax_scale = D ** -0.5
     if kv_cache is not None:
         assert kv_cache.dtype == torch.float8_e4m3fn and kv_cache.shape[0] == T and kv_cache.shape[2] == D
-        assert kv_cache.stride(2) == 1 and kv_cache.stride(1) == D and kv_scale.dtype == torch.float32
+        assert kv_cache.stride(2) == 1 and kv_cache.stride(1) == D
+        _check_kv_scale(kv_scale, kv_cache.shape[1] // 2)
         hkv, kp, vp, ldkv = kv_cache.shape[1] // 2, None, None, 0
         cp, ldc, sp = kv_cache.data_ptr(), kv_cache.stride(0) if T > 1 else kv_cache.shape[1] * D, kv_scale.data_ptr()
     else:

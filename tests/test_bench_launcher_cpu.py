@@ -31,8 +31,18 @@ def test_single_rank_needs_no_launcher():
 
 
 def test_mismatch_between_gpus_and_world_size_fails_loudly():
-    r = _run(["--gpus", "2", "--cpu-selftest"], env={"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
+    r = _run(["--gpus", "2", "--cpu-selftest"], env={"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0", "MASTER_PORT": "29999"})
     assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout)
+
+
+def test_a_stray_world_size_without_the_rendezvous_environment_runs_as_a_single_process():
+    """A scheduler that exports WORLD_SIZE (but no RANK / LOCAL_RANK / MASTER_PORT) must not push a plain `python bench.py` into
+    init_process_group(env://): the process is not a torch.distributed.run rank and runs alone."""
+    import json
+    r = _run(["--cpu-selftest"], env={"WORLD_SIZE": "4"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["gathered_ok"] is True
 
 
 def test_launcher_runs_before_any_gpu_import():

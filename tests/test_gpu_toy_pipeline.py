@@ -259,3 +259,47 @@ def test_sibling_group_never_serves_a_stale_or_foreign_product():
             m(torch.randn(7, q.module.in_features, device=DEV))
     assert not grp.enabled and q.__dict__.get("_group") is None
     assert torch.equal(k(x), y_k2)
+
+
+def test_sibling_group_drops_its_cache_at_every_forward_pass_of_the_parent():
+    """A partially consumed product must not survive into the next pass when the same buffer was refilled through a path the
+    version counter does not see (``.data``, this repository's in-place kernels, inference tensors): the parent module's
+    forward-pre-hook empties the cache; the hook pickles and deep-copies as a no-op."""
+    import copy
+    import pickle
+    from fake_quant import quant_utils as qu
+    model, wrappers, pixels, ids, _ = build(96, False, False, 8, False)
+    calibrate(model, pixels, ids, None)
+    attn = model.model.layers[0].self_attn
+    q, k = attn.q_proj, attn.k_proj
+    grp = q.__dict__["_group"]
+    assert grp._hook is not None
+    x = torch.randn(7, q.module.in_features, device=DEV)
+    y_q = q(x).clone()                       # product computed, only q consumed it
+    x.data.copy_(torch.randn_like(x))        # refill through .data: the version counter does not move
+    stale_key_would_match = True             # (same storage, same version: without the pass boundary k would get the old product)
+    for h in attn._forward_pre_hooks.values():
+        h(attn, ())                          # what the parent's next forward pass does first
+    launches = grp.launches
+    y_k = k(x)
+    assert grp.launches == launches + 1 and stale_key_would_match      # recomputed from the refilled buffer
+    qu.model_quant(model, types.SimpleNamespace(skip_names=[], no_sibling_fusion=True))
+    assert torch.equal(k(x), y_k)
+    # inference tensors have no version counter: without a parent hook the group does not share at all
+    qu.model_quant(model, Args())
+    grp = q.__dict__["_group"]
+    grp._hook.remove()
+    grp._hook = None
+    with torch.inference_mode():
+        xi = torch.randn(7, q.module.in_features, device=DEV)
+        q(xi)
+        n = grp.launches
+        k(xi)
+        assert grp.launches == n             # no product was cached or served: both ran alone
+    # the parent pickles / deep-copies with the hook as a no-op
+    qu.model_quant(model, Args())
+    clone = copy.deepcopy(attn)
+    blob = pickle.dumps(attn)
+    for m in (clone, pickle.loads(blob)):
+        for h in m._forward_pre_hooks.values():
+            assert h(m, ()) is None
