@@ -410,7 +410,7 @@ extern "C" int mq_attn_prefill_fp8kv(const void *q, int dtype, long T, int heads
     MQ_REQUIRE(head_dim == D, "mq_attn_prefill_fp8kv: head_dim %d (the e4m3 variant is built for 128)", head_dim);
     // the running maximum is taken over RAW scores and the (positive) scale applied afterwards: a zero / negative / non-finite scale would
     // silently produce wrong probabilities (kv_scale entries must be positive and finite as well: kv_heads K scales, then kv_heads V scales)
-    MQ_REQUIRE(softmax_scale > 0.0f && isfinite(softmax_scale), "mq_attn_prefill_fp8kv: softmax_scale must be positive and finite (got %g)", (double)softmax_scale);
+    MQ_REQUIRE(softmax_scale > 0.0f && softmax_scale < 3.0e38f, "mq_attn_prefill_fp8kv: softmax_scale must be positive and finite (got %g)", (double)softmax_scale);
     if (T == 0) return MQ_OK;
     MQ_REQUIRE(q && kv_cache && kv_scale && out, "mq_attn_prefill_fp8kv: null pointer");
     MQ_REQUIRE(ldq >= (long)heads * D && ldo >= (long)heads * D && ldkv >= 2L * kv_heads * D, "mq_attn_prefill_fp8kv: row strides too short");
@@ -430,7 +430,7 @@ extern "C" int mq_attn_prefill(const void *q, int dtype, long T, int heads, int 
     MQ_REQUIRE(dtype == MQ_F16 || dtype == MQ_BF16, "mq_attn_prefill: dtype must be fp16 or bf16 (got %d)", dtype);
     MQ_REQUIRE(T >= 0 && heads >= 1 && kv_heads >= 1 && heads % kv_heads == 0, "mq_attn_prefill: bad head counts %d / %d", heads, kv_heads);
     MQ_REQUIRE(head_dim == 128 || head_dim == 80, "mq_attn_prefill: head_dim %d (built: 128 and 80)", head_dim);
-    MQ_REQUIRE(softmax_scale > 0.0f && isfinite(softmax_scale), "mq_attn_prefill: softmax_scale must be positive and finite (got %g)", (double)softmax_scale);
+    MQ_REQUIRE(softmax_scale > 0.0f && softmax_scale < 3.0e38f, "mq_attn_prefill: softmax_scale must be positive and finite (got %g)", (double)softmax_scale);
     if (T == 0) return MQ_OK;
     MQ_REQUIRE(q && k && v && out, "mq_attn_prefill: null pointer");
     const long D = head_dim;
@@ -453,7 +453,7 @@ extern "C" int mq_attn_prefill_quant_i8(const void *q, int dtype, long T, int he
     MQ_REQUIRE(T >= 0 && heads >= 1 && kv_heads >= 1 && heads % kv_heads == 0, "mq_attn_prefill_quant_i8: bad head counts %d / %d", heads, kv_heads);
     const bool kv8 = kv_cache != nullptr;
     MQ_REQUIRE(head_dim == 128 || (head_dim == 80 && !kv8), "mq_attn_prefill_quant_i8: head_dim %d (built: 128, and 80 for 16-bit K / V)", head_dim);
-    MQ_REQUIRE(softmax_scale > 0.0f && isfinite(softmax_scale), "mq_attn_prefill_quant_i8: softmax_scale must be positive and finite (got %g)", (double)softmax_scale);
+    MQ_REQUIRE(softmax_scale > 0.0f && softmax_scale < 3.0e38f, "mq_attn_prefill_quant_i8: softmax_scale must be positive and finite (got %g)", (double)softmax_scale);
     if (T == 0) return MQ_OK;
     const long D = head_dim;
     MQ_REQUIRE(q && out && (kv8 ? kv_scale != nullptr : (k && v)), "mq_attn_prefill_quant_i8: null pointer");

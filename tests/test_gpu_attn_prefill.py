@@ -250,3 +250,21 @@ def test_size_independent_properties_at_full_size():
     assert float((c - want).abs().max()) <= float(want.abs().max()) * 3e-3
     e = torch.empty((0, H, D), device=DEV, dtype=torch.float16)
     assert ops.attn_prefill(e, e[:, :HKV], e[:, :HKV]).shape == (0, H * D)
+
+
+def test_scales_that_would_silently_break_the_softmax_are_refused():
+    """The running maximum is taken over raw scores and the scale applied afterwards: zero, negative and non-finite softmax /
+    K-V scales must be errors, not wrong probabilities (advisor finding, round 3)."""
+    from mquant_amd import ops
+    from mquant_amd._lib import MQuantHipError
+    T, H, HKV, D = 33, 4, 2, 128
+    q = torch.randn(T, H, D, device=DEV, dtype=torch.float16)
+    k = torch.randn(T, HKV, D, device=DEV, dtype=torch.float16)
+    v = torch.randn(T, HKV, D, device=DEV, dtype=torch.float16)
+    for bad in (0.0, -0.1, float("nan"), float("inf")):
+        with pytest.raises(MQuantHipError):
+            ops.attn_prefill(q, k, v, softmax_scale=bad)
+    cache = torch.zeros(T, 2 * HKV, D, device=DEV, dtype=torch.float8_e4m3fn)
+    for scales in (torch.tensor([1.0, 1.0, 0.0, 1.0]), torch.tensor([1.0, -1.0, 1.0, 1.0]), torch.tensor([1.0, 1.0, 1.0])):
+        with pytest.raises(AssertionError):
+            ops.attn_prefill_fp8kv(q, cache, scales.to(DEV))
