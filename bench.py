@@ -491,7 +491,7 @@ def main():
     quant_ms = timed(capture(pf.step_quant_only))
     lm_ms = None
     if with_logits:
-        last_row = torch.zeros((1, hidden), dtype=torch.float16, device=dev)
+        last_row = torch.zeros((B_local, hidden), dtype=torch.float16, device=dev)
 
         def lm_only():
             h = torch.nn.functional.rms_norm(last_row, (hidden,), eps=1e-6)

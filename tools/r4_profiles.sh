@@ -10,7 +10,7 @@ timeout 900 python3 bench.py > gpurun_out/r4p/r4_final_bench.json 2> gpurun_out/
 timeout 600 python3 bench.py --had-fast --no-cpu-baseline --no-full-prefill > gpurun_out/r4p/r4_bench_had_fast.json 2>> gpurun_out/r4p/bench.err; echo "fast rc=$?"
 timeout 600 python3 bench.py --no-fuse --no-cpu-baseline --no-full-prefill > gpurun_out/r4p/r4_bench_no_fuse.json 2>> gpurun_out/r4p/bench.err; echo "nofuse rc=$?"
 timeout 600 python3 bench.py --batch 8 --no-cpu-baseline --no-full-prefill > gpurun_out/r4p/r4_bench_batch8.json 2>> gpurun_out/r4p/bench.err; echo "b8 rc=$?"
-timeout 900 tools/bench_prof.sh gpurun_out/r4p/r4_final > gpurun_out/r4p/bench_prof.log 2>&1; echo "prof rc=$?"
+timeout 900 tools/bench_prof.sh gpurun_out/r4p/r4_final_prof > gpurun_out/r4p/bench_prof.log 2>&1; mv gpurun_out/r4p/r4_final_prof_kernel_stats.csv gpurun_out/r4p/r4_final_kernel_stats.csv; mv gpurun_out/r4p/r4_final_prof_bench.json gpurun_out/r4p/r4_final_bench_under_rocprof.json; echo "prof rc=$?"
 rm -rf gpurun_out/sq; mkdir -p gpurun_out/sq
 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d gpurun_out/sq -o s -- python3 bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-full-prefill > gpurun_out/sq/log 2>&1; echo "sq rc=$?"
 python3 tools/pmc_sq_summary.py gpurun_out/sq/s_counter_collection.csv > gpurun_out/r4p/r4_final_sq_counters.csv; rm -rf gpurun_out/sq
@@ -18,6 +18,7 @@ timeout 1200 tools/traffic_prof.sh gpurun_out/r4p/r4_traffic.json "$COMMIT" > gp
 python3 - <<'PY'
 import json,glob
 for f in sorted(glob.glob("gpurun_out/r4p/r4_*bench*.json")):
+    if "rocprof" in f: continue
     try:
         j=json.loads(open(f).read().strip().splitlines()[-1]); r=j["roofline"]
         print(f, j["value"], j["ms_per_step"], "frac", r["frac"], "step_frac", r["step_frac"], "gemm", r["gemm_ms_per_step"], "quant", r["quant_hadamard_ms_per_step"])
