@@ -106,6 +106,80 @@ __global__ __launch_bounds__(256) void act_quant_kernel(
     }
 }
 
+// The prefill's case on its own kernel: one scale per row (two with the token-type mask), int8 levels into the tiled
+// image, 16-byte aligned rows, K a multiple of 16.  A wave owns one 1 KiB piece (EPT = 16: lane = 16 chunk + row) or
+// half of one (EPT = 8: lane = 32 chunk + 2 row + half chunk) and writes it as ONE contiguous run; the piece comes from
+// the grid (x: four k-units per workgroup, y: 16-row tile), so there is no division, and 1 / s comes from the host.
+struct AqTiledArgs {
+    const void *x;
+    long M, K, ldx;
+    float s0, s1, inv0, inv1;
+    int rcp0, rcp1;
+    const uint8_t *row_sel;
+    int skip_col0;
+    float *x0_out;
+    int8_t *out;
+    int kts;
+};
+
+#ifndef MQ_AQ_EPT
+#define MQ_AQ_EPT 8
+#endif
+
+template <int DT, int EPT>
+__global__ __launch_bounds__(256) void act_quant_tiled_kernel(AqTiledArgs p)
+{
+    typedef typename Elem<DT>::T T;
+    constexpr int WPP = 16 / EPT;                                  // waves per piece
+    const int lane = threadIdx.x & 63;
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);           // kt * WPP + half, wave-uniform
+    if (unit >= p.kts * WPP) return;
+    const int kt = unit / WPP, half = unit % WPP;
+    const int mt = blockIdx.y;
+    int r, col;
+    if (EPT == 16) {
+        r = lane & 15;
+        col = kt * 64 + (lane >> 4) * 16;
+    } else {
+        r = (lane >> 1) & 15;
+        col = kt * 64 + (half * 2 + (lane >> 5)) * 16 + (lane & 1) * 8;
+    }
+    const long row = (long)mt * 16 + r;
+    if (row >= p.M) return;
+    const bool sel = p.row_sel && p.row_sel[row] != 0;             // requested ahead of the activations: it returns first
+    int8_t *o = p.out + ((long)mt * p.kts + kt) * 1024 + half * 512 + lane * EPT;
+    if (col >= p.K) {                                               // pad columns of the image
+        if (EPT == 16) *reinterpret_cast<v4i *>(o) = v4i{0, 0, 0, 0};
+        else *reinterpret_cast<v2i *>(o) = v2i{0, 0};
+        return;
+    }
+    const T *xr = reinterpret_cast<const T *>(p.x) + row * p.ldx + col;
+    float v[EPT];
+    if (sizeof(T) == 2) {
+#pragma unroll
+        for (int j = 0; j < EPT / 8; ++j) {
+            const v8us a = *reinterpret_cast<const v8us *>(xr + 8 * j);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[8 * j + i] = Elem<DT>::ld((T)a[i]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < EPT / 4; ++j) {
+            const v4f a = *reinterpret_cast<const v4f *>((const float *)xr + 4 * j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[4 * j + i] = a[i];
+        }
+    }
+    unsigned w[EPT / 4];
+    quant_levels_i8_packed<EPT>(v, sel ? p.s1 : p.s0, sel ? p.inv1 : p.inv0, (sel ? p.rcp1 : p.rcp0) != 0, w);
+    if (p.skip_col0 && col == 0) {
+        if (p.x0_out) p.x0_out[row] = v[0];
+        w[0] &= 0xffffff00u;
+    }
+    if (EPT == 16) *reinterpret_cast<v4i *>(o) = v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+    else *reinterpret_cast<v2i *>(o) = v2i{(int)w[0], (int)w[1]};
+}
+
 template <int DT, bool DEQUANT>
 static int launch_act_quant(const void *x, long M, long K, long ldx, float scale0, float scale1,
                             const float *sv0, const float *sv1, const uint8_t *row_sel,
@@ -116,6 +190,14 @@ static int launch_act_quant(const void *x, long M, long K, long ldx, float scale
     const long total = ((!DEQUANT && ldo == MQ_LD_TILED) ? ((M + 15) / 16) * 16 : M) * (K_pad / 16);
     if (total == 0) return MQ_OK;
     const int vec_ok = (((uintptr_t)x) % 16 == 0) && ((ldx * (long)sizeof(T)) % 16 == 0);
+    if (!DEQUANT && ldo == MQ_LD_TILED && !sv0 && vec_ok && K % 16 == 0 && (M + 15) / 16 <= 65535) {
+        constexpr int EPT = MQ_AQ_EPT;
+        AqTiledArgs a{x, M, K, ldx, scale0, scale1, 1.0f / scale0, 1.0f / scale1, quant_rcp_ok(scale0), quant_rcp_ok(scale1),
+                      row_sel, skip_col0, x0_out, (int8_t *)out, (int)(K_pad / 64)};
+        const unsigned gx = (unsigned)ceil_div(K_pad / 64 * (16 / EPT), 4);
+        hipLaunchKernelGGL((act_quant_tiled_kernel<DT, EPT>), dim3(gx, (unsigned)((M + 15) / 16)), dim3(256), 0, st, a);
+        return check_launch("act_quant_tiled");
+    }
     long blocks = ceil_div(total, 256);
     if (blocks > 256L * 16) blocks = 256L * 16;
     hipLaunchKernelGGL((act_quant_kernel<DT, DEQUANT>), dim3((unsigned)blocks), dim3(256), 0, st,

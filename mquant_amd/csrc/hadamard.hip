@@ -91,16 +91,23 @@ __device__ __forceinline__ void had_emit_n(const HadArgs &p, long row, long col,
     float r[N];
 #pragma unroll
     for (int e = 0; e < N; ++e) r[e] = Elem<DT>::rnd(v[e]);
-    if (QUANT) {
+    if (QUANT && N == 4 && aligned) {
+        unsigned w[1];
+        const float r4[4] = {r[0], r[1], r[N > 2 ? 2 : 0], r[N > 3 ? 3 : 0]};   // (N == 4 here)
+        quant_levels_i8_packed<4>(r4, rs.s, rs.inv, rs.rcp, w);
+        if (p.skip_col0 && col == 0) {
+            if (p.x0_out) p.x0_out[row] = r[0];
+            w[0] &= 0xffffff00u;
+        }
+        *reinterpret_cast<unsigned *>(o) = w[0];
+    } else if (QUANT) {
         int q[N];
         quant_levels<N>(r, rs.s, rs.inv, rs.rcp, -128.0f, 127.0f, q);
         if (p.skip_col0 && col == 0) {
             if (p.x0_out) p.x0_out[row] = r[0];
             q[0] = 0;
         }
-        if (N == 4 && aligned) {
-            *reinterpret_cast<unsigned *>(o) = (q[0] & 0xff) | ((q[1] & 0xff) << 8) | ((q[2] & 0xff) << 16) | ((unsigned)(q[3] & 0xff) << 24);
-        } else if (N == 2) {
+        if (N == 2) {
             *reinterpret_cast<unsigned short *>(o) = (unsigned short)((q[0] & 0xff) | ((q[1] & 0xff) << 8));
         } else {
 #pragma unroll
@@ -194,15 +201,15 @@ __device__ __forceinline__ void had_kxk_unit(const HadArgs &p, long row, const R
                 if ((r & 1) || j >= K) continue;                   // K % 4 == 0 and j0 % 4 == 0: rows r, r + 1 are both valid or both past K
                 const float v4[4] = {Elem<DT>::rnd(acc[jj][0][r]), Elem<DT>::rnd(acc[jj][1][r]),
                                      Elem<DT>::rnd(acc[jj][0][r + 1]), Elem<DT>::rnd(acc[jj][1][r + 1])};
-                int q[4];
-                quant_levels<4>(v4, rs.s, rs.inv, rs.rcp, -128.0f, 127.0f, q);
+                unsigned w[1];
+                quant_levels_i8_packed<4>(v4, rs.s, rs.inv, rs.rcp, w);
                 if (p.skip_col0 && j == 0 && col0 == 0) {          // (row j = 0, column 0) is flat column 0
                     if (p.x0_out) p.x0_out[row] = v4[0];
-                    q[0] = 0;
+                    w[0] &= 0xffffff00u;
                 }
                 int8_t *o = obase + (jj * 16 + r) * ostride;
-                *reinterpret_cast<unsigned short *>(o) = (unsigned short)((q[0] & 0xff) | ((q[1] & 0xff) << 8));
-                *reinterpret_cast<unsigned short *>(o + ostride) = (unsigned short)((q[2] & 0xff) | ((q[3] & 0xff) << 8));
+                *reinterpret_cast<unsigned short *>(o) = (unsigned short)w[0];
+                *reinterpret_cast<unsigned short *>(o + ostride) = (unsigned short)(w[0] >> 16);
                 continue;
             }
             if (j < K) {

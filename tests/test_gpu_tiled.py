@@ -66,6 +66,38 @@ def test_static_quantizer_tiled_equals_oracle(dtype, shape):
     assert torch.equal(q.to_rows(), q2)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(16, 64), (45, 1296), (768, 3584), (1030, 1280), (3, 3600)])
+def test_static_quantizer_tiled_next_to_half_integers(dtype, shape):
+    """The per-row-scale kernel of the tiled image (K % 16 == 0, aligned rows) multiplies by 1 / s and takes the IEEE quotient
+    only where the two can round differently: quotients ON and one ulp either side of every half-integer, saturating values,
+    zeros, pad columns (K < K_pad) and a ragged last row tile must give the oracle's levels (uniform.py:20-33)."""
+    M, K = shape
+    rng = np.random.default_rng(M * 7 + K)
+    s0, s1 = np.float32(0.0371), np.float32(0.00931)
+    sel = (np.arange(M) % 2 == 1).astype(np.uint8)
+    s_row = np.where(sel != 0, s1, s0).astype(np.float32)[:, None]
+    half = (rng.integers(-131, 131, size=(M, K)).astype(np.float32) + np.float32(0.5)) * s_row
+    nudge = rng.integers(-2, 3, size=(M, K))
+    x = half.copy()
+    for d in (-2, -1, 1, 2):
+        tgt = np.float32(np.inf) if d > 0 else np.float32(-np.inf)
+        step = x.copy()
+        for _ in range(abs(d)):
+            step = np.nextafter(step, tgt)
+        x = np.where(nudge == d, step, x)
+    plain = make_x(11, shape, outlier_gain=30.0)
+    x = np.where(rng.random((M, K)) < 0.5, x, plain).astype(np.float32)
+    x[:, 1::97] = 0.0
+    xt = to_dev(x, dtype)
+    q, _ = ops().quantize_act_i8(xt, float(s0), float(s1), row_sel=to_dev(sel), tiled=True)
+    xr = xt.float().cpu().numpy()
+    ref = np.where(sel[:, None] != 0, oracle.quant_static(xr, s1), oracle.quant_static(xr, s0))
+    got = q.to_rows().cpu().numpy()
+    np.testing.assert_array_equal(got[:, :K], ref)
+    assert not got[:, K:].any()
+
+
 @pytest.mark.parametrize("n_in,n", [(5120, 5120), (18944, 19968), (1280, 1280), (700, 768)])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_hadamard_quant_tiled_equals_row_major(had_table, n_in, n, dtype):
