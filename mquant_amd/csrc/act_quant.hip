@@ -125,37 +125,41 @@ struct AqTiledArgs {
 #ifndef MQ_AQ_EPT
 #define MQ_AQ_EPT 8
 #endif
+#ifndef MQ_AQ_THREADS
+#define MQ_AQ_THREADS 256
+#endif
 
-template <int DT, int EPT>
-__global__ __launch_bounds__(256) void act_quant_tiled_kernel(AqTiledArgs p)
+template <int DT, int EPT, int THREADS>
+__global__ __launch_bounds__(THREADS) void act_quant_tiled_kernel(AqTiledArgs p)
 {
     typedef typename Elem<DT>::T T;
     constexpr int WPP = 16 / EPT;                                  // waves per piece
+    constexpr int SUB = 16 / EPT;                                  // lanes per 16-byte chunk of the image
+    constexpr int CPW = EPT / 4;                                   // chunks (of 16 rows) per wave
     const int lane = threadIdx.x & 63;
-    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);           // kt * WPP + half, wave-uniform
+    const int unit = blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6);   // kt * WPP + part, wave-uniform
     if (unit >= p.kts * WPP) return;
-    const int kt = unit / WPP, half = unit % WPP;
+    const int kt = unit / WPP, part = unit % WPP;
     const int mt = blockIdx.y;
-    int r, col;
-    if (EPT == 16) {
-        r = lane & 15;
-        col = kt * 64 + (lane >> 4) * 16;
-    } else {
-        r = (lane >> 1) & 15;
-        col = kt * 64 + (half * 2 + (lane >> 5)) * 16 + (lane & 1) * 8;
-    }
+    const int r = (lane / SUB) & 15;
+    const int col = kt * 64 + (part * CPW + lane / (SUB * 16)) * 16 + (lane % SUB) * EPT;
     const long row = (long)mt * 16 + r;
     if (row >= p.M) return;
     const bool sel = p.row_sel && p.row_sel[row] != 0;             // requested ahead of the activations: it returns first
-    int8_t *o = p.out + ((long)mt * p.kts + kt) * 1024 + half * 512 + lane * EPT;
+    int8_t *o = p.out + ((long)mt * p.kts + kt) * 1024 + part * (64 * EPT) + lane * EPT;
     if (col >= p.K) {                                               // pad columns of the image
         if (EPT == 16) *reinterpret_cast<v4i *>(o) = v4i{0, 0, 0, 0};
-        else *reinterpret_cast<v2i *>(o) = v2i{0, 0};
+        else if (EPT == 8) *reinterpret_cast<v2i *>(o) = v2i{0, 0};
+        else *reinterpret_cast<int *>(o) = 0;
         return;
     }
     const T *xr = reinterpret_cast<const T *>(p.x) + row * p.ldx + col;
     float v[EPT];
-    if (sizeof(T) == 2) {
+    if (sizeof(T) == 2 && EPT == 4) {
+        const v4us a = *reinterpret_cast<const v4us *>(xr);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = Elem<DT>::ld((T)a[i]);
+    } else if (sizeof(T) == 2) {
 #pragma unroll
         for (int j = 0; j < EPT / 8; ++j) {
             const v8us a = *reinterpret_cast<const v8us *>(xr + 8 * j);
@@ -177,7 +181,8 @@ __global__ __launch_bounds__(256) void act_quant_tiled_kernel(AqTiledArgs p)
         w[0] &= 0xffffff00u;
     }
     if (EPT == 16) *reinterpret_cast<v4i *>(o) = v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
-    else *reinterpret_cast<v2i *>(o) = v2i{(int)w[0], (int)w[1]};
+    else if (EPT == 8) *reinterpret_cast<v2i *>(o) = v2i{(int)w[0], (int)w[EPT / 4 - 1]};
+    else *reinterpret_cast<unsigned *>(o) = w[0];
 }
 
 template <int DT, bool DEQUANT>
@@ -190,12 +195,18 @@ static int launch_act_quant(const void *x, long M, long K, long ldx, float scale
     const long total = ((!DEQUANT && ldo == MQ_LD_TILED) ? ((M + 15) / 16) * 16 : M) * (K_pad / 16);
     if (total == 0) return MQ_OK;
     const int vec_ok = (((uintptr_t)x) % 16 == 0) && ((ldx * (long)sizeof(T)) % 16 == 0);
-    if (!DEQUANT && ldo == MQ_LD_TILED && !sv0 && vec_ok && K % 16 == 0 && (M + 15) / 16 <= 65535) {
+#ifdef MQ_AQ_GENERIC_ONLY   // A/B builds (tools/bench_ab.sh): everything on the general kernel, as before round 4
+    const bool own_kernel = false;
+#else
+    const bool own_kernel = true;
+#endif
+    if (own_kernel && !DEQUANT && ldo == MQ_LD_TILED && !sv0 && vec_ok && K % 16 == 0 && (M + 15) / 16 <= 65535) {
         constexpr int EPT = MQ_AQ_EPT;
         AqTiledArgs a{x, M, K, ldx, scale0, scale1, 1.0f / scale0, 1.0f / scale1, quant_rcp_ok(scale0), quant_rcp_ok(scale1),
                       row_sel, skip_col0, x0_out, (int8_t *)out, (int)(K_pad / 64)};
-        const unsigned gx = (unsigned)ceil_div(K_pad / 64 * (16 / EPT), 4);
-        hipLaunchKernelGGL((act_quant_tiled_kernel<DT, EPT>), dim3(gx, (unsigned)((M + 15) / 16)), dim3(256), 0, st, a);
+        constexpr int THREADS = MQ_AQ_THREADS;
+        const unsigned gx = (unsigned)ceil_div(K_pad / 64 * (16 / EPT), THREADS / 64);
+        hipLaunchKernelGGL((act_quant_tiled_kernel<DT, EPT, THREADS>), dim3(gx, (unsigned)((M + 15) / 16)), dim3(THREADS), 0, st, a);
         return check_launch("act_quant_tiled");
     }
     long blocks = ceil_div(total, 256);

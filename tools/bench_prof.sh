@@ -39,4 +39,4 @@ with open(sys.argv[1] + "_kernel_stats.csv", "w") as fh:
         fh.write(f'"{name}",{blocks},{len(v)},{sum(v)/len(v)/1e3:.2f},{min(v)/1e3:.2f},{sum(v)/1e6:.3f},{sum(v)/tot:.4f}\n')
 print(open(sys.argv[1] + "_kernel_stats.csv").read())
 PY
-rm -f gpurun_out/bp/b_kernel_trace.csv
+[ -n "${KEEP_TRACE:-}" ] || rm -f gpurun_out/bp/b_kernel_trace.csv
