@@ -160,33 +160,74 @@ __device__ __forceinline__ void had_kxk_unit(const HadArgs &p, long row, const R
     int jts[UJ];
 #pragma unroll
     for (int jj = 0; jj < UJ; ++jj) jts[jj] = (jg * UJ + jj < JT) ? jg * UJ + jj : JT - 1;
-    // (fetching the masks / staged values of step t+1 during step t was measured slower: the register
-    // copies are VALU work too, and VALU work is what this kernel is bound by -- DESIGN 4.2)
-    for (int t = 0; t < ksteps; ++t) {
+    // Two register sets, filled one k-step AHEAD (the loop is unrolled by two, so no set is ever copied): the scalar loads
+    // of the masks and the LDS read of the staged values of step t+1 are in flight while the ten MFMAs of step t issue, and
+    // the wave never waits for them at the top of a step.  (Per-CU timelines, profiles/r4_hadamard_cu_timeline.txt: a
+    // row alone on its CU spent 1077 cycles per k-step on a SIMD whose two waves need 640 for their MFMAs.)
+    typedef unsigned long long u64;
+    u64 mk[2][UJ];
+    unsigned hvw[2][UG == 2 ? 1 : 2];
+    float bf[2][UG];
+    auto fetch = [&](int set, int t) {
         const char *src = yp + t * kstride;
-        float b[UG];
         if (HALF_LDS) {
             if (UG == 2) {
-                const unsigned hv = *reinterpret_cast<const unsigned *>(src);
-                b[0] = S::ld((YT)(hv & 0xffff));
-                b[1] = S::ld((YT)(hv >> 16));
+                hvw[set][0] = *reinterpret_cast<const unsigned *>(src);
             } else {
-                const v4us hv = *reinterpret_cast<const v4us *>(src);
-#pragma unroll
-                for (int g = 0; g < UG; ++g) b[g] = S::ld((YT)hv[g]);
+                const v2i hv = *reinterpret_cast<const v2i *>(src);
+                hvw[set][0] = (unsigned)hv[0];
+                hvw[set][UG == 2 ? 0 : 1] = (unsigned)hv[1];
             }
         } else {
 #pragma unroll
-            for (int g = 0; g < UG; ++g) b[g] = *reinterpret_cast<const float *>(src + 4 * g);
+            for (int g = 0; g < UG; ++g) bf[set][g] = *reinterpret_cast<const float *>(src + 4 * g);
         }
 #pragma unroll
-        for (int jj = 0; jj < UJ; ++jj) {
-            const unsigned long long mask = ((cmask_t *)(p.masks))[(long)t * JT + jts[jj]];   // scalar load
-            // lane l: bit l set <=> hadK[16 jt + (l & 15)][4 t + (l >> 4)] == -1; one v_cndmask with the SGPR pair
-            const float a = __builtin_amdgcn_inverse_ballot_w64(mask) ? negv[jj] : posv[jj];
+        for (int jj = 0; jj < UJ; ++jj) mk[set][jj] = ((cmask_t *)(p.masks))[(long)t * JT + jts[jj]];   // scalar loads
+    };
+    // (scalar loads return out of order, so ANY wait for one is lgkmcnt(0): the operands of a step are therefore formed --
+    //  one v_cndmask per 16-row tile, the conversions -- BEFORE the next step's loads go out, and its MFMAs issue after)
+    float av[UJ], b[UG];
+    auto prep = [&](int set) {
+        if (HALF_LDS) {
 #pragma unroll
-            for (int g = 0; g < UG; ++g) acc[jj][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[g], acc[jj][g], 0, 0, 0);
+            for (int g = 0; g < UG; ++g) {
+                const unsigned wd = hvw[set][UG == 2 ? 0 : g >> 1];
+                b[g] = S::ld((YT)((g & 1) ? (wd >> 16) : (wd & 0xffff)));
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < UG; ++g) b[g] = bf[set][g];
         }
+        // lane l: bit l set <=> hadK[16 jt + (l & 15)][4 t + (l >> 4)] == -1; one v_cndmask with the SGPR pair
+#pragma unroll
+        for (int jj = 0; jj < UJ; ++jj) av[jj] = __builtin_amdgcn_inverse_ballot_w64(mk[set][jj]) ? negv[jj] : posv[jj];
+    };
+    auto mma = [&]() {
+#pragma unroll
+        for (int jj = 0; jj < UJ; ++jj)
+#pragma unroll
+            for (int g = 0; g < UG; ++g) acc[jj][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj], b[g], acc[jj][g], 0, 0, 0);
+    };
+    fetch(0, 0);
+    int t = 0;
+    for (; t + 2 <= ksteps; t += 2) {
+        prep(0);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(1, t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma();
+        __builtin_amdgcn_sched_barrier(0);
+        prep(1);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(0, t + 2 < ksteps ? t + 2 : t + 1);          // (the last fetch of an even count is a repeat, never used)
+        __builtin_amdgcn_sched_barrier(0);
+        mma();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (t < ksteps) {
+        prep(0);
+        mma();
     }
     const int j0 = jg * UJ * 16 + lk * 4;                       // first output row j of this lane
     const long ostride = had_out_stride(p);
@@ -225,8 +266,9 @@ __device__ __forceinline__ void had_kxk_unit(const HadArgs &p, long row, const R
         }
 }
 
+// (16-bit staging: four waves per SIMD -- two 8-wave or four 4-wave rows per CU -- are part of the design: at most 128 registers)
 template <int DT, bool QUANT, bool HALF_LDS, int THREADS, bool ACT = false, int UNIT = 0>
-__global__ __launch_bounds__(THREADS) void hadamard_kernel(HadArgs p)
+__global__ __launch_bounds__(THREADS, HALF_LDS ? 4 : 1) void hadamard_kernel(HadArgs p)
 {
     constexpr int HAD_THREADS = THREADS;
     constexpr int HAD_WAVES = THREADS / 64;

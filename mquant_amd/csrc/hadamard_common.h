@@ -3,6 +3,10 @@
 #pragma once
 #include "mq_common.h"
 
+#ifndef MQ_HAD_X4
+#define MQ_HAD_X4 1   // lane ^ 4 exchange of the butterflies: 0 = two DPP rotations + select, 1 = ds_swizzle (measured a little faster)
+#endif
+
 namespace mq {
 
 struct HadArgs {
@@ -84,6 +88,39 @@ __device__ __forceinline__ void had_load_chunk(const HadArgs &p, long row, long 
     }
 }
 
+// One butterfly stage between lanes l and l ^ LM (LM = 1, 2, 4, 8) for the 8 registers of a lane.  Lower lane of a pair:
+// a + b; upper lane: a - b seen from the lower one = other + (-own): other + (+-own) with its ONE rounding either way.
+// The partner's value comes through the DPP lane network (lane ^ 1, ^ 2: quad permutes; ^ 8: rotation by 8 inside the row
+// of 16; ^ 4: the two rotations by 4, selected by the lane's bit) -- plain vector-ALU operands, where ds_bpermute sends
+// every exchange through the LDS crossbar: the 32 exchanges per chunk bound phase A of the kernel
+// (profiles/r4_hadamard_cu_timeline.txt).
+template <int LM>
+__device__ __forceinline__ void had_lane_stage(float (&v)[8], int lane)
+{
+    const unsigned flip = (lane & LM) ? 0x80000000u : 0u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int own = __float_as_int(v[i]);
+        int o;
+        if (LM == 1) {
+            o = __builtin_amdgcn_update_dpp(0, own, 0xB1, 0xf, 0xf, true);          // quad_perm [1,0,3,2]
+        } else if (LM == 2) {
+            o = __builtin_amdgcn_update_dpp(0, own, 0x4E, 0xf, 0xf, true);          // quad_perm [2,3,0,1]
+        } else if (LM == 4) {
+#if MQ_HAD_X4 == 1
+            o = __builtin_amdgcn_ds_swizzle(own, 0x101f);                           // lane ^ 4 (bit mode)
+#else
+            const int up = __builtin_amdgcn_update_dpp(0, own, 0x124, 0xf, 0xf, true);   // row_ror:4
+            const int dn = __builtin_amdgcn_update_dpp(0, own, 0x12C, 0xf, 0xf, true);   // row_ror:12
+            o = (lane & 4) ? up : dn;
+#endif
+        } else {
+            o = __builtin_amdgcn_update_dpp(0, own, 0x128, 0xf, 0xf, true);         // row_ror:8
+        }
+        v[i] = __int_as_float(o) + __uint_as_float((unsigned)own ^ flip);
+    }
+}
+
 // Butterflies of one chunk in the reference's ascending-stride (a + b, a - b) order: strides 1, 2, 4 inside
 // the lane's 8 registers, strides 8 .. min(m, 512) / 2 by wavefront shuffles (lane ^ stride / 8); when the
 // whole co-factor fits the chunk (m <= 512) also * 1 / sqrt(n) and the cast the FHT extension performs.
@@ -101,10 +138,14 @@ __device__ __forceinline__ void had_butterfly_chunk(float (&v)[8], int lane, int
             }
         }
     }
-    for (int h = 8; h < m && h < 512; h <<= 1) {
+    // strides 8 .. 64 (lane ^ 1 .. ^ 8) on the DPP lane network, one straight-line stage each; 128, 256 (m = 256, 512) by
+    // wavefront shuffle
+    if (m > 8) had_lane_stage<1>(v, lane);
+    if (m > 16) had_lane_stage<2>(v, lane);
+    if (m > 32) had_lane_stage<4>(v, lane);
+    if (m > 64) had_lane_stage<8>(v, lane);
+    for (int h = 128; h < m && h < 512; h <<= 1) {
         const int lm = h >> 3;
-        // lower lane of a pair: a + b, upper lane: a - b.  fma(own, +-1, other) is that sum / difference with its one
-        // rounding (own * +-1 is exact) in ONE instruction per element instead of a subtract, an add and a select
         const float sgn = (lane & lm) ? -1.0f : 1.0f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
