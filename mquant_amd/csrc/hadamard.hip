@@ -543,6 +543,12 @@ static int launch_hadamard_t(HadArgs p, hipStream_t st)
     }
     long per_cu = (160 * 1024) / (long)lds;
     if (per_cu > 8) per_cu = 8;
+#ifndef MQ_HAD_GRID_BY_LDS
+    // Only as many workgroups as are RESIDENT (16-bit staging: 16 waves per CU, the kernel's launch bounds): the row loop
+    // hands a workgroup its next row the moment it is done, whereas a workgroup dispatched into a freed slot started
+    // 15 k cycles later (profiles/r4_hadamard_cu_timeline.txt)
+    if (HALF_LDS && per_cu > 16 / (THREADS / 64)) per_cu = 16 / (THREADS / 64);
+#endif
     if (per_cu < 1) per_cu = 1;
     long blocks = 256L * per_cu;
     if (blocks > p.M) blocks = p.M;
