@@ -437,6 +437,14 @@ __global__ __launch_bounds__(THREADS, HALF_LDS ? 4 : 1) void hadamard_kernel(Had
                                                  S::ld(*reinterpret_cast<const YT *>(ybase + yoff(0, (int)(idx + i)))), s);
                 }
             }
+        } else if (UNIT == 3) {
+            // prepared descriptor: 3 x 2 units, ONE per wave (the vision tower's fc2, 40 x 128: four; Qwen-VL's 172 x 64: eight).
+            // The classic path below has six (16 rows x 64 columns) units for the four waves of a row; the waves with two
+            // sit on the same two SIMDs in every resident workgroup, which then carry twice the matrix work of the others.
+            const int JT = (K + 15) / 16;
+            const int JG = (JT + 2) / 3, CG = m / 32;
+            for (int u = wave; u < JG * CG; u += HAD_WAVES)
+                had_kxk_unit<DT, QUANT, HALF_LDS, 3, 2>(p, row, rs, ybase, row_bytes, swz, u / CG, u % CG, lane);
         } else if (UNIT == 5) {
             // prepared descriptor: mask-driven 5 x 2 units (had_kxk_unit), one unit per wave for K = 156, m = 128.
             // Its own instantiation: the 40 accumulator registers must not raise the register count (and lower
@@ -612,12 +620,18 @@ static int launch_hadamard(const HadArgs &p, hipStream_t st)
         if (!g_had_threads) threads = units >= 8 ? 512 : 256;
     }
     const bool unit5 = p.masks && p.unit_j == 5 && threads == 512;
+    const bool unit3 = p.masks && p.unit_j == 3 && threads == 256 && units == 4;
+    const bool unit3w = p.masks && p.unit_j == 3 && threads == 512 && units == 8;
     if (QUANT && p.act != MQ_ACT_NONE) {
         if (unit5) return launch_hadamard_t<DT, QUANT, HALF_LDS, 512, QUANT, 5>(p, st);
+        if (unit3) return launch_hadamard_t<DT, QUANT, HALF_LDS, 256, QUANT, 3>(p, st);
+        if (unit3w) return launch_hadamard_t<DT, QUANT, HALF_LDS, 512, QUANT, 3>(p, st);
         if (threads == 512) return launch_hadamard_t<DT, QUANT, HALF_LDS, 512, QUANT>(p, st);
         return launch_hadamard_t<DT, QUANT, HALF_LDS, 256, QUANT>(p, st);
     }
     if (unit5) return launch_hadamard_t<DT, QUANT, HALF_LDS, 512, false, 5>(p, st);
+    if (unit3) return launch_hadamard_t<DT, QUANT, HALF_LDS, 256, false, 3>(p, st);
+    if (unit3w) return launch_hadamard_t<DT, QUANT, HALF_LDS, 512, false, 3>(p, st);
     if (threads == 512) return launch_hadamard_t<DT, QUANT, HALF_LDS, 512>(p, st);
     return launch_hadamard_t<DT, QUANT, HALF_LDS, 256>(p, st);
 }
@@ -657,8 +671,16 @@ static int hadamard_common(HadArgs p, int x_dtype, bool quant, void *stream)
         const int JT = (p.K + 15) / 16;
         // measured (profiles/r2_hadamard.txt): the 5 x 2 units pay off for the large factors (K = 140 / 156 /
         // 172, down_proj 76 -> 72 us); for small K the round-1 form (one tile x four column tiles) is faster
-        if (p.m >= 64 && p.m % 32 == 0 && JT >= 8) {
+        // measured (profiles/r2_hadamard.txt, r4_hadamard_cu_timeline.txt): mask-driven units pay off where a row splits into
+        // exactly ONE unit per wave (wave w of every resident workgroup runs on the same SIMD, so uneven shares pile up there):
+        // 5 x 2 units for K = 140 / 156 with m = 128 (eight waves), 3 x 2 units for K = 172 with m = 64 (eight waves) and for the
+        // vision tower's 40 x 128 (four waves); everything else keeps the round-1 form (one tile x four column tiles)
+        const int u5 = ((JT + 4) / 5) * (p.m / 32), u3 = ((JT + 2) / 3) * (p.m / 32);
+        if (p.m >= 64 && p.m % 32 == 0 && JT >= 8 && u5 == 8) {
             p.unit_j = 5;
+            p.unit_g = 2;
+        } else if (p.m >= 64 && p.m % 32 == 0 && (u3 == 8 || u3 == 4)) {
+            p.unit_j = 3;
             p.unit_g = 2;
         } else {
             p.masks = nullptr;
