@@ -185,7 +185,7 @@ __device__ __forceinline__ void store_quad(const GemmArgs &p, long m, long n, v4
     if (EPI == EPI_F32) {
         float *o = reinterpret_cast<float *>(p.out) + m * p.ldo + n;
         if (full) {
-            *reinterpret_cast<v4f *>(o) = v4f{y[0], y[1], y[2], y[3]};
+            store_out(reinterpret_cast<v4f *>(o), v4f{y[0], y[1], y[2], y[3]});
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -198,7 +198,7 @@ __device__ __forceinline__ void store_quad(const GemmArgs &p, long m, long n, v4
             h[r] = (EPI == EPI_F16) ? f32_to_f16_bits(y[r]) : f32_to_bf16_bits(y[r]);
         unsigned short *o = reinterpret_cast<unsigned short *>(p.out) + m * p.ldo + n;
         if (full) {
-            *reinterpret_cast<v4us *>(o) = v4us{h[0], h[1], h[2], h[3]};
+            store_out(reinterpret_cast<v4us *>(o), v4us{h[0], h[1], h[2], h[3]});
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -374,8 +374,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][
             if (EPI == EPI_F32) {
                 float *o = reinterpret_cast<float *>(p.out) + m * p.ldo + n;
                 if (n_full) {
-                    *reinterpret_cast<v4f *>(o) = v4f{y[0], y[1], y[2], y[3]};
-                    *reinterpret_cast<v4f *>(o + 4) = v4f{y[4], y[5], y[6], y[7]};
+                    store_out(reinterpret_cast<v4f *>(o), v4f{y[0], y[1], y[2], y[3]});
+                    store_out(reinterpret_cast<v4f *>(o + 4), v4f{y[4], y[5], y[6], y[7]});
                 } else {
                     for (int e = 0; e < 8; ++e)
                         if (n + e < p.N) o[e] = y[e];
@@ -387,7 +387,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][
                     h[e] = (EPI == EPI_F16) ? f32_to_f16_bits(y[e]) : f32_to_bf16_bits(y[e]);
                 unsigned short *o = reinterpret_cast<unsigned short *>(p.out) + m * p.ldo + n;
                 if (n_full) {
-                    *reinterpret_cast<v8us *>(o) = h;
+                    store_out(reinterpret_cast<v8us *>(o), h);
                 } else {
                     for (int e = 0; e < 8; ++e)
                         if (n + e < p.N) o[e] = h[e];

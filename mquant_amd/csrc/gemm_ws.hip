@@ -413,14 +413,14 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
             if (m >= p.M || t * RPI + lrow >= BM) continue;
             if (EPI == EPI_F32) {
                 float *o = reinterpret_cast<float *>(p.out) + m * p.ldo + n;
-                *reinterpret_cast<v4f *>(o) = v4f{y[0], y[1], y[2], y[3]};
-                *reinterpret_cast<v4f *>(o + 4) = v4f{y[4], y[5], y[6], y[7]};
+                store_out(reinterpret_cast<v4f *>(o), v4f{y[0], y[1], y[2], y[3]});
+                store_out(reinterpret_cast<v4f *>(o + 4), v4f{y[4], y[5], y[6], y[7]});
             } else {
                 v8us h;
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     h[e] = (EPI == EPI_F16) ? f32_to_f16_bits(y[e]) : f32_to_bf16_bits(y[e]);
-                *reinterpret_cast<v8us *>(reinterpret_cast<unsigned short *>(p.out) + m * p.ldo + n) = h;
+                store_out(reinterpret_cast<v8us *>(reinterpret_cast<unsigned short *>(p.out) + m * p.ldo + n), h);
             }
         }
         return;
@@ -496,8 +496,8 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
         if (EPI == EPI_F32) {
             float *o = reinterpret_cast<float *>(p.out) + m * p.ldo + n;
             if (n_full) {
-                *reinterpret_cast<v4f *>(o) = v4f{y[0], y[1], y[2], y[3]};
-                *reinterpret_cast<v4f *>(o + 4) = v4f{y[4], y[5], y[6], y[7]};
+                store_out(reinterpret_cast<v4f *>(o), v4f{y[0], y[1], y[2], y[3]});
+                store_out(reinterpret_cast<v4f *>(o + 4), v4f{y[4], y[5], y[6], y[7]});
             } else {
                 for (int e = 0; e < 8; ++e)
                     if (n + e < p.N) o[e] = y[e];
@@ -509,7 +509,7 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
                 h[e] = (EPI == EPI_F16) ? f32_to_f16_bits(y[e]) : f32_to_bf16_bits(y[e]);
             unsigned short *o = reinterpret_cast<unsigned short *>(p.out) + m * p.ldo + n;
             if (n_full) {
-                *reinterpret_cast<v8us *>(o) = h;
+                store_out(reinterpret_cast<v8us *>(o), h);
             } else {
                 for (int e = 0; e < 8; ++e)
                     if (n + e < p.N) o[e] = h[e];

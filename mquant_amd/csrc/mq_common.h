@@ -30,6 +30,23 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned short v8us __attribute__((ext_vector_type(8)));
 typedef unsigned short v4us __attribute__((ext_vector_type(4)));
 
+// ---- stores of kernel RESULTS ------------------------------------------------------------------
+// What a kernel writes here is read next by ANOTHER launch (on all XCDs: through the Infinity Cache / HBM, never through the
+// writer's L2).  A plain store leaves the lines dirty in the XCD's L2 and the launch ends with their write-back; the
+// non-temporal form streams them out while the kernel still runs: 4-9 % of a small GEMM launch
+// (profiles/r4_streaming_stores.txt).  For WHOLE lines only (the GEMM epilogues: 16 bytes per lane, rows of 128+ bytes): the
+// 2-byte level stores of the Hadamard kernel became slower that way (partial lines go out one by one instead of merging
+// in L2) and the quantizer did not change, so both keep plain stores.  MQ_PLAIN_STORES: A/B builds.
+template <typename V>
+__device__ __forceinline__ void store_out(V *ptr, V v)
+{
+#ifdef MQ_PLAIN_STORES
+    *ptr = v;
+#else
+    __builtin_nontemporal_store(v, ptr);
+#endif
+}
+
 // ---- dtype conversion (round-to-nearest-even everywhere) --------------------
 __device__ __forceinline__ float f16_bits_to_f32(unsigned short h)
 {
