@@ -270,6 +270,104 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][
     // per lane, and parked behind the slab so the store loop never waits on global memory
     float *rowpar = reinterpret_cast<float *>(slab + PASS_ROWS * SLAB_LD);   // [PASS_ROWS][4]: s_x, x0, x1, unused
 
+    // Fast path (what every Linear of the prefill takes: whole 8-channel groups, fp16 / bf16 / fp32 output, no residual,
+    // no split-K, integer accumulators).  Straight-line code per half pass: the slab reads and row parameters of four row
+    // groups first, then the packed arithmetic, then the stores back to back.  The general loop below spent 16.5 k cycles
+    // per 256 x 256 tile (a fifth of the tile, with or without the stores: profiles/r4_pp_cu_timeline.txt) on one
+    // LDS round trip and a chain of uniform branches per row group.
+    if (NWAVES <= 8 && EPI != EPI_I32 && !to_partial && !p.residual && !p.acc_float && __all(n_full)) {   // (16 waves: 128 registers, no room)
+        constexpr int ITERS = PASS_ROWS / ROWS_PER_IT;
+        constexpr int UNR = ITERS % 4 == 0 ? 4 : (ITERS % 2 == 0 ? 2 : 1);
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const bool has_bias = p.bias != nullptr, has_x0 = p.x0 != nullptr, has_x1 = p.x1 != nullptr;
+        v2f sw2[4], bs2[4], wz2[4], w12[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sw2[e] = v2f{swv[2 * e], swv[2 * e + 1]};
+            bs2[e] = v2f{bsv[2 * e], bsv[2 * e + 1]};
+            wz2[e] = v2f{wzv[2 * e], wzv[2 * e + 1]};
+            w12[e] = v2f{w1v[2 * e], w1v[2 * e + 1]};
+        }
+#pragma unroll
+        for (int pass = 0; pass < TM / PASS_MT; ++pass) {
+#pragma unroll
+            for (int jj = 0; jj < PASS_MT; ++jj)
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+                    *reinterpret_cast<v4i *>(slab + (jj * 16 + ml) * SLAB_LD + (i * 16 + nq) * 4) =
+                        acc[i][pass * PASS_MT + jj];
+            if (lane < PASS_ROWS) {
+                const long mr = m0 + (wm * TM + pass * PASS_MT) * 16 + lane;
+                float sxl = p.sx0, xzl = 0.0f, x1l = 0.0f;
+                if (mr < p.M) {
+                    if (p.sx_vec) sxl = p.sx_vec[mr];
+                    else if (p.row_sel && p.row_sel[mr]) sxl = p.sx1;
+                    if (p.x0) xzl = p.x0[mr];
+                    if (p.x1) x1l = p.x1[mr];
+                }
+                rowpar[lane * 4] = sxl;
+                rowpar[lane * 4 + 1] = xzl;
+                rowpar[lane * 4 + 2] = x1l;
+            }
+            asm volatile("" ::: "memory");          // the reads below follow the slab / parameter writes of THIS pass
+            const long mp = m0 + (wm * TM + pass * PASS_MT) * 16 + lrow;
+#pragma unroll
+            for (int t0 = 0; t0 < ITERS; t0 += UNR) {
+                v4i q0[UNR], q1[UNR];
+                float sxr[UNR], xzr[UNR], x1r[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int row = (t0 + u) * ROWS_PER_IT + lrow;
+                    q0[u] = *reinterpret_cast<const v4i *>(slab + row * SLAB_LD + c8 * 4);
+                    q1[u] = *reinterpret_cast<const v4i *>(slab + row * SLAB_LD + c8 * 4 + 16);
+                    sxr[u] = rowpar[row * 4];
+                    xzr[u] = rowpar[row * 4 + 1];
+                    x1r[u] = rowpar[row * 4 + 2];
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const long m = mp + (t0 + u) * ROWS_PER_IT;
+                    const int a[8] = {q0[u][0], q0[u][1], q0[u][2], q0[u][3], q1[u][0], q1[u][1], q1[u][2], q1[u][3]};
+                    // int4 weights: the accumulator carries a factor 16; float(16 a) * (s_x / 16) is the same real product
+                    // as float(a) * s_x (exact power-of-two rescale on both sides): same bits, no shift
+                    const float sxe = (W_BITS == 4) ? sxr[u] * 0.0625f : sxr[u];
+                    const v2f sx2 = v2f{sxe, sxe}, xz2 = v2f{xzr[u], xzr[u]}, x12 = v2f{x1r[u], x1r[u]};
+                    float y[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v2f v = v2f{(float)a[2 * e], (float)a[2 * e + 1]};
+                        v = v * sx2;
+                        v = v * sw2[e];
+                        if (has_bias) v = v + bs2[e];
+                        if (has_x0) {
+                            const v2f pr = xz2 * wz2[e];
+                            v = v + pr;
+                        }
+                        if (has_x1) {
+                            const v2f pr = x12 * w12[e];
+                            v = v + pr;
+                        }
+                        y[2 * e] = v[0];
+                        y[2 * e + 1] = v[1];
+                    }
+                    if (m >= p.M) continue;
+                    if (EPI == EPI_F32) {
+                        float *o = reinterpret_cast<float *>(p.out) + m * p.ldo + n;
+                        store_out(reinterpret_cast<v4f *>(o), v4f{y[0], y[1], y[2], y[3]});
+                        store_out(reinterpret_cast<v4f *>(o + 4), v4f{y[4], y[5], y[6], y[7]});
+                    } else {
+                        v4i h;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            h[e] = (int)((EPI == EPI_F16) ? pack2_f16(y[2 * e], y[2 * e + 1]) : pack2_bf16(y[2 * e], y[2 * e + 1]));
+                        store_out(reinterpret_cast<v4i *>(reinterpret_cast<unsigned short *>(p.out) + m * p.ldo + n), h);
+                    }
+                }
+            }
+        }
+        return;
+    }
+
 #pragma unroll
     for (int pass = 0; pass < TM / PASS_MT; ++pass) {
 #pragma unroll
@@ -291,6 +389,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][
             rowpar[lane * 4 + 1] = xzl;
             rowpar[lane * 4 + 2] = x1l;
         }
+        asm volatile("" ::: "memory");              // (the compiler must not move the reads below above these writes)
         // the slab is wave-private: LDS operations of one wave complete in order
 #pragma unroll 1
         for (int r0 = 0; r0 < PASS_ROWS; r0 += ROWS_PER_IT) {

@@ -416,11 +416,11 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
                 store_out(reinterpret_cast<v4f *>(o), v4f{y[0], y[1], y[2], y[3]});
                 store_out(reinterpret_cast<v4f *>(o + 4), v4f{y[4], y[5], y[6], y[7]});
             } else {
-                v8us h;
+                v4i h;
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    h[e] = (EPI == EPI_F16) ? f32_to_f16_bits(y[e]) : f32_to_bf16_bits(y[e]);
-                store_out(reinterpret_cast<v8us *>(reinterpret_cast<unsigned short *>(p.out) + m * p.ldo + n), h);
+                for (int e = 0; e < 4; ++e)
+                    h[e] = (int)((EPI == EPI_F16) ? pack2_f16(y[2 * e], y[2 * e + 1]) : pack2_bf16(y[2 * e], y[2 * e + 1]));
+                store_out(reinterpret_cast<v4i *>(reinterpret_cast<unsigned short *>(p.out) + m * p.ldo + n), h);
             }
         }
         return;

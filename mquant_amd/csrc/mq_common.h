@@ -73,6 +73,26 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f)
     return (unsigned short)(x >> 16);
 }
 
+// two fp32 -> two half-precision numbers in one dword (low half = a), round-to-nearest-even: V_CVT_PK_F16_F32 /
+// V_CVT_PK_BF16_F32 (gfx950).  The empty asm keeps the pair opaque (see f32_to_f16_bits: no fused multiply-convert).
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2_f16(float a, float b)
+{
+    typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+    v2f_t t = {a, b};
+    asm volatile("" : "+v"(t));
+    const v2h h = __builtin_convertvector(t, v2h);
+    return *reinterpret_cast<const unsigned *>(&h);
+}
+__device__ __forceinline__ unsigned pack2_bf16(float a, float b)
+{
+    typedef __bf16 v2b __attribute__((ext_vector_type(2)));
+    v2f_t t = {a, b};
+    asm volatile("" : "+v"(t));
+    const v2b h = __builtin_convertvector(t, v2b);
+    return *reinterpret_cast<const unsigned *>(&h);
+}
+
 template <int DT> struct Elem;
 template <> struct Elem<MQ_F16> {
     typedef unsigned short T;
