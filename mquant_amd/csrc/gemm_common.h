@@ -114,9 +114,9 @@ inline bool geometry_in_range(const GemmArgs &p)
 // every XCD one contiguous range of the order (split, m-group, n-block, m-block in group): the
 // m-blocks that share a weight panel (and, under split-K, the tiles of one k-slice) are consecutive on
 // ONE XCD, so a panel is fetched into one L2 once per m-group.
-__device__ __forceinline__ void tile_of_block(const GemmArgs &p, int &bm, int &bn, int &split)
+__device__ __forceinline__ void tile_of_id(const GemmArgs &p, unsigned total, unsigned b, int &bm, int &bn, int &split)
 {
-    const unsigned total = gridDim.x, b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const unsigned xcd = b & 7, idx = b >> 3;
     const unsigned q = total >> 3, r = total & 7;
     const unsigned wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     const unsigned t1 = p.mg == 1 ? wid : __umulhi(wid, p.mag_m);
@@ -126,6 +126,11 @@ __device__ __forceinline__ void tile_of_block(const GemmArgs &p, int &bm, int &b
     const unsigned sp = p.xm == 1 ? t2 : __umulhi(t2, p.mag_xm);
     split = (int)sp;
     bm = (int)((t2 - sp * p.xm) * p.mg + bm_in);
+}
+
+__device__ __forceinline__ void tile_of_block(const GemmArgs &p, int &bm, int &bn, int &split)
+{
+    tile_of_id(p, gridDim.x, blockIdx.x, bm, bn, split);
 }
 
 __device__ __forceinline__ void k_range_of_split(const GemmArgs &p, int split, int &k_begin, int &nk)

@@ -59,8 +59,13 @@ __global__ __launch_bounds__(512) void gemm_w4a8_pp_kernel(GemmArgs p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wn = wave & 3;                // waves w and w + 4 share a SIMD
 
+    // Persistent over the work ids: a launch with more tiles than CUs (gate|up: 444) starts 256 workgroups (a multiple of 8:
+    // id % 8 stays the workgroup's XCD, tile_of_id) and each walks ids b, b + 256, ...: a CU's second tile starts behind one
+    // barrier instead of a new workgroup's dispatch (5.3 k cycles between the two, profiles/r4_pp_cu_timeline.txt).
+    const unsigned total_ids = p.m_blocks * p.n_blocks * (unsigned)p.splits;
+    for (unsigned wid = blockIdx.x; wid < total_ids; wid += gridDim.x) {
     int bm, bn, split, sb, ns;
-    tile_of_block(p, bm, bn, split);
+    tile_of_id(p, total_ids, wid, bm, bn, split);
     k_range_of_split(p, split, sb, ns);                       // in steps of KT k-tiles
     const long m0 = (long)bm * BM;
     const long nt0 = (long)bn * (BN / 16);
@@ -209,6 +214,8 @@ __global__ __launch_bounds__(512) void gemm_w4a8_pp_kernel(GemmArgs p)
     }
 #endif
     gemm_epilogue<TM, TN, NWAVES, RING * SLOT, 4, EPI>(p, acc, smem, wave, lane, grp, wn, m0, nt0, split);
+    if (wid + gridDim.x < total_ids) __syncthreads();         // the slab of this tile is the ring of the next
+    }
 #undef MQ_PP_STEP
 #undef MQ_PP_BAR
 #undef MQ_PP_WAIT_CASE
@@ -226,7 +233,11 @@ static int launch_pp(const GemmArgs &p, hipStream_t st)
     GemmArgs g = p;
     set_geometry(g, BM, BN, 64 * KT, 4);
     if (!geometry_in_range(g)) return fail(MQ_EINVAL, "mq_gemm_w4a8: %u x %u x %d workgroups exceed the range of the launch-geometry arithmetic", g.m_blocks, g.n_blocks, g.splits);
-    hipLaunchKernelGGL(kern, dim3(g.m_blocks * g.n_blocks * (unsigned)g.splits), dim3(512), SMEM, st, g);
+    unsigned ids = g.m_blocks * g.n_blocks * (unsigned)g.splits;
+#ifndef MQ_PP_ONE_TILE_PER_WG
+    if (ids > 256) ids = 256;                                 // persistent: one workgroup per CU (150 KiB of LDS each)
+#endif
+    hipLaunchKernelGGL(kern, dim3(ids), dim3(512), SMEM, st, g);
     return check_launch("gemm_w4a8_pp");
 }
 
