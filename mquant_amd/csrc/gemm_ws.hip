@@ -248,8 +248,13 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
         constexpr int DS_PER_GAP = (N_DS + N_MFMA - 1) / N_MFMA, VALU_PER_GAP = (N_VALU + N_MFMA - 1) / N_MFMA;
         auto substep = [&](int sub, int slot2, int sub2) {       // (slot2, sub2): where sub-step s+2 lives
             __builtin_amdgcn_sched_barrier(0);
+#ifdef MQ_WS_XFIRST
             load_x((sub + 2) & 3, slot2, sub2);
             load_w((sub + 2) & 3, slot2, sub2);
+#else
+            load_w((sub + 2) & 3, slot2, sub2);          // the packed weights first: the unpack one sub-step later waits for THEM, and
+            load_x((sub + 2) & 3, slot2, sub2);          // LDS returns in order -- its wait then leaves the activation reads in flight
+#endif
             unpack((sub + 1) & 3, (sub + 1) & 1);
             mfmas(sub);
 #pragma unroll
