@@ -31,7 +31,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 n = len(rows)
 # calibration + 3 warm-up + 5 timed steps; a step has a fixed number of launches L: steady part = last 8 L launches (roughly); find L from the
 # positions of the rms_norm of the last position (unique per step): use the Hadamard down_proj kernel count instead (28 per step)
-idx = [i for i, r in enumerate(rows) if "hadamard_kernel" in r["Kernel_Name"] and int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]) == 768]
+idx = [i for i, r in enumerate(rows) if "hadamard_kernel" in r["Kernel_Name"] and ", 5>" in r["Kernel_Name"]]   # the decoder's down_proj rotation (5 x 2 units)
 per_step = 28
 last = idx[-5 * per_step]            # first down_proj Hadamard of the 5 timed steps
 # back up to the start of that step: the first kernel after the previous step's last launch -> approximate by the launch count of a step
