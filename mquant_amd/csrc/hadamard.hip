@@ -7,7 +7,7 @@
 //
 // One workgroup (4 waves) owns one activation row at a time, staged in LDS:
 //   A. butterflies in ascending stride, exactly the (a+b, a-b) order of the reference:
-//      strides 1,2,4 inside a lane's 8 registers, strides 8..256 with wavefront shuffles
+//      strides 1,2,4 inside a lane's 8 registers, strides 8..64 between lanes on the DPP network, 128 / 256 with wavefront shuffles
 //      (lane ^ stride/8), strides >= 512 through LDS; then * 1/sqrt(n) (fp32 scalar) and the
 //      cast to x's dtype that the FHT extension performs for half inputs.  In that mode the
 //      values ARE half-precision numbers, so the LDS copy is stored as 16-bit (half the
