@@ -319,6 +319,45 @@ def test_prepared_descriptor_against_the_oracle(had_table):
     np.testing.assert_array_equal(q.cpu().numpy()[:, :n], oracle.quant_static(rot, np.float32(0.05)))
 
 
+@pytest.mark.parametrize("n_in,n,K,M", [(18944, 19968, 156, 1300), (5120, 5120, 40, 2500), (11008, 11008, 172, 1100)])
+def test_row_loop_of_the_resident_hadamard_workgroups(had_table, n_in, n, K, M):
+    """The Hadamard launch starts only the resident workgroups (512 of eight waves, 1024 of four) and their row loop hands
+    out the rest: with more rows than that, every row must equal the same row computed in a launch of its own block of 64
+    rows (no loop there), in both output layouts."""
+    o = ops()
+    desc = o.hadamard_prepare(to_dev(had_table["words"][K]), K)
+    x = to_dev(make_x(M + K, (M, n_in)), torch.float16)
+    sel = to_dev((np.arange(M) % 3 == 1).astype(np.uint8))
+    full, x0 = o.hadamard_quant_i8(x, n, K, desc, 0.05, 0.021, row_sel=sel, skip_col0=True)
+    tiled, x0t = o.hadamard_quant_i8(x, n, K, desc, 0.05, 0.021, row_sel=sel, skip_col0=True, tiled=True)
+    assert torch.equal(tiled.to_rows(), full) and torch.equal(x0, x0t)
+    for r0 in (0, 448, 512, 960, M - 64):
+        part, x0p = o.hadamard_quant_i8(x[r0:r0 + 64], n, K, desc, 0.05, 0.021, row_sel=sel[r0:r0 + 64], skip_col0=True)
+        assert torch.equal(part, full[r0:r0 + 64]) and torch.equal(x0p, x0[r0:r0 + 64]), r0
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(768, 24576, 256, 14), (700, 33000, 384, 14), (512, 40960, 128, 19)])
+def test_persistent_ping_pong_launch_with_more_tiles_than_cus(M, N, K, tile):
+    """More work ids than CUs: the ping-pong kernel starts 256 workgroups that walk ids b, b + 256, ... (gemm_pp.hip); every
+    accumulator and the dequantised output must equal the wave-specialised kernel's (one workgroup per tile)."""
+    o = ops()
+    rng = np.random.default_rng(M + N + K)
+    a = to_dev(rng.integers(-128, 128, size=(M, K), dtype=np.int8))
+    w = to_dev(_levels(3, (N, K), 4))
+    s_w = to_dev(rng.uniform(0.001, 0.01, size=N).astype(np.float32))
+    bias = to_dev(rng.normal(size=N).astype(np.float32))
+    at, img = o.TiledAct.from_rows(a), o.prepack(w, 4)
+    try:
+        o.gemm_debug_force(40, 1)
+        acc_ref = o.gemm_w4a8_i32(at, img, 4, N)
+        y_ref = o.gemm_w4a8(at, img, 4, N, 0.02, s_w, bias=bias)
+        o.gemm_debug_force(tile, 1)
+        assert torch.equal(o.gemm_w4a8_i32(at, img, 4, N), acc_ref)
+        assert torch.equal(o.gemm_w4a8(at, img, 4, N, 0.02, s_w, bias=bias), y_ref)
+    finally:
+        o.gemm_debug_force(-1, 0)
+
+
 @pytest.mark.parametrize("M,N,K", [(768, 1100, 512), (1000, 300, 384)])
 def test_every_m_grouping_of_the_xcd_mapping_is_a_bijection(M, N, K):
     """tile_of_block with xm m-groups (gemm_common.h): forced through the debug hook (bits 8.. of
