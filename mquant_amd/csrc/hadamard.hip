@@ -316,6 +316,9 @@ __global__ __launch_bounds__(THREADS, HALF_LDS ? 4 : 1) void hadamard_kernel(Had
         const RowScale rs = row_scale(s);
 
         // ---------------- A: butterflies ------------------------------------------------
+        // four-wave rows (four resident per CU): the butterflies go ahead of the other rows' matrix phase (vis.fc2 16.9 -> 16.1 us;
+        // with eight-wave rows the same priority costs 4 %: profiles/r4_hadamard_cu_timeline.txt)
+        if (HAD_WAVES == 4) __builtin_amdgcn_s_setprio(3);
         if (m >= 8) {
             const long nchunks = ceil_div(n, 512);
             // chunks whose global loads are in flight together; the activation prologue holds two
@@ -358,6 +361,7 @@ __global__ __launch_bounds__(THREADS, HALF_LDS ? 4 : 1) void hadamard_kernel(Had
                     S::st((i < p.n_in) ? Elem<DT>::ld(xr[i]) : 0.0f);
             }
         }
+        if (HAD_WAVES == 4) __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         // (co-factors above 512 always stage in fp32: the register block below exists only in those instantiations and
         //  cannot raise the register count -- and lower the occupancy -- of the half-precision-staging kernels)
