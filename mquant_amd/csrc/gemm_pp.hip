@@ -59,8 +59,8 @@ __global__ __launch_bounds__(512) void gemm_w4a8_pp_kernel(GemmArgs p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wn = wave & 3;                // waves w and w + 4 share a SIMD
 
-    // Persistent over the work ids: a launch with more tiles than CUs (gate|up: 444) starts 256 workgroups (a multiple of 8:
-    // id % 8 stays the workgroup's XCD, tile_of_id) and each walks ids b, b + 256, ...: a CU's second tile starts behind one
+    // Persistent over the work ids: a launch with more tiles than CUs (gate|up: 444) starts one workgroup per CU (256: a multiple
+    // of 8, so id % 8 stays the workgroup's XCD, tile_of_id) and each walks ids b, b + gridDim, ...: a CU's second tile starts behind one
     // barrier instead of a new workgroup's dispatch (5.3 k cycles between the two, profiles/r4_pp_cu_timeline.txt).
     const unsigned total_ids = p.m_blocks * p.n_blocks * (unsigned)p.splits;
     for (unsigned wid = blockIdx.x; wid < total_ids; wid += gridDim.x) {
@@ -235,7 +235,8 @@ static int launch_pp(const GemmArgs &p, hipStream_t st)
     if (!geometry_in_range(g)) return fail(MQ_EINVAL, "mq_gemm_w4a8: %u x %u x %d workgroups exceed the range of the launch-geometry arithmetic", g.m_blocks, g.n_blocks, g.splits);
     unsigned ids = g.m_blocks * g.n_blocks * (unsigned)g.splits;
 #ifndef MQ_PP_ONE_TILE_PER_WG
-    if (ids > 256) ids = 256;                                 // persistent: one workgroup per CU (150 KiB of LDS each)
+    const unsigned cus = (unsigned)device_cu_count();         // persistent: one workgroup per CU (150 KiB of LDS each)
+    if (ids > cus) ids = cus;
 #endif
     hipLaunchKernelGGL(kern, dim3(ids), dim3(512), SMEM, st, g);
     return check_launch("gemm_w4a8_pp");

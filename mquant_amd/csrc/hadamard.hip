@@ -562,7 +562,7 @@ static int launch_hadamard_t(HadArgs p, hipStream_t st)
     if (HALF_LDS && per_cu > 16 / (THREADS / 64)) per_cu = 16 / (THREADS / 64);
 #endif
     if (per_cu < 1) per_cu = 1;
-    long blocks = 256L * per_cu;
+    long blocks = (long)device_cu_count() * per_cu;
     if (blocks > p.M) blocks = p.M;
     if (QUANT && p.ldq == MQ_LD_TILED) blocks = ceil_div(blocks, 8) * 8;   // XCD-consistent row map (tiled_row_of)
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), lds, st, p);

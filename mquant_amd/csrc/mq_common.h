@@ -16,6 +16,7 @@ char *last_error_buf();
 int fail(int code, const char *fmt, ...);
 int check_launch(const char *what);
 int ensure_dynamic_lds(const void *kernel, int bytes);   // per device, thread-safe (runtime.hip)
+int device_cu_count();                                   // CUs of the current device, cached per device (runtime.hip); 256 on an MI355X
 
 #define MQ_REQUIRE(cond, ...)                                   \
     do {                                                        \

@@ -56,6 +56,25 @@ int ensure_dynamic_lds(const void *kernel, int bytes)
     return MQ_OK;
 }
 
+// Persistent launches (gemm_pp, hadamard) size their grids by the CU count: rounded DOWN to a multiple of 8 (work ids are dealt
+// to the XCDs by id % 8), never below 8; a failed query answers 256 (MI355X).
+int device_cu_count()
+{
+    struct Entry { int dev; int cus; };
+    static std::mutex mu;
+    static std::vector<Entry> table;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto &t : table)
+        if (t.dev == dev) return t.cus;
+    int cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8) cus = prop.multiProcessorCount / 8 * 8;
+    table.push_back({dev, cus});
+    return cus;
+}
+
 }  // namespace mq
 
 extern "C" int mq_version(void) { return 100; }  // 0.1.0
