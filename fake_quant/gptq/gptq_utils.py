@@ -100,6 +100,10 @@ class GPTQ:
                 E1 = torch.empty((self.rows, i2 - i1), dtype=torch.float32, device=W.device)
                 self._block(W, i1, i2, Hrows, scale, qz.bits, Q, E1)
                 W[:, i2:] -= E1 @ Hinv[i1:i2, i2:]
+        # --w_groupsize: every group's (scale, zero point) is KEPT (the reference's quantizer remembers the last group only,
+        # gptq_utils.py:263-273); with contiguous groups -- no activation ordering -- they are what the integer backend needs
+        # (mq_gemm_w4a8_wgroupscale): quantizer.group_scales / group_zeros [rows, groups], quantizer.groupsize
+        group_scales, group_zeros = [], []
         for i1 in ([] if fused else range(0, self.columns, blocksize)):
             i2 = min(i1 + blocksize, self.columns)
             W1 = W[:, i1:i2].clone()
@@ -112,6 +116,8 @@ class GPTQ:
                     if not static_groups:
                         if (i1 + i) % groupsize == 0:
                             self.quantizer.find_params(W[:, (i1 + i):(i1 + i + groupsize)])
+                            group_scales.append(self.quantizer.scale.reshape(-1).float().clone())
+                            group_zeros.append(self.quantizer.zero.reshape(-1).float().clone())
                     else:
                         col = i1 + i
                         self.quantizer = groups[(int(perm[col]) if actorder else col) // groupsize]
@@ -122,6 +128,11 @@ class GPTQ:
                 E1[:, i] = err
             Q[:, i1:i2] = Q1
             W[:, i2:] -= E1 @ Hinv[i1:i2, i2:]
+        if groupsize != -1 and not static_groups:
+            qz.groupsize = int(groupsize)
+            qz.group_permuted = bool(actorder)          # groups of PERMUTED columns: no contiguous-k scale, simulated path only
+            qz.group_scales = None if actorder else torch.stack(group_scales, dim=1)
+            qz.group_zeros = None if actorder else torch.stack(group_zeros, dim=1)
         if actorder:
             Q = Q[:, invperm]
         self.layer.weight.data = Q.reshape(self.layer.weight.shape).to(self.layer.weight.data.dtype)

@@ -93,11 +93,11 @@ def gptq_group(block_call: Callable[[Sample], object], samples: Sequence[Sample]
         solver.fasterquant(percdamp=args.percdamp, groupsize=args.w_groupsize, actorder=args.act_order,
                            static_groups=False)
         quantizers[key(name)] = solver.quantizer
-        if args.w_groupsize == -1:
-            _attach(subset[name], solver.quantizer)
-        # with --w_groupsize > 0 fasterquant re-runs find_params per column group, so the quantizer left
-        # behind holds the LAST group's scales only: the wrapper must stay on the simulated path (the
-        # real-integer backend and the flat checkpoint assume one scale per output channel)
+        # with --w_groupsize > 0 fasterquant re-runs find_params per column group: ``scale`` holds the LAST group's as in the
+        # reference, every group's is kept in ``group_scales`` (gptq_utils.py here) and the wrapper runs
+        # mq_gemm_w4a8_wgroupscale.  With --act_order on top the groups are runs of PERMUTED columns: ``group_scales`` is None
+        # and the wrapper stays on the simulated path (ActQuantWrapper.extra_repr says which backend runs).
+        _attach(subset[name], solver.quantizer)
         solver.free()
 
 

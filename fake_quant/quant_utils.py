@@ -346,7 +346,85 @@ class ActQuantWrapper(torch.nn.Module):
                 return " (Static Per-Tensor%s)" % (", MSQ" if getattr(qz, "msq", False) else "")
             return " (Symmetric Per-Token)" if qz.sym else " (Asymmetric Per-Token)"
         return (f"Input Quantizer Bits: {self.quantizer.bits}{kind(self.quantizer)}\n"
-                f"Output Quantizer Bits: {self.out_quantizer.bits}{kind(self.out_quantizer)}")
+                f"Output Quantizer Bits: {self.out_quantizer.bits}{kind(self.out_quantizer)}\n"
+                f"Backend: {self.backend()}")
+
+    def backend(self) -> str:
+        """Which evaluation a quantized forward of this wrapper takes: the hand-written integer kernels ("W4A8 integer", with
+        the entry point family) or the reference's simulated torch ops -- and then why (a model that falls back must
+        say so; ``print(model)`` shows this line for every wrapper)."""
+        qz = self.quantizer
+        if qz.bits >= 16:
+            return "float (activation quantizer not configured)"
+        if getattr(self, "_real_frozen", False) and self._real is not None:
+            return "W%dA%d integer (engine from a flat checkpoint)" % (self._real.w_bits, 8)
+        why = self._simulated_because()
+        if why:
+            return "simulated (torch ops): " + why
+        name, _ = self._weight_module()
+        wq = self.weight_quantizers[name]
+        mode = "static" if qz.static else "dynamic"
+        if getattr(wq, "group_scales", None) is not None:
+            mode += ", weight groups of %d" % wq.groupsize
+        return "W%dA%d integer (%s)" % (wq.bits, qz.bits, mode)
+
+    def _simulated_because(self) -> str:
+        """'' when the integer backend can run this wrapper's configuration, else the first reason it cannot (dtype and
+        convolution-geometry checks that need the input are ``_real_ready``'s)."""
+        qz = self.quantizer
+        if not self.real_quant:
+            return "real_quant switched off"
+        if self.out_quantizer.bits < 16:
+            return "output quantizer configured"
+        if self.online_partial_had:
+            return "online partial Hadamard"
+        if qz.static:
+            if qz.bits != 8:
+                return "static activations other than int8"
+            if qz.calibrate or not qz.quant:
+                return "static quantizer not calibrated / not switched on (model_quant)"
+            if qz.quantizer.scale is None or qz.quantizer.scale.numel() != 1:
+                return "channel_wise static scales"
+        elif not self._dynamic_real_ok():
+            return "dynamic activation mode outside the kernels (bits, group size, split or asymmetric weights with groups)"
+        name, _ = self._weight_module()
+        wq = self.weight_quantizers.get(name)
+        if wq is None:
+            return "no weight quantizer attached (run the RTN / GPTQ pass of fake_quant.gptq)"
+        if wq.bits not in (4, 8):
+            return "weight bits %d" % wq.bits
+        w_asym = not getattr(wq, "sym", False)
+        a_asym = (not qz.static) and not getattr(qz, "sym", False)
+        if w_asym and not getattr(wq, "perchannel", False):
+            return "asymmetric per-tensor weights"
+        if int(bool(self.split)) + int(w_asym) + int(a_asym) > 2:
+            return "split column + asymmetric weights + asymmetric activations (two rank-1 epilogue slots)"
+        if getattr(wq, "groupsize", -1) and getattr(wq, "groupsize", -1) > 0:
+            return self._weight_groups_because(wq)
+        return ""
+
+    def _weight_groups_because(self, wq) -> str:
+        """--w_groupsize on the integer path (mq_gemm_w4a8_wgroupscale): contiguous groups of 64 or a multiple of 128 input
+        channels, symmetric levels, no split column; static, dynamic per-token symmetric or same-size group-wise activations."""
+        qz = self.quantizer
+        g = int(wq.groupsize)
+        if getattr(wq, "group_scales", None) is None:
+            return "weight groups over --act_order's permuted columns" if getattr(wq, "group_permuted", False) else "weight group scales not recorded"
+        if not getattr(wq, "sym", False):
+            return "asymmetric weights with --w_groupsize"
+        if self.split:
+            return "--w_groupsize with the split column"
+        _, wmod = self._weight_module()
+        width = wmod.weight.shape[1] if wmod.weight.dim() == 2 else 0
+        if not ((g == 64 or g % 128 == 0) and g <= 1024 and (g & (g - 1)) == 0 and width > 0 and width % g == 0):
+            return "weight group size %d (64 or a power of two from 128 to 1024 that divides the input width)" % g
+        if not qz.static:
+            ag = getattr(qz, "groupsize", -1)
+            if not getattr(qz, "sym", False) or getattr(qz, "act_per_tensor", False):
+                return "--w_groupsize with asymmetric or per-tensor dynamic activations"
+            if ag > 0 and ag != g:
+                return "--a_groupsize %d differs from --w_groupsize %d" % (ag, g)
+        return ""
 
     def register_forward_pre_hook(self, hook, *args, **kwargs):
         """The drivers pad ``down_proj`` inputs with a ``revise_down_input`` pre-hook.  That
@@ -393,29 +471,10 @@ class ActQuantWrapper(torch.nn.Module):
         qz = self.quantizer
         if getattr(self, "_real_frozen", False) and self._real is not None:
             return self.real_quant
-        if not self.real_quant or self.out_quantizer.bits < 16 or self.online_partial_had:
-            return False
-        if qz.static:
-            if not (qz.quant and not qz.calibrate) or qz.bits != 8:
-                return False
-        elif not self._dynamic_real_ok(x.dtype):
+        if qz.bits >= 16 or self._simulated_because():
             return False
         if x.dtype not in (torch.float16, torch.bfloat16, torch.float32):
             return False
-        name, _ = self._weight_module()
-        wq = self.weight_quantizers.get(name)
-        if wq is None or wq.bits not in (4, 8):
-            return False
-        # the epilogue has two rank-1 slots (mq_gemm_w4a8_rank2_ws): the split column, the zero points of asymmetric
-        # weights (--w_asym, per-channel only) and those of asymmetric dynamic activations (--a_asym) take one each
-        w_asym = not getattr(wq, "sym", False)
-        a_asym = (not qz.static) and not getattr(qz, "sym", False)
-        if w_asym and not getattr(wq, "perchannel", False):
-            return False
-        if int(bool(self.split)) + int(w_asym) + int(a_asym) > 2:
-            return False
-        if qz.static and (qz.quantizer.scale is None or qz.quantizer.scale.numel() != 1):
-            return False                                   # channel_wise scales: simulated path
         mod = self.module
         if isinstance(mod, torch.nn.Linear):
             return True
@@ -461,7 +520,18 @@ class ActQuantWrapper(torch.nn.Module):
         if scale.numel() == 1:
             scale = scale.expand(W2.shape[0]).contiguous()
         w_shift = None
-        if getattr(wq, "sym", False):
+        w_groups = None
+        if getattr(wq, "group_scales", None) is not None:
+            # --w_groupsize: one scale per (channel, group of g consecutive input channels); levels on each group's own grid
+            g = int(wq.groupsize)
+            gs = wq.group_scales.to(device=device, dtype=torch.float32)                  # [N, K / g]
+            assert gs.shape == (W2.shape[0], W2.shape[1] // g), "group scales do not match the weight"
+            half = 1 << (wq.bits - 1)
+            levels = torch.round(W2.float().reshape(W2.shape[0], -1, g) / gs[:, :, None]).clamp(-half, half - 1)
+            levels = levels.reshape(W2.shape).to(torch.int8)
+            w_groups = (gs.t().contiguous(), g)                                          # [K / g, N] as the kernel reads it
+            scale = gs.repeat_interleave(g, dim=1)                                       # per element, for the grid check below
+        elif getattr(wq, "sym", False):
             levels = ops.weight_levels(W2, scale, wq.bits)
         else:
             # W~ = s_w (q - z_w), q in 0 .. 2^b - 1: rint(W~ / s_w) = q - z_w; stored level = q - 2^(b-1)
@@ -478,8 +548,9 @@ class ActQuantWrapper(torch.nn.Module):
         # remembers its last column group)
         # (any weight is within half a step of SOME level, so the test is the MEAN distance: ~0.25 steps for
         # a foreign grid, at most a few 1e-2 for half-precision roundings of scale * level, 0 in fp32)
-        grid_w = levels.float() * scale[:, None] if w_shift is None else levels.float() * scale[:, None] + w_shift[:, None]
-        dev_steps = ((grid_w - W2.float()).abs() / scale[:, None]).mean()
+        sc2 = scale if scale.dim() == 2 else scale[:, None]
+        grid_w = levels.float() * sc2 if w_shift is None else levels.float() * sc2 + w_shift[:, None]
+        dev_steps = ((grid_w - W2.float()).abs() / sc2).mean()
         if float(dev_steps) > 0.12:
             raise RuntimeError(f"ActQuantWrapper: weights of '{name}' are not on the attached quantizer's grid "
                                f"(mean distance {float(dev_steps):.3g} quantization steps); refusing to build the integer backend")
@@ -508,16 +579,18 @@ class ActQuantWrapper(torch.nn.Module):
             dynamic = dict(bits=int(qz.bits), clip_ratio=float(qz.clip_ratio), sym=bool(qz.sym),
                            per_tensor=bool(qz.act_per_tensor),
                            groupsize=(int(qz.groupsize) if getattr(qz, "groupsize", -1) > 0 and not qz.act_per_tensor else -1))
+        if w_groups is not None:
+            scale = w_groups[0][-1].contiguous()                                         # (unused by the kernels; the last group's, as upstream keeps)
         return dict(levels=levels, scale=scale, bits=wq.bits,
                     bias=None if bias is None else bias.data.to(device), s0=s0, s1=s1,
-                    had=had, w0=w0, dynamic=dynamic, w_shift=w_shift, split_slice=split_slice)
+                    had=had, w0=w0, dynamic=dynamic, w_shift=w_shift, split_slice=split_slice, w_groups=w_groups)
 
     def _build_real(self, device):
         from mquant_amd.engine import W4A8Linear
         p = self._real_parts(device)
         self._real = W4A8Linear(p["levels"], p["scale"], p["bits"], p["bias"], p["s0"], p["s1"],
                                 had=p["had"], w0=p["w0"], dynamic=p["dynamic"], w_shift=p["w_shift"],
-                                split_slice=p["split_slice"])
+                                split_slice=p["split_slice"], w_groups=p["w_groups"])
         return self._real
 
     def _forward_real(self, x):
@@ -702,8 +775,13 @@ class SiblingGroup:
             parts.append(w._real_parts(rows.device))
         p0 = parts[0]
         if any(p["s0"] != p0["s0"] or p["s1"] != p0["s1"] or p["bits"] != p0["bits"] or p["dynamic"] is not None
-               or p["w_shift"] is not None or p["levels"].shape[1] != p0["levels"].shape[1] for p in parts):
+               or p["w_shift"] is not None or p["levels"].shape[1] != p0["levels"].shape[1]
+               or (p["w_groups"] is None) != (p0["w_groups"] is None)
+               or (p["w_groups"] is not None and p["w_groups"][1] != p0["w_groups"][1]) for p in parts):
             return False
+        w_groups = None
+        if p0["w_groups"] is not None:                      # --w_groupsize: the members' [groups, channels] scale tables side by side
+            w_groups = (torch.cat([p["w_groups"][0] for p in parts], dim=1).contiguous(), p0["w_groups"][1])
         bias = None
         if any(p["bias"] is not None for p in parts):
             bias = torch.cat([p["bias"].float() if p["bias"] is not None
@@ -713,7 +791,8 @@ class SiblingGroup:
             ends.append((n, n + p["levels"].shape[0]))
             n += p["levels"].shape[0]
         self.engine = W4A8Linear(torch.cat([p["levels"] for p in parts], dim=0),
-                                 torch.cat([p["scale"] for p in parts], dim=0), p0["bits"], bias, p0["s0"], p0["s1"])
+                                 torch.cat([p["scale"] for p in parts], dim=0), p0["bits"], bias, p0["s0"], p0["s1"],
+                                 w_groups=w_groups)
         self.offsets = ends
         return True
 

@@ -458,6 +458,20 @@ int mq_gemm_w4a8_groupscale_asym(const int8_t *a, long lda, const void *w, int w
                                  long n_groups, int group_k, const float *s_w, const float *bias, void *out,
                                  int out_dtype, long ldo, void *stream);
 
+/* The GEMM for group-wise WEIGHT scales (--w_groupsize g; reference fake_quant/gptq/gptq_utils.py:263-273: the GPTQ solver re-runs
+ * WeightQuantizer.find_params on every group of g consecutive input channels, so channel n carries one scale per group; flag at
+ * exam/quant_qwen2vl.py:327).  s_w_groups[g * N + n] = that scale.
+ *   y[m][n] = (sum_g ((float(acc_g[m][n]) * s_x_groups[m][g]) * s_w_groups[g][n])) * s_x(m) + bias[n]
+ * acc_g = the exact int32 sum over the group's k; groups added in ascending order in fp32 (one rounding per product and per sum);
+ * s_x(m) = s_x_rows[m] (dynamic per-token), or s_x1 where row_sel[m] else s_x0 (static, MSQ), or 1 when s_x_groups (group-wise
+ * activation scales of the SAME group size, quant_utils.py:181-203; NULL otherwise: the factor is then 1 inside the sum).
+ * Replaces F.linear on fake-quantized tensors (quant_utils.py:384): outputs agree with the reference to the 1e-3 of the other modes,
+ * the per-group accumulators are exact.  group_k: 64 or a multiple of 128; n_groups * group_k covers K_pad up to its zero padding. */
+int mq_gemm_w4a8_wgroupscale(const int8_t *a, long lda, const void *w, int w_bits, long M, long N, long K_pad,
+                             const float *s_w_groups, long n_groups, int group_k, float s_x0, float s_x1,
+                             const uint8_t *row_sel, const float *s_x_rows, const float *s_x_groups,
+                             const float *bias, void *out, int out_dtype, long ldo, void *stream);
+
 /* Scaled row sums of the int8 activation levels, for ASYMMETRIC weights (--w_asym; WeightQuantizer with
  * sym = False, quant_utils.py:446-509).  With the weight levels stored as q - 2^(b-1) the fake-quantized
  * weight is s_w[n] (stored + 2^(b-1) - z_w[n]); the zero points come back through the rank-1 epilogue term
@@ -475,6 +489,15 @@ int mq_act_rowsum_scaled(const int8_t *a, long lda, long M, long K_pad, float s_
 int mq_gemm_debug_force(int tile, int splits);
 /* TEST-ONLY: the plan (tile id, split-K factor) the dispatcher takes for a shape; host arithmetic only. */
 int mq_gemm_debug_plan(long M, long N, long K_pad, int w_bits, int a_tiled, int have_workspace, int *tile, int *splits);
+
+/* BENCH-ONLY, not part of the drop-in surface: the dense int8 matrix rate the device sustains under its package power limit.
+ * Register-only V_MFMA_I32_32X32X32_I8 (kind 0) / V_MFMA_I32_16X16X64_I8 (kind 1) chains, two waves per SIMD on every CU, no memory or
+ * LDS traffic; operands: 8 x 64 x 16 bytes on the device (four A and four B fragment register sets, rotated over the MFMAs --
+ * the caller supplies bytes with the statistics of its workload: the clock the part holds depends on them,
+ * profiles/r5_clock_reconciliation.txt).  Runs 3 + launches launches of iters x 16 (kind 0) / x 32 (kind 1) MFMAs per wave, times
+ * the last `launches` with HIP events on `stream` (blocking) and returns the achieved int8 ops per second.  sink: 4 bytes of
+ * device scratch.  bench.py reports the result as roofline.peak_sustained_measured beside the nominal peak. */
+int mq_bench_mfma_burn(int kind, const void *operands, int iters, int launches, int *sink, double *ops_per_s, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Min/max observer reduction.  Replaces the two reductions of

@@ -200,7 +200,7 @@ static int launch_act_quant(const void *x, long M, long K, long ldx, float scale
 #else
     const bool own_kernel = true;
 #endif
-    if (own_kernel && !DEQUANT && ldo == MQ_LD_TILED && !sv0 && vec_ok && K % 16 == 0 && (M + 15) / 16 <= 65535) {
+    if (own_kernel && !DEQUANT && ldo == MQ_LD_TILED && !sv0 && !sv1 && vec_ok && K % 16 == 0 && (M + 15) / 16 <= 65535) {
         constexpr int EPT = MQ_AQ_EPT;
         AqTiledArgs a{x, M, K, ldx, scale0, scale1, 1.0f / scale0, 1.0f / scale1, quant_rcp_ok(scale0), quant_rcp_ok(scale1),
                       row_sel, skip_col0, x0_out, (int8_t *)out, (int)(K_pad / 64)};

@@ -42,6 +42,10 @@ struct GemmArgs {
     // asymmetric groups: x~ = s_g a + shift_g with shift_groups[m * n_groups + g] = s_g (2^(b-1) - z_g); the constant part meets
     // the group's weight sum wsum_groups[g * N + n] = sum_{k in g} q_w[n][k] (as fp32): facc += shift_g * wsum_g
     const float *shift_groups = nullptr, *wsum_groups = nullptr;
+    // group-wise WEIGHT scales (--w_groupsize, reference gptq/gptq_utils.py:263-273): sw_groups[g * N + n] is the scale the GPTQ
+    // solver found for channel n on k-group g.  The grouped kernel multiplies a group's (row-scaled) sum by it before the fp32
+    // accumulation; the epilogue then applies the ROW scale (s_x per tensor / token-type / token) instead of s_w[n].
+    const float *sw_groups = nullptr;
     long n_groups = 0;
     int group_k = 0;
     int acc_float = 0;
@@ -248,7 +252,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][
     float swv[8], bsv[8], wzv[8], w1v[8];
     if (EPI != EPI_I32 && !to_partial) {
         if (n_full && p.par_ok) {
-            const v4f s0 = *reinterpret_cast<const v4f *>(p.s_w + n), s1 = *reinterpret_cast<const v4f *>(p.s_w + n + 4);
+            const v4f one4 = {1.f, 1.f, 1.f, 1.f};      // weight-group scales were applied group by group: x 1.0 is exact
+            const v4f s0 = p.sw_groups ? one4 : *reinterpret_cast<const v4f *>(p.s_w + n), s1 = p.sw_groups ? one4 : *reinterpret_cast<const v4f *>(p.s_w + n + 4);
             v4f b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0, z0 = b0, z1 = b0, u0 = b0, u1 = b0;
             if (p.bias) { b0 = *reinterpret_cast<const v4f *>(p.bias + n); b1 = *reinterpret_cast<const v4f *>(p.bias + n + 4); }
             if (p.w0) { z0 = *reinterpret_cast<const v4f *>(p.w0 + n); z1 = *reinterpret_cast<const v4f *>(p.w0 + n + 4); }
@@ -264,7 +269,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const long nn = (n + e < p.N) ? n + e : p.N - 1;
-                swv[e] = (n < p.N) ? p.s_w[nn] : 0.0f;
+                swv[e] = (n < p.N) ? (p.sw_groups ? 1.0f : p.s_w[nn]) : 0.0f;
                 bsv[e] = (p.bias && n < p.N) ? p.bias[nn] : 0.0f;
                 wzv[e] = (p.w0 && n < p.N) ? p.w0[nn] : 0.0f;
                 w1v[e] = (p.w1 && n < p.N) ? p.w1[nn] : 0.0f;
@@ -422,7 +427,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][
             }
             // int4 weights: the accumulator carries a factor 16; float(16 a) * (s_x / 16) is the same real
             // product as float(a) * s_x (exact power-of-two rescale on both sides): same bits, no shift
-            const float sx = p.acc_float ? 1.0f : ((W_BITS == 4) ? rowpar[row * 4] * 0.0625f : rowpar[row * 4]);
+            // float accumulators: activation-group scales (and the 1/16 of int4 levels) are already in; with weight-group scales
+            // the ROW scale is still due
+            const float sx = p.acc_float ? (p.sw_groups ? rowpar[row * 4] : 1.0f) : ((W_BITS == 4) ? rowpar[row * 4] * 0.0625f : rowpar[row * 4]);
             const float xz = rowpar[row * 4 + 1], x1r = rowpar[row * 4 + 2];
             float res[8];
             if (p.residual) {   // issued ahead of the arithmetic below
@@ -452,7 +459,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
                 v2f t = p.acc_float ? v2f{__int_as_float(a[e]), __int_as_float(a[e + 1])} : v2f{(float)a[e], (float)a[e + 1]};
-                if (!p.acc_float) t = t * sx2;
+                if (!p.acc_float || p.sw_groups) t = t * sx2;
                 t = t * v2f{swv[e], swv[e + 1]};
                 if (p.bias) t = t + v2f{bsv[e], bsv[e + 1]};
                 if (p.x0) {

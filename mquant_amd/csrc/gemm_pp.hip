@@ -20,7 +20,8 @@
 //     M(t): KT * TM * TN MFMA (V_MFMA_I32_16X16X64_I8)                                                         | barrier
 //
 // Slot safety: the slot of step t-1 is last read in L(t-1) of the lagging group; those reads are complete before
-// that group's barrier (the unpack waits for the W read, which is issued after the X reads; LDS returns in order),
+// that group's barrier -- an explicit s_waitcnt lgkmcnt(0) in front of it (it used to rest on hipcc keeping the X reads
+// ahead of the W reads the unpack waits for; the MFMAs behind the barrier need every operand anyway, so the wait is free) --
 // and the slot is refilled from L(t) of the leading group on -- the interval after that barrier.  Step t+1 is
 // complete in LDS for everybody after the barrier that ends L(t) of the lagging group; its first reader is L(t+1)
 // of the leading group, behind that barrier.
@@ -119,7 +120,10 @@ __global__ __launch_bounds__(512) void gemm_w4a8_pp_kernel(GemmArgs p)
     };
 
 #ifdef MQ_PP_STAMP
+    // stamp build (tools/gemm_kslope.py, tools/clock_recon.py): per work id 8 ints in the split-K workspace -- s_memtime ticks and
+    // s_memrealtime ticks (100 MHz, chip-wide) over the k-loop, the k-steps, realtime at loop start / after the epilogue, HW_ID, XCC_ID
     const unsigned long long stamp0 = __builtin_readcyclecounter();
+    const unsigned long long real0 = __builtin_amdgcn_s_memrealtime();
 #endif
     v4i acc[TN][TM];
 #pragma unroll
@@ -186,6 +190,7 @@ __global__ __launch_bounds__(512) void gemm_w4a8_pp_kernel(GemmArgs p)
                 wait_younger(last - (t + 1));                                                   \
             }                                                                                   \
         }                                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* every fragment read of L(t) has returned */ \
         MQ_PP_BAR();                                                                            \
         if (!(MQ_PP_ABL & 8)) {                                                                 \
             __builtin_amdgcn_s_setprio(1);                                                      \
@@ -207,13 +212,25 @@ __global__ __launch_bounds__(512) void gemm_w4a8_pp_kernel(GemmArgs p)
 #ifdef MQ_PP_STAMP
     {
         const unsigned long long stamp1 = __builtin_readcyclecounter();
+        const unsigned long long real1 = __builtin_amdgcn_s_memrealtime();
         if (tid == 0 && p.partial && p.splits == 1) {
-            p.partial[blockIdx.x * 2] = (int)(stamp1 - stamp0);
-            p.partial[blockIdx.x * 2 + 1] = ns;
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            int *o = p.partial + (long)wid * 8;
+            o[0] = (int)(stamp1 - stamp0);
+            o[1] = ns;
+            o[2] = (int)(real1 - real0);
+            o[3] = (int)real0;
+            o[5] = (int)hw;
+            o[6] = (int)xcc;
         }
     }
 #endif
     gemm_epilogue<TM, TN, NWAVES, RING * SLOT, 4, EPI>(p, acc, smem, wave, lane, grp, wn, m0, nt0, split);
+#ifdef MQ_PP_STAMP
+    if (tid == 0 && p.partial && p.splits == 1) p.partial[(long)wid * 8 + 4] = (int)__builtin_amdgcn_s_memrealtime();
+#endif
     if (wid + gridDim.x < total_ids) __syncthreads();         // the slab of this tile is the ring of the next
     }
 #undef MQ_PP_STEP

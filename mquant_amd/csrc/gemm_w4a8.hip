@@ -128,23 +128,31 @@ __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmAr
         }
     // D layout: column (lane & 15) = activation row, so a lane needs ONE group scale per row tile
     auto fold_group = [&](long gi) {
-        if (gi >= p.n_groups) gi = p.n_groups - 1;         // zero-padded tail of K_pad: the accumulators are 0 there
+        // Zero-padded tail of K_pad (group_k = 64 and K % 128 == 64): the accumulators are 0 there, so the scaled sum adds
+        // nothing -- but the asymmetric constant term is NOT an accumulator product and must not be added a second time
+        // for the last real group (advisor finding r4: K = 192 -> K_pad = 256, 3 groups, 4 k-tiles).
+        const bool tail = gi >= p.n_groups;
+        if (tail) gi = p.n_groups - 1;
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
             long row = m0 + (wm * TM + j) * 16 + (lane & 15);
             if (row >= p.M) row = p.M - 1;
-            float sg = p.sx_groups[row * p.n_groups + gi];
+            float sg = p.sx_groups ? p.sx_groups[row * p.n_groups + gi] : 1.0f;   // (weight groups alone: the row scale waits in the epilogue)
             if (W_BITS == 4) sg = sg * 0.0625f;                // the int4 levels sit in the high nibble: exact rescale
-            const float sh = p.shift_groups ? p.shift_groups[row * p.n_groups + gi] : 0.0f;
+            const float sh = (p.shift_groups && !tail) ? p.shift_groups[row * p.n_groups + gi] : 0.0f;
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
                 // D layout: register r of the tile = channel 16 (nt0 + wn TN + i) + 4 (lane >> 4) + r
                 const long nb = (nt0 + wn * TN + i) * 16 + (lane >> 4) * 4;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float t = (float)acc[i][j][r] * sg;
+                    float t = (float)acc[i][j][r] * sg;
+                    if (p.sw_groups) {                         // weight-group scale of (group, channel): one more rounding
+                        const long nn = nb + r < p.N ? nb + r : p.N - 1;
+                        t = t * p.sw_groups[gi * p.N + nn];
+                    }
                     float f = facc[GROUPED ? i : 0][GROUPED ? j : 0][r] + t;
-                    if (p.shift_groups) {                      // asymmetric groups: the constant part of the group's levels
+                    if (p.shift_groups && !tail) {             // asymmetric groups: the constant part of the group's levels
                         const long nn = nb + r < p.N ? nb + r : p.N - 1;
                         const float u = sh * p.wsum_groups[gi * p.N + nn];
                         f = f + u;
@@ -502,9 +510,18 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
     if (a_tiled) {
         // wave-specialised kernels (gemm_ws.hip), every operand byte arrives as contiguous KiB pieces:
         // the bytes the busiest CU has to pull decide, ceil(tiles/256) x (BM + BN/2) per unit of K
+        // (round 5: the V_MFMA_I32_16X16X64_I8 twins of the round-2 tiles, ids 47 / 48 / 45 / 46 for 64 / 96 / 128 / 192 x 128 -- bit-identical
+        //  results, 1-7 % faster per shape on one box: the 16x16x64 form does the same MACs with half the accumulator register traffic and
+        //  the launches run at the package power limit, profiles/r5_ws_tiles_ab.txt; -DMQ_PLAN_WS_32X32 restores ids 43 / 40 / 41 / 42)
+#ifdef MQ_PLAN_WS_32X32
         static const int cand[][3] = {{43, 64, 128}, {40, 96, 128}, {41, 128, 128}, {42, 192, 128}};
+        constexpr int WS192 = 42;
+#else
+        static const int cand[][3] = {{47, 64, 128}, {48, 96, 128}, {45, 128, 128}, {46, 192, 128}};
+        constexpr int WS192 = 46;
+#endif
         for (const auto &c : cand) {
-            if (c[0] == 42 && !w4) continue;
+            if (c[0] == WS192 && !w4) continue;
             const long tiles = ceil_div(M, c[1]) * ceil_div(N, c[2]);
             const long cost = ceil_div(tiles, 256) * (c[1] + (w4 ? c[2] / 2 : c[2]));
             if (best < 0 || cost < best) { best = cost; pl.tile = c[0]; }
@@ -534,7 +551,11 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
             auto rounds = [](long tiles) { const long f = tiles / 256, r = tiles % 256; return (float)f + (r ? 0.8f + 0.2f * (float)r / 256.0f : 0.0f); };
             const float t_pipe = rounds(t256) * (4.0f + 1.65f * (float)kps);
             const float t_192 = rounds(ceil_div(M, 192) * ceil_div(N, 128)) * (7.8f + 0.55f * (float)kps);
+#ifdef MQ_PLAN_WS_32X32
             if (t_192 < t_pipe) pl.tile = 42;
+#else
+            if (t_192 < t_pipe) pl.tile = 46;
+#endif
         }
     } else if (a_tiled && best >= 0 && ceil_div(M, 96) * ceil_div(N, 128) >= 128) {
         // enough 96..192 x 128 tiles for most CUs: the wave-specialised kernel walks the whole reduction
@@ -610,7 +631,7 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
                        void *stream, const float *sx_vec = nullptr, const void *residual = nullptr,
                        long ldr = 0, const float *sx_groups = nullptr, long n_groups = 0, int group_k = 0,
                        const float *x1 = nullptr, const float *w1 = nullptr, const float *shift_groups = nullptr,
-                       const float *wsum_groups = nullptr)
+                       const float *wsum_groups = nullptr, const float *sw_groups = nullptr)
 {
     MQ_REQUIRE(M >= 0 && N >= 0 && K_pad >= 0, "mq_gemm_w4a8: negative shape");
     if (M == 0 || N == 0) return MQ_OK;
@@ -622,7 +643,7 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
     MQ_REQUIRE(((uintptr_t)w) % 16 == 0, "mq_gemm_w4a8: weight image must be 16-byte aligned");
     MQ_REQUIRE(w_bits == 4 || w_bits == 8, "mq_gemm_w4a8: w_bits must be 4 or 8");
     MQ_REQUIRE(ldo >= N, "mq_gemm_w4a8: ldo < N");
-    MQ_REQUIRE(epi == EPI_I32 || s_w, "mq_gemm_w4a8: s_w is required");
+    MQ_REQUIRE(epi == EPI_I32 || s_w || sw_groups, "mq_gemm_w4a8: s_w is required");
     MQ_REQUIRE((x0 == nullptr) == (w0 == nullptr), "mq_gemm_w4a8: x0 and w0 go together");
     MQ_REQUIRE((x1 == nullptr) == (w1 == nullptr) && (x1 == nullptr || epi != EPI_I32), "mq_gemm_w4a8: x1 and w1 go together (floating-point outputs)");
     // int32 headroom: |acc| <= K * 128 * 8 * 16 (int4 in the high nibble) or K * 128 * 128
@@ -639,12 +660,13 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
     MQ_REQUIRE(!residual || (epi != EPI_I32 && ldr >= N), "mq_gemm_w4a8: bad residual geometry");
     p.res_vec = residual && (((uintptr_t)residual) % 16 == 0) && ((ldr * ((epi == EPI_F32) ? 4 : 2)) % 16 == 0);
     p.out = out; p.ldo = ldo;
-    if (sx_groups) {
-        // group-wise activation scales: the symmetric 128 x 128 kernel, no split-K, floating-point outputs only
-        MQ_REQUIRE(epi != EPI_I32 && group_k > 0 && (group_k == 64 || group_k % 128 == 0) && K_pad % 64 == 0 && !sx_vec && !x1,
+    if (sx_groups || sw_groups) {
+        // group-wise activation and / or weight scales: the symmetric 128 x 128 kernel, no split-K, floating-point outputs only
+        MQ_REQUIRE(epi != EPI_I32 && group_k > 0 && (group_k == 64 || group_k % 128 == 0) && K_pad % 64 == 0 && !x1 && (!sx_vec || (sw_groups && !sx_groups)),
                    "mq_gemm_w4a8_groupscale: group size %d (64 or a multiple of 128)", group_k);
         MQ_REQUIRE((shift_groups == nullptr) == (wsum_groups == nullptr), "mq_gemm_w4a8_groupscale: shift_groups and wsum_groups go together");
-        p.sx_groups = sx_groups; p.n_groups = n_groups; p.group_k = group_k; p.acc_float = 1;
+        MQ_REQUIRE(!(sw_groups && shift_groups), "mq_gemm_w4a8_wgroupscale: asymmetric activation groups are not combined with weight groups");
+        p.sx_groups = sx_groups; p.sw_groups = sw_groups; p.n_groups = n_groups; p.group_k = group_k; p.acc_float = 1;
         p.shift_groups = shift_groups; p.wsum_groups = wsum_groups;
         p.splits = 1; p.partial = nullptr;
         p.vec_ok = (N % 8 == 0) && (ldo % 8 == 0) && (((uintptr_t)out) % 16 == 0);
@@ -800,6 +822,25 @@ extern "C" int mq_gemm_w4a8_groupscale_asym(const int8_t *a, long lda, const voi
     return mq::gemm_common(a, lda, w, w_bits, M, N, K_pad, 1.0f, 1.0f, nullptr, s_w, bias, nullptr, nullptr,
                            out, out_dtype, ldo, nullptr, 0, stream, nullptr, nullptr, 0, s_x_groups, n_groups, group_k,
                            nullptr, nullptr, shift_groups, wsum_groups);
+}
+
+extern "C" int mq_gemm_w4a8_wgroupscale(const int8_t *a, long lda, const void *w, int w_bits, long M, long N, long K_pad,
+                                        const float *s_w_groups, long n_groups, int group_k, float s_x0, float s_x1,
+                                        const uint8_t *row_sel, const float *s_x_rows, const float *s_x_groups,
+                                        const float *bias, void *out, int out_dtype, long ldo, void *stream)
+{
+    if (out_dtype != MQ_F16 && out_dtype != MQ_BF16 && out_dtype != MQ_F32)
+        return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_wgroupscale: unknown output dtype %d", out_dtype);
+    if (M == 0 || N == 0) return MQ_OK;
+    if (!s_w_groups || n_groups <= 0) return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_wgroupscale: s_w_groups is required");
+    if ((long)group_k * n_groups > K_pad || (long)group_k * n_groups + 127 < K_pad)
+        return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_wgroupscale: %ld groups of %d do not cover K_pad=%ld", n_groups, group_k, K_pad);
+    if (s_x_groups && (s_x_rows || row_sel))
+        return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_wgroupscale: group-wise activation scales exclude per-row / per-token-type scales");
+    const bool unit = s_x_groups || s_x_rows;           // the row scale is elsewhere: x 1.0 in the epilogue is exact
+    return mq::gemm_common(a, lda, w, w_bits, M, N, K_pad, unit ? 1.0f : s_x0, unit ? 1.0f : s_x1, unit ? nullptr : row_sel, nullptr, bias,
+                           nullptr, nullptr, out, out_dtype, ldo, nullptr, 0, stream, s_x_groups ? nullptr : s_x_rows, nullptr, 0,
+                           s_x_groups, n_groups, group_k, nullptr, nullptr, nullptr, nullptr, s_w_groups);
 }
 
 extern "C" int mq_gemm_w4a8_i32(const int8_t *a, long lda, const void *w, int w_bits, long M,

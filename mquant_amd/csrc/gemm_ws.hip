@@ -26,7 +26,11 @@
 
 namespace mq {
 
-template <int BM, int BN, int MW_M, int MW_N, int NL, int S, int W_BITS, int EPI>
+// MF: matrix instruction of the math waves -- 0: V_MFMA_I32_32X32X32_I8 (rounds 2-4), 1: V_MFMA_I32_16X16X64_I8 (round 5: under the
+// package power limit the 16x16x64 form sustains 15 % more int8 ops per watt on random operands, 3.82 against 3.32 POP/s in the
+// register-only burn of tools/probes/clock_recon.hip; its accumulator tile is a quarter of the 32x32 one, half the accumulator
+// register traffic per MAC).
+template <int BM, int BN, int MW_M, int MW_N, int NL, int S, int W_BITS, int EPI, int MF = 0>
 __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmArgs p)
 {
     // Math waves: MW_M x MW_N wave tiles of (BM / MW_M) x (BN / MW_N), one or two per SIMD.  (A second group of
@@ -44,7 +48,7 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
     constexpr int STAGE = PIECES * 1024;
     constexpr int RING = S * STAGE;
     constexpr int PITCH = BN * 4 + 16;              // epilogue slab row pitch (bytes)
-    static_assert(BM % (MW_M * 32) == 0 && BN % (MW_N * 32) == 0, "tile shape");
+    static_assert(MF == 1 ? (BM % (MW_M * 16) == 0 && BN % (MW_N * 16) == 0) : (BM % (MW_M * 32) == 0 && BN % (MW_N * 32) == 0), "tile shape");
     static_assert(PIECES % NL == 0, "pieces must divide over the loader waves");
     static_assert(S >= 4 && S <= 8 && (S - 2) * LPW < 64, "ring depth (vmcnt is 6 bits)");
     constexpr int BODY = RING > BM * PITCH ? RING : BM * PITCH;   // the epilogue slab reuses the ring (and may exceed it)
@@ -62,6 +66,27 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef MQ_WS_TL
+    // Timeline build (tools/gemm_timeline.py, profiles/r5_ws_fixed_cost_timeline.txt): 16 ints per workgroup in the
+    // split-K workspace -- s_memtime at entry / first stage requested / first stage landed / B(0) / loop end / slab
+    // parked / last store issued / stores drained, s_memrealtime (100 MHz, chip-wide) at entry and end, HW_ID, XCC_ID.
+    int *tl = (p.partial && p.splits == 1) ? p.partial + (long)blockIdx.x * 16 : nullptr;
+#define MQ_TL(who, i)                                                          \
+    do {                                                                       \
+        if (tl && tid == (who)) tl[i] = (int)__builtin_amdgcn_s_memtime();      \
+    } while (0)
+    if (tl && tid == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        tl[0] = (int)__builtin_amdgcn_s_memtime();
+        tl[1] = (int)__builtin_amdgcn_s_memrealtime();
+        tl[2] = (int)hw;
+        tl[3] = (int)xcc;
+    }
+#else
+#define MQ_TL(who, i) do { } while (0)
+#endif
 
     // ---- workgroup -> (split, bn, bm), XCD-aware and bijective (gemm_common.h) ---------------------
     int bm, bn, split, kb, nk;
@@ -77,8 +102,10 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
     // a dependent MFMA chain only three or four instructions long and every VALU / LDS instruction
     // between two sub-steps would add to it (tools/probes/math_loop.hip: 520 -> 760 cycles per k-step);
     // even and odd sub-steps therefore accumulate into separate sets, added at the end (integers: exact).
-    constexpr int NACC = (TM * TN < 6) ? 2 : 1;
-    v16i acc[NACC][TN][TM];
+    constexpr int NACC = (MF == 1) ? 1 : ((TM * TN < 6) ? 2 : 1);
+    v16i acc[MF == 1 ? 1 : NACC][MF == 1 ? 1 : TN][MF == 1 ? 1 : TM];
+    constexpr int TM16 = BM / MW_M / 16, TN16 = BN / MW_N / 16;    // MF == 1: 16-row / 16-channel fragments per math wave
+    v4i acc16[MF == 1 ? TN16 : 1][MF == 1 ? TM16 : 1];
 
     if (wave >= NM) {
         // =========================== loader waves ===========================================
@@ -137,7 +164,13 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
 #pragma unroll
         for (int s = 0; s < PRE0; ++s)
             if (s < pre0) issue(s, s);
+#ifdef MQ_WS_TL
+        const int tl_req = (int)__builtin_amdgcn_s_memtime();       // first stages requested (kept in registers: a store
+#endif                                                              // here would sit in the counted vmcnt of the ring)
         wait_younger(pre0 - 1);                      // stage 0 landed
+#ifdef MQ_WS_TL
+        const int tl_land = (int)__builtin_amdgcn_s_memtime();
+#endif
         __builtin_amdgcn_s_barrier();                // B(0)
         int last = pre0 - 1;                         // last stage issued
         int slot = pre0 == S ? 0 : pre0;             // slot of stage last + 1
@@ -158,6 +191,12 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
             }
         }
         __builtin_amdgcn_s_setprio(0);
+#ifdef MQ_WS_TL
+        if (tl && tid == NM * 64) {
+            tl[4] = tl_req;
+            tl[5] = tl_land;
+        }
+#endif
     } else {
         // =========================== math waves =============================================
         const int wm = wave / MW_N, wn = wave % MW_N;
@@ -178,6 +217,94 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
             pr_x1 = (p.x1 ? p.x1 : p.s_w)[p.x1 ? mc : 0];
             pr_rs = (p.row_sel ? p.row_sel : reinterpret_cast<const uint8_t *>(p.s_w))[p.row_sel ? mc : 0];
         }
+        if constexpr (MF == 1) {
+            // ---- V_MFMA_I32_16X16X64_I8: one interval per 64-wide k-tile t (two per stage, so every register-set index below
+            // is a compile-time parity):   X[(t+1)&1] <- activations (t+1)   |  F[t&1] <- packed weights (t+2)
+            //                               WU[(t+1)&1] <- unpack F[(t+1)&1] (= weights t+1, requested one interval ago)
+            //                               TM16 x TN16 MFMAs on WU[t&1], X[t&1]
+            // The LDS image is already in this instruction's fragment order (a 1 KiB piece = 16 rows x 64 k, lane l at byte 16 l).
+#pragma unroll
+            for (int i = 0; i < TN16; ++i)
+#pragma unroll
+                for (int j = 0; j < TM16; ++j) acc16[i][j] = v4i{0, 0, 0, 0};
+            v4i X[2][TM16], WU[2][TN16], F[2][TN16];       // F: W4 uses the first two words
+            auto rd_x = [&](int set, int slot, int kt) {
+                const char *xs = smem + slot * STAGE + kt * 1024 + lane * 16;
+#pragma unroll
+                for (int j = 0; j < TM16; ++j) X[set][j] = *reinterpret_cast<const v4i *>(xs + (wm * TM16 + j) * 2048);
+            };
+            auto rd_w = [&](int set, int slot, int kt) {
+                const char *ws = smem + slot * STAGE + A_BYTES + kt * 1024 + lane * 16;
+#pragma unroll
+                for (int i = 0; i < TN16; ++i) {
+                    const int nt = wn * TN16 + i;
+                    if (W_BITS == 4) {
+                        const v2i pk = *reinterpret_cast<const v2i *>(ws + (nt >> 1) * 2048 + (nt & 1) * 8);
+                        F[set][i][0] = pk[0];
+                        F[set][i][1] = pk[1];
+                    } else {
+                        F[set][i] = *reinterpret_cast<const v4i *>(ws + nt * 2048);
+                    }
+                }
+            };
+            auto unpack16 = [&](int set) {
+#pragma unroll
+                for (int i = 0; i < TN16; ++i) {
+                    if (W_BITS == 4) {
+                        const int lo = F[set][i][0], hi = F[set][i][1];
+                        WU[set][i][0] = (lo << 4) & 0xF0F0F0F0;
+                        WU[set][i][1] = lo & 0xF0F0F0F0;
+                        WU[set][i][2] = (hi << 4) & 0xF0F0F0F0;
+                        WU[set][i][3] = hi & 0xF0F0F0F0;
+                    } else {
+                        WU[set][i] = F[set][i];
+                    }
+                }
+            };
+            // Issue order inside an interval: one fragment read and one share of the nibble unpack per MFMA gap.  The packed-weight
+            // read goes out FIRST (LDS returns in order: the unpack of the NEXT interval then waits for the oldest read only, a
+            // whole interval old), the activation reads behind it in the order the next interval's MFMAs consume them.
+            constexpr int N_MFMA = TM16 * TN16;
+            constexpr int N_DS = TM16 + ((W_BITS == 4) ? (TN16 + 1) / 2 : TN16);    // hipcc merges the two 8-byte reads of a channel-tile pair
+            constexpr int N_VALU = (W_BITS == 4) ? 6 * TN16 : 0;
+            constexpr int DS_PER_GAP = (N_DS + N_MFMA - 1) / N_MFMA, VALU_PER_GAP = (N_VALU + N_MFMA - 1) / N_MFMA;
+            // interval of k-tile (parity par): slotx / ktx = where activations t+1 live, slotw / ktw = where weights t+2 live
+            auto interval = [&](int par, int slotx, int ktx, int slotw, int ktw) {
+                __builtin_amdgcn_sched_barrier(0);
+                rd_w(par, slotw, ktw);
+                rd_x(par ^ 1, slotx, ktx);
+                unpack16(par ^ 1);                           // weights t+1 (requested during the previous interval)
+#pragma unroll
+                for (int i = 0; i < TN16; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM16; ++j)
+                        acc16[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(WU[par][i], X[par][j], acc16[i][j], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < N_MFMA; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // MFMA
+                    if (N_VALU) __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_GAP, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, DS_PER_GAP, 0);        // DS reads
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            __builtin_amdgcn_s_barrier();            // B(0): stage 0 landed
+            MQ_TL(0, 6);
+            rd_w(0, 0, 0);
+            rd_x(0, 0, 0);
+            rd_w(1, 0, 1);
+            unpack16(0);
+            int cur = 0;
+            for (int it = 0; it < nk; ++it) {
+                __builtin_amdgcn_s_barrier();        // B(it+1): stage it+1 landed
+                int nxt = cur + 1;
+                if (nxt == S) nxt = 0;
+                if (it + 1 >= nk) nxt = cur;         // last step: harmless re-reads of a live slot
+                interval(0, cur, 1, nxt, 0);         // k-tile 2 it:     activations 2 it + 1 (this stage), weights 2 it + 2 (next stage)
+                interval(1, nxt, 0, nxt, 1);         // k-tile 2 it + 1: activations 2 it + 2,              weights 2 it + 3
+                cur = nxt;
+            }
+            MQ_TL(0, 7);                             // k-loop done
+        } else {
 #pragma unroll
         for (int a = 0; a < NACC; ++a)
 #pragma unroll
@@ -266,6 +393,7 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
             __builtin_amdgcn_sched_barrier(0);
         };
         __builtin_amdgcn_s_barrier();                // B(0): stage 0 landed
+        MQ_TL(0, 6);
 #ifdef MQ_WS_STAMP
         const unsigned long long stamp0 = __builtin_readcyclecounter();
 #endif
@@ -286,6 +414,7 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
             substep(3, nxt, 1);
             cur = nxt;
         }
+        MQ_TL(0, 7);                                 // k-loop done
 #ifdef MQ_WS_STAMP
         {
             const unsigned long long stamp1 = __builtin_readcyclecounter();
@@ -300,6 +429,7 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
             for (int i = 0; i < TN; ++i)
 #pragma unroll
                 for (int j = 0; j < TM; ++j) acc[0][i][j] += acc[1][i][j];
+        }
         }
         if (EPI != EPI_I32) {                        // the parameter block sits behind the ring
             if (tid < BN) {
@@ -329,7 +459,17 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
         // D layout of the 32x32 form: column (-> row m) = lane & 31, rows (-> channels) 8 q + 4 (lane >> 5) + e
         const int wm = wave / MW_N, wn = wave % MW_N;
         const int ml = lane & 31, nh = (lane >> 5) * 4;
-        if (wave < NM) {
+        if (MF == 1) {
+            // D layout of the 16x16 form: column (-> row m) = lane & 15, rows (-> channels) 4 (lane >> 4) + r
+            if (wave < NM) {
+#pragma unroll
+                for (int j = 0; j < TM16; ++j)
+#pragma unroll
+                    for (int i = 0; i < TN16; ++i)
+                        *reinterpret_cast<v4i *>(smem + ((wm * TM16 + j) * 16 + (lane & 15)) * PITCH + ((wn * TN16 + i) * 16 + (lane >> 4) * 4) * 4) =
+                            acc16[i][j];
+            }
+        } else if (wave < NM) {
 #pragma unroll
             for (int j = 0; j < TM; ++j)
 #pragma unroll
@@ -341,6 +481,7 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
         }
     }
     __syncthreads();
+    MQ_TL(0, 8);                                     // slab parked
 
     constexpr int LPR = BN / 8;                      // lanes per output row (8 channels per lane)
     constexpr int RPI = NT / LPR;                    // rows per iteration of the whole workgroup
@@ -428,6 +569,17 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
                 store_out(reinterpret_cast<v4i *>(reinterpret_cast<unsigned short *>(p.out) + m * p.ldo + n), h);
             }
         }
+#ifdef MQ_WS_TL
+        MQ_TL(0, 9);                                 // last store issued (wave 0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MQ_TL(0, 10);                                // wave 0's stores acknowledged
+        __syncthreads();
+        if (tl && tid == 0) {
+            tl[11] = (int)__builtin_amdgcn_s_memtime();  // every wave's stores acknowledged
+            tl[12] = (int)__builtin_amdgcn_s_memrealtime();
+            tl[13] = nk;
+        }
+#endif
         return;
     }
 #pragma unroll 1
@@ -523,14 +675,14 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
     }
 }
 
-template <int BM, int BN, int MW_M, int MW_N, int NL, int S, int W_BITS, int EPI>
+template <int BM, int BN, int MW_M, int MW_N, int NL, int S, int W_BITS, int EPI, int MF = 0>
 static int launch_ws(const GemmArgs &p, hipStream_t st)
 {
     constexpr int PIECES = (BM / 16) * 2 + ((W_BITS == 4) ? (BN / 32) * 2 : (BN / 16) * 2);
     constexpr int RING = S * PIECES * 1024, SLAB = BM * (BN * 4 + 16);
     constexpr int SMEM = (RING > SLAB ? RING : SLAB) + (4 * BN + 3 * BM) * 4;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
-    auto kern = gemm_ws_kernel<BM, BN, MW_M, MW_N, NL, S, W_BITS, EPI>;
+    auto kern = gemm_ws_kernel<BM, BN, MW_M, MW_N, NL, S, W_BITS, EPI, MF>;
     int rc = ensure_dynamic_lds((const void *)kern, SMEM);
     if (rc != MQ_OK) return rc;
     GemmArgs g = p;
@@ -551,6 +703,15 @@ int dispatch_ws(const GemmArgs &p, int tile, hipStream_t st)
         if constexpr (W_BITS == 4) return launch_ws<192, 128, 2, 4, 4, 4, W_BITS, EPI>(p, st);
         else break;
     case 43: return launch_ws<64, 128, 1, 4, 4, (W_BITS == 4 ? 8 : 6), W_BITS, EPI>(p, st);
+    // the same tiles with V_MFMA_I32_16X16X64_I8 in the math waves (round 5)
+    case 44: return launch_ws<96, 128, 1, 4, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI, 1>(p, st);
+    case 45: return launch_ws<128, 128, 2, 4, 4, (W_BITS == 4 ? 6 : 4), W_BITS, EPI, 1>(p, st);
+    case 46:
+        if constexpr (W_BITS == 4) return launch_ws<192, 128, 2, 4, 4, 4, W_BITS, EPI, 1>(p, st);
+        else break;
+    case 47: return launch_ws<64, 128, 1, 4, 4, (W_BITS == 4 ? 8 : 6), W_BITS, EPI, 1>(p, st);
+    // 96 x 128 with TWO math waves per SIMD (48 x 32 per wave): the 16x16x64 form issues at full rate from two waves
+    case 48: return launch_ws<96, 128, 2, 4, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI, 1>(p, st);
     default: break;
     }
     return fail(MQ_EINVAL, "gemm_ws: unknown tile %d", tile);

@@ -5,6 +5,7 @@ streams); every function below launches hand-written gfx950 kernels through
 from __future__ import annotations
 
 import math
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -440,23 +441,28 @@ def kv_dequant_fp8(q: torch.Tensor, scale: torch.Tensor, dtype: torch.dtype = to
     return out
 
 
-_KV_SCALE_OK = {}
+_KV_SCALE_OK = {}      # id(tensor) -> (weak reference to it, version counter, address) the check was made at
 
 
 def _check_kv_scale(kv_scale: torch.Tensor, kv_heads: int) -> None:
     """kv_heads K scales then kv_heads V scales, fp32, positive and finite (the attention kernels apply them AFTER the running
     maximum over raw scores: a zero / negative scale silently gives wrong probabilities).  The value check reads the tensor back
-    once per (storage, version) and never during stream capture."""
+    once per tensor OBJECT and version counter (the entry holds a weak reference: an address -- or an id -- recycled after the
+    tensor died belongs to a new object and is checked again; advisor finding r4) and never during stream capture."""
     assert kv_scale.dtype == torch.float32 and kv_scale.is_contiguous() and kv_scale.numel() == 2 * kv_heads, \
         f"kv_scale must hold 2 * kv_heads = {2 * kv_heads} fp32 values (got {tuple(kv_scale.shape)})"
-    key = (kv_scale.data_ptr(), kv_scale._version if not kv_scale.is_inference() else -1)
-    if _KV_SCALE_OK.get(key) or torch.cuda.is_current_stream_capturing():
+    version = kv_scale._version if not kv_scale.is_inference() else -1
+    seen = _KV_SCALE_OK.get(id(kv_scale))
+    if (seen is not None and seen[0]() is kv_scale and seen[1:] == (version, kv_scale.data_ptr())) or torch.cuda.is_current_stream_capturing():
         return
     ok = bool((torch.isfinite(kv_scale) & (kv_scale > 0)).all().item())
     assert ok, "kv_scale entries must be positive and finite"
     if len(_KV_SCALE_OK) > 256:
-        _KV_SCALE_OK.clear()
-    _KV_SCALE_OK[key] = True
+        for k in [k for k, v in _KV_SCALE_OK.items() if v[0]() is None]:
+            del _KV_SCALE_OK[k]
+        if len(_KV_SCALE_OK) > 256:
+            _KV_SCALE_OK.clear()
+    _KV_SCALE_OK[id(kv_scale)] = (weakref.ref(kv_scale), version, kv_scale.data_ptr())
 
 
 @_on_device
@@ -560,17 +566,22 @@ def prepack(q: torch.Tensor, bits: int, zero_col0: bool = False) -> torch.Tensor
 
 # --------------------------------------------------------------------------- GEMM
 _SPLITK_WS = {}
+_SPLITK_PINNED = []      # outgrown workspaces that a captured hipGraph may still replay into
 
 
 def splitk_workspace(device, nbytes: int = 64 << 20) -> torch.Tensor:
-    """Per-device scratch for split-K partial sums (grow-only, reused by every call on the
-    device's current stream order)."""
+    """Per-device scratch for split-K partial sums: ONE grow-only buffer per device, reused by every call in the
+    device's current stream order.  A buffer handed out during stream capture is kept alive when a larger one replaces it."""
     key = (device.index or 0)
-    ws = _SPLITK_WS.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
-        _SPLITK_WS[key] = ws
-    return ws
+    ent = _SPLITK_WS.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if ent is None or ent[0].numel() < nbytes:
+        if ent is not None and ent[1]:
+            _SPLITK_PINNED.append(ent[0])
+        ent = [torch.empty((nbytes,), dtype=torch.uint8, device=device), False]
+        _SPLITK_WS[key] = ent
+    ent[1] = ent[1] or capturing
+    return ent[0]
 
 
 def gemm_debug_force(tile: int = -1, splits: int = 0) -> None:
@@ -661,6 +672,31 @@ def quantize_act_group_asym_i8(x: torch.Tensor, groupsize: int, bits: int = 8, c
     call("mq_quantize_act_group_asym_i8", x2.data_ptr(), dtype_code(x2.dtype), M, K, x2.stride(0), int(groupsize), int(bits),
          float(clip_ratio), scales.data_ptr(), zero.data_ptr(), shift.data_ptr(), optr, K_pad, ldo, _stream())
     return out, scales, zero, shift
+
+
+@_on_device
+def gemm_w4a8_wgroupscale(a, w_img: torch.Tensor, w_bits: int, N: int, s_w_groups: torch.Tensor, group_k: int, *,
+                          s_x0: float = 1.0, s_x1: Optional[float] = None, row_sel: Optional[torch.Tensor] = None,
+                          s_x_rows: Optional[torch.Tensor] = None, s_x_groups: Optional[torch.Tensor] = None,
+                          bias: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.float16,
+                          out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Group-wise WEIGHT scales (``--w_groupsize``, ``mq_gemm_w4a8_wgroupscale``): s_w_groups fp32 [K / group_k, N];
+    y = (sum_g ((float(acc_g) * s_x_groups[m][g]) * s_w_groups[g][n])) * s_x(m) + bias[n] with s_x(m) the per-tensor /
+    token-type / per-token scale (1 with group-wise activation scales of the same group size)."""
+    _need_cuda(a, w_img, s_w_groups, row_sel, s_x_rows, s_x_groups, bias, out)
+    aptr, lda, M, K_pad = _a_args(a)
+    assert s_w_groups.dtype == torch.float32 and s_w_groups.dim() == 2 and s_w_groups.is_contiguous() and s_w_groups.shape[1] == N
+    G = s_w_groups.shape[0]
+    if s_x_groups is not None:
+        assert s_x_groups.dtype == torch.float32 and s_x_groups.is_contiguous() and tuple(s_x_groups.shape) == (M, G)
+    if s_x_rows is not None:
+        assert s_x_rows.dtype == torch.float32 and s_x_rows.is_contiguous() and s_x_rows.numel() == M
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=s_w_groups.device)
+    call("mq_gemm_w4a8_wgroupscale", aptr, lda, w_img.data_ptr(), w_bits, M, N, K_pad, s_w_groups.data_ptr(), G, int(group_k),
+         float(s_x0), float(s_x0 if s_x1 is None else s_x1), _ptr(row_sel), _ptr(s_x_rows), _ptr(s_x_groups), _ptr(bias),
+         out.data_ptr(), dtype_code(out.dtype), out.stride(0), _stream())
+    return out
 
 
 @_on_device

@@ -193,6 +193,29 @@ def epilogue(acc, sx0, s_w, bias=None, sx1=None, row_sel=None, x0=None, w0=None,
     return out
 
 
+def gemm_wgroup(a, w, s_wg, g, sx0=1.0, sx1=None, row_sel=None, sx_rows=None, s_xg=None, bias=None, want_acc=False):
+    """Group-wise weight scales (``--w_groupsize``, reference gptq/gptq_utils.py:263-273 + quant_utils.py:384):
+    y = (sum_g (float(acc_g) [* s_xg[m][g]]) * s_wg[g][n]) * s_x(m) + bias[n]; a int8 (M, K), w levels (N, K), s_wg fp32 (K / g, N).
+    Returns y (and the exact per-group accumulators [M, G, N] when ``want_acc``)."""
+    a = np.ascontiguousarray(a, dtype=np.int8)
+    w = np.ascontiguousarray(w, dtype=np.int8)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and K % g == 0
+    s_wg = _f32(s_wg)
+    assert s_wg.shape == (K // g, N)
+    s_xg = _f32(s_xg)
+    sx_rows = None if sx_rows is None else _f32(sx_rows).reshape(-1)
+    rs = None if row_sel is None else np.ascontiguousarray(row_sel, dtype=np.uint8)
+    bias = _f32(bias)
+    acc = np.empty((M, K // g, N), dtype=np.int32) if want_acc else None
+    out = np.empty((M, N), dtype=np.float32)
+    lib().orc_gemm_wgroup(_p(a, C.c_int8), _p(w, C.c_int8), C.c_long(M), C.c_long(N), C.c_long(K), C.c_long(g),
+                          _p(s_wg, C.c_float), _p(s_xg, C.c_float), C.c_float(sx0), C.c_float(sx0 if sx1 is None else sx1),
+                          _p(rs, C.c_uint8), _p(sx_rows, C.c_float), _p(bias, C.c_float), _p(acc, C.c_int32), _p(out, C.c_float))
+    return (out, acc) if want_acc else out
+
+
 def linear_fakequant_f32(x, s_x, w_dq, bias=None) -> np.ndarray:
     x = _f32(x)
     w_dq = _f32(w_dq)

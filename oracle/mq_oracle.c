@@ -474,6 +474,48 @@ void orc_epilogue(const int32_t *acc, long M, long N,
 }
 
 /* ------------------------------------------------------------------ */
+/* Group-wise WEIGHT scales (--w_groupsize g, gptq/gptq_utils.py:263-273: */
+/* the GPTQ solver re-runs WeightQuantizer.find_params, quant_utils.py:   */
+/* 446-509, on every group of g consecutive input channels, so W~[n][k] = */
+/* s_w[n][k / g] * q[n][k]).  The integer path evaluates F.linear         */
+/* (quant_utils.py:384) group by group:                                   */
+/*   acc_g[m][n] = sum_{k in g} a[m][k] q[n][k]          exact int32      */
+/*   f += (float(acc_g) * s_xg[m][g]) * s_wg[g][n]       ascending g, one */
+/*                                                       fp32 rounding    */
+/*                                                       per operation    */
+/*   y  = f * s_x(m) + bias[n]                                            */
+/* s_xg: group-wise activation scales of the same group size (NULL: the   */
+/* factor is absent); s_x(m): sx_rows[m], or sx1 where row_sel[m] else    */
+/* sx0.  acc_groups (optional, [M][G][N]) receives the per-group sums.    */
+/* ------------------------------------------------------------------ */
+void orc_gemm_wgroup(const int8_t *a, const int8_t *w, long M, long N, long K, long g,
+                     const float *s_wg, const float *s_xg, float sx0, float sx1, const uint8_t *row_sel,
+                     const float *sx_rows, const float *bias, int32_t *acc_groups, float *out)
+{
+    const long G = K / g;
+#pragma omp parallel for schedule(static)
+    for (long m = 0; m < M; ++m) {
+        const float sx = sx_rows ? sx_rows[m] : ((row_sel && row_sel[m]) ? sx1 : sx0);
+        for (long n = 0; n < N; ++n) {
+            float f = 0.0f;
+            for (long gi = 0; gi < G; ++gi) {
+                int32_t acc = 0;
+                const int8_t *ar = a + m * K + gi * g, *wr = w + n * K + gi * g;
+                for (long k = 0; k < g; ++k) acc += (int32_t)ar[k] * (int32_t)wr[k];
+                if (acc_groups) acc_groups[(m * G + gi) * N + n] = acc;
+                float t = (float)acc;
+                if (s_xg) t = t * s_xg[m * G + gi];
+                t = t * s_wg[gi * N + n];
+                f = f + t;
+            }
+            float y = f * sx;
+            if (bias) y = y + bias[n];
+            out[m * N + n] = y;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
 /* Whole fake-quant Linear exactly as the reference evaluates it on CPU */
 /* in fp32 (quant_utils.py:378-384): dequantize both operands, then an  */
 /* fp32 matmul.  Used as the timed CPU baseline ("port") and as a        */

@@ -5,7 +5,8 @@ import ctypes as C
 
 import pytest
 
-PIPE, WS64, WS96, WS128, WS192 = 14, 43, 40, 41, 42   # PIPE: the 256 x 256 tile (ping-pong kernel since round 4)
+PIPE, WS64, WS96, WS128, WS192 = 14, 47, 48, 45, 46   # PIPE: the 256 x 256 tile (ping-pong kernel since round 4); WS*: the
+#                                                       wave-specialised tiles with V_MFMA_I32_16X16X64_I8 math waves (round 5)
 
 
 def _plan(M, N, K):

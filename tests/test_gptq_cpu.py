@@ -350,10 +350,34 @@ def _llm_wrappers_after_gptq(**over):
     return llm
 
 
-def test_group_wise_gptq_does_not_attach_a_partial_quantizer():
-    """--w_groupsize > 0 with static_groups=False leaves a quantizer that only remembers its LAST column
-    group: the wrappers must not get it (they would rebuild integer levels on the wrong grid)."""
-    assert all(not w.weight_quantizers for w in _llm_wrappers_after_gptq(w_groupsize=8))
+def test_group_wise_gptq_attaches_every_groups_scale():
+    """--w_groupsize > 0 (static_groups=False): the reference's quantizer only remembers its LAST column group
+    (gptq_utils.py:263-273).  The solver here keeps every group's scale (``group_scales`` [rows, groups]) and attaches the
+    quantizer, so the wrappers can run mq_gemm_w4a8_wgroupscale; every weight is on ITS group's grid."""
+    llm = _llm_wrappers_after_gptq(w_groupsize=8)
+    assert all(w.weight_quantizers for w in llm)
+    for w in llm:
+        for sub, wq in w.weight_quantizers.items():
+            W = getattr(w, sub).weight.data.float()
+            assert wq.groupsize == 8 and not wq.group_permuted
+            assert tuple(wq.group_scales.shape) == (W.shape[0], W.shape[1] // 8)
+            np.testing.assert_array_equal(wq.group_scales[:, -1].numpy(), wq.scale.reshape(-1).float().numpy())   # what upstream keeps
+            lv = W.reshape(W.shape[0], -1, 8) / wq.group_scales[:, :, None]
+            np.testing.assert_allclose(lv.numpy(), np.rint(lv.numpy()), atol=1e-3)
+            assert float(lv.abs().max()) <= 8.0
+        # groups of 8 are below what the kernels take: the wrapper says it simulates, and why
+        assert "weight group size 8" in w._simulated_because() or w._simulated_because()
+
+
+def test_group_wise_gptq_with_act_order_stays_simulated_and_says_so():
+    llm = _llm_wrappers_after_gptq(w_groupsize=8, act_order=True)
+    for w in llm:
+        for wq in w.weight_quantizers.values():
+            assert wq.group_scales is None and wq.group_permuted
+    w = llm[0]
+    w.quantizer.configure(bits=8, sym=True)
+    assert "permuted" in w._simulated_because() and "simulated" in w.backend() and "Backend:" in w.extra_repr()
+    assert not w._real_ready(torch.zeros(2, w.module.in_features))
 
 
 def test_per_channel_gptq_still_attaches():

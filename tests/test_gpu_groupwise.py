@@ -145,7 +145,10 @@ def test_asymmetric_group_quantizer_kernel_equals_the_oracle(dtype, M, K, g, bit
 
 
 @pytest.mark.parametrize("w_bits,out_dtype", [(4, torch.float16), (8, torch.float32), (4, torch.bfloat16)])
-@pytest.mark.parametrize("M,N,K,g", [(37, 200, 1280, 128), (130, 96, 2048, 64), (16, 48, 3584, 256), (300, 264, 1920, 64)])
+@pytest.mark.parametrize("M,N,K,g", [(37, 200, 1280, 128), (130, 96, 2048, 64), (16, 48, 3584, 256), (300, 264, 1920, 64),
+                                     # K % 128 == 64 with groups of 64: K_pad ends in a zero-padded k-tile that belongs to no
+                                     # group -- its constant term must not be added again for the last group (advisor r4)
+                                     (33, 72, 192, 64), (140, 200, 1984, 64)])
 def test_asymmetric_groupscale_gemm_equals_its_arithmetic_restated(w_bits, out_dtype, M, N, K, g):
     from mquant_amd import ops
     rng = np.random.default_rng(M + N + K + 7)
@@ -213,3 +216,26 @@ def test_wrapper_runs_the_asymmetric_group_wise_mode_on_the_integer_path(golden_
         np.testing.assert_array_equal(s.cpu().numpy(), g["s_groups"], err_msg=path)
         np.testing.assert_array_equal(z.cpu().numpy(), g["z_groups"], err_msg=path)
         np.testing.assert_array_equal(a[:, :c["K_pad"]].cpu().numpy(), g["qx"], err_msg=path)
+
+
+@pytest.mark.parametrize("K", [192, 1984])
+def test_wrapper_asymmetric_groups_of_64_with_a_padded_last_k_tile(K):
+    """K % 128 == 64 with groups of 64 (advisor finding r4): the integer path pads K to a multiple of 128, the pad tile belongs
+    to no group.  The wrapper's integer result has to stay on the simulated evaluation of the same wrapper."""
+    from fake_quant import quant_utils as qu
+    from fake_quant.gptq.rtn import rtn_module
+    M, N = 45, 136
+    lin = torch.nn.Linear(K, N, bias=True)
+    lin.weight.data = torch.from_numpy(make_w(K, (N, K)))
+    lin.bias.data = torch.from_numpy(make_w(K + 1, (N,), std=0.1))
+    wrap = qu.ActQuantWrapper(lin.to(DEV))
+    rtn_module(wrap, "layer", 4, True, False, [], {})
+    wrap.quantizer.configure(bits=8, groupsize=64, sym=False, clip_ratio=1.0)
+    x = (torch.from_numpy(make_x(K + 3, (M, K))) + 0.7).to(DEV)        # off-centre: the zero points matter
+    assert wrap._real_ready(x)
+    y = wrap(x)
+    assert wrap._real is not None and wrap._real.wsum_groups is not None
+    wrap.real_quant = False
+    y_sim = wrap(x.clone())
+    tol = 1e-3 * float(y_sim.abs().max())
+    np.testing.assert_allclose(y.cpu().numpy(), y_sim.cpu().numpy(), rtol=0, atol=tol)

@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 DTYPES = [torch.float16, torch.bfloat16, torch.float32]
 MODE = {torch.float16: 1, torch.bfloat16: 2, torch.float32: 0}
-WS_TILES = (40, 41, 42, 43)
+WS_TILES = (40, 41, 42, 43, 44, 45, 46, 47, 48)     # 44-47: the same tiles with V_MFMA_I32_16X16X64_I8 in the math waves (round 5)
+W4_ONLY = (42, 46)
 
 
 def ops():
@@ -160,7 +161,7 @@ def test_every_wave_specialised_tile_is_exact(w_bits, M, N, K):
     o.splitk_workspace(torch.device(DEV), 64 << 20)
     try:
         for tile in WS_TILES:
-            if w_bits == 8 and tile == 42:
+            if w_bits == 8 and tile in W4_ONLY:
                 continue                      # these exist for int4 weights only
             for splits in (1, 3):
                 o.gemm_debug_force(tile, splits)
@@ -212,7 +213,7 @@ def test_dequant_epilogue_with_every_optional_term_tiled(out_dtype, M, N, K):
     ref = oracle.round_to(oracle.epilogue(acc, np.float32(sx0), s_w, bias=bias, sx1=np.float32(sx1), row_sel=sel,
                                           x0=x0, w0=w0), MODE[out_dtype])
     try:
-        for tile in (-1, 40, 41, 43):
+        for tile in (-1, 40, 41, 43, 44, 45, 47):
             o.gemm_debug_force(tile, 0)
             y = o.gemm_w4a8(at, img, 4, N, sx0, to_dev(s_w), s_x1=sx1, row_sel=to_dev(sel), bias=to_dev(bias),
                             x0=to_dev(x0), w0=to_dev(w0), out_dtype=out_dtype)
@@ -372,7 +373,7 @@ def test_every_m_grouping_of_the_xcd_mapping_is_a_bijection(M, N, K):
     img = o.prepack(to_dev(w), 4)
     o.splitk_workspace(torch.device(DEV), 64 << 20)
     try:
-        for tile in (40, 41, 42, 43, 3, 1, 14, 15, 16, 17, 18, 19):
+        for tile in (40, 41, 42, 43, 44, 45, 46, 47, 48, 3, 1, 14, 15, 16, 17, 18, 19):
             for xm in (1, 2, 3, 4, 6, 8):
                 for splits in (1, 2):
                     o.gemm_debug_force(tile, splits | (xm << 8))
@@ -388,7 +389,7 @@ def test_random_shapes_tiles_and_epilogues_against_the_oracle():
     o = ops()
     rng = np.random.default_rng(20261002)
     tiles_w4 = list(WS_TILES) + [1, 3, 13, 14, 15, 16, 17, 18, 19, 2, 10, 26, 31, 35]
-    tiles_w8 = [t for t in WS_TILES if t != 42] + [3, 2, 10, 26, 31]
+    tiles_w8 = [t for t in WS_TILES if t not in W4_ONLY] + [3, 2, 10, 26, 31]
     o.splitk_workspace(torch.device(DEV), 64 << 20)
     try:
         for case in range(96):

@@ -62,3 +62,30 @@ def test_write_and_read_formulas():
     ok = np.abs(xf) > scale[None, :, None] * 2.0 ** -6
     ok &= np.abs(xf) <= scale[None, :, None] * 448
     assert float(np.max(np.abs(y[ok] - xf[ok]) / np.abs(xf[ok]))) <= 2.0 ** -4 + 1e-3
+
+
+def test_kv_scale_check_is_per_tensor_object_not_per_address(monkeypatch):
+    """advisor finding r4: the positive / finite check of kv_scale was cached on (address, version); a NEW tensor that the
+    caching allocator places at a freed, already validated address skipped it.  The cache is keyed on the tensor object now."""
+    from mquant_amd import ops
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    good = torch.full((8,), 0.5)
+    ops._check_kv_scale(good, 4)
+    ops._check_kv_scale(good, 4)                               # cached: same object, same version
+    ptr = good.data_ptr()
+    bad = torch.full((8,), 0.5)
+    bad[3] = -1.0
+    # same address and version as a validated tensor, different object: must be checked (simulated through the cache itself)
+    ops._KV_SCALE_OK[id(bad)] = ops._KV_SCALE_OK[id(good)]
+    try:
+        ops._check_kv_scale(bad, 4)
+        raise RuntimeError("a foreign cache entry validated a bad tensor")
+    except AssertionError:
+        pass
+    good[0] = 0.0                                              # in-place write: version bump, checked again
+    try:
+        ops._check_kv_scale(good, 4)
+        raise RuntimeError("a version bump was not re-checked")
+    except AssertionError:
+        pass
+    assert ptr == good.data_ptr()

@@ -58,9 +58,11 @@ def worker(tile, bm, bn, ks):
         res.append(best)
         if os.environ.get("MQ_STAMPS"):
             torch.cuda.synchronize()
-            st_ = ops.splitk_workspace(dev)[: mb * nb * 8].view(torch.int32).view(-1, 2).cpu()
+            per = 8 if tile in (14, 15, 16, 17, 18, 19) else 2      # ints per workgroup: gemm_pp.hip writes 8 (incl. s_memrealtime), gemm_ws.hip 2
+            st_ = ops.splitk_workspace(dev)[: mb * nb * per * 4].view(torch.int32).view(-1, per).cpu()
             cyc = st_[:, 0].float()
-            print(f"    K={K}: loop cycles (incl. prologue) median {cyc.median().item():.0f} min {cyc.min().item():.0f} max {cyc.max().item():.0f}, k-tiles {st_[0, 1].item()}", flush=True)
+            real = f", in-kernel s_memtime / s_memrealtime = {(cyc / st_[:, 2].float() * 0.1).median().item():.3f} GHz" if per == 8 else ""
+            print(f"    K={K}: loop cycles (incl. prologue) median {cyc.median().item():.0f} min {cyc.min().item():.0f} max {cyc.max().item():.0f}, k-tiles {st_[0, 1].item()}{real}", flush=True)
             stamps.append(cyc.median().item())
         del copies, q
     if len(stamps) == len(ks):
