@@ -354,10 +354,12 @@ class ActQuantWrapper(torch.nn.Module):
         the entry point family) or the reference's simulated torch ops -- and then why (a model that falls back must
         say so; ``print(model)`` shows this line for every wrapper)."""
         qz = self.quantizer
+        if getattr(self, "_real_frozen", False) and self._real is not None:
+            if not self.real_quant:
+                return "simulated (torch ops): real_quant switched off"
+            return "W%dA%d integer (engine from a flat checkpoint)" % (self._real.w_bits, 8 if self._real.dynamic is None else self._real.dynamic["bits"])
         if qz.bits >= 16:
             return "float (activation quantizer not configured)"
-        if getattr(self, "_real_frozen", False) and self._real is not None:
-            return "W%dA%d integer (engine from a flat checkpoint)" % (self._real.w_bits, 8)
         why = self._simulated_because()
         if why:
             return "simulated (torch ops): " + why

@@ -458,6 +458,17 @@ int mq_gemm_w4a8_groupscale_asym(const int8_t *a, long lda, const void *w, int w
                                  long n_groups, int group_k, const float *s_w, const float *bias, void *out,
                                  int out_dtype, long ldo, void *stream);
 
+/* W4A8 Linear with the rotary position embedding of its q | k output columns folded into the store (the fused q|k|v projection of
+ * a decoder layer).  NOT part of MQuant -- the reference never touches RoPE; it exists because the whole-prefill TTFT report chains
+ * the Linears through the model's glue ("the step either side of the Linear").  Columns n < rope_cols are heads of
+ * head_dim = 128 channels (one 128-wide output tile each, rope_cols % 128 == 0); cos / sin: [M, 128] in the output dtype, row = token
+ * position.  Result = mq_gemm_w4a8 followed by mq_rope_inplace on the same columns, bit for bit:
+ *   x = cast(linear output);  out = cast(cast(x * cos) + cast(rotate_half(x) * sin)),  rotate_half(x) = cat(-x[64:], x[:64]).
+ * Needs tiled activations (lda = MQ_LD_TILED), a 16-bit output, N % 8 == 0; other head sizes: MQ_EUNSUPPORTED (run mq_rope_inplace). */
+int mq_gemm_w4a8_rope_ws(const int8_t *a, long lda, const void *w, int w_bits, long M, long N, long K_pad, float s_x0, float s_x1,
+                         const uint8_t *row_sel, const float *s_w, const float *bias, const void *rope_cos, const void *rope_sin,
+                         long rope_cols, int head_dim, void *out, int out_dtype, long ldo, void *stream);
+
 /* The GEMM for group-wise WEIGHT scales (--w_groupsize g; reference fake_quant/gptq/gptq_utils.py:263-273: the GPTQ solver re-runs
  * WeightQuantizer.find_params on every group of g consecutive input channels, so channel n carries one scale per group; flag at
  * exam/quant_qwen2vl.py:327).  s_w_groups[g * N + n] = that scale.

@@ -132,6 +132,7 @@ struct AqTiledArgs {
 template <int DT, int EPT, int THREADS>
 __global__ __launch_bounds__(THREADS) void act_quant_tiled_kernel(AqTiledArgs p)
 {
+    kernarg_warm<sizeof(AqTiledArgs)>();     // one scalar-load round trip instead of five (mq_common.h)
     typedef typename Elem<DT>::T T;
     constexpr int WPP = 16 / EPT;                                  // waves per piece
     constexpr int SUB = 16 / EPT;                                  // lanes per 16-byte chunk of the image

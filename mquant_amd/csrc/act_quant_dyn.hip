@@ -31,6 +31,7 @@ struct DqArgs {
 template <int DT, bool ASYM = false>
 __global__ __launch_bounds__(DQ_THREADS) void act_quant_dyn_kernel(DqArgs p)
 {
+    kernarg_warm<sizeof(DqArgs)>();
     typedef typename Elem<DT>::T T;
     __shared__ float rmin[DQ_THREADS / 64], rmax[DQ_THREADS / 64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -286,6 +287,7 @@ struct GqArgs {
 template <int DT, bool ASYM = false>
 __global__ __launch_bounds__(256) void act_quant_group_kernel(GqArgs p)
 {
+    kernarg_warm<sizeof(GqArgs)>();
     typedef typename Elem<DT>::T T;
     const long cpr = p.K_pad / 16;                                  // 16-channel chunks per row (a multiple of lanes_per_group)
     const long total = p.M * cpr;

@@ -46,6 +46,12 @@ struct GemmArgs {
     // solver found for channel n on k-group g.  The grouped kernel multiplies a group's (row-scaled) sum by it before the fp32
     // accumulation; the epilogue then applies the ROW scale (s_x per tensor / token-type / token) instead of s_w[n].
     const float *sw_groups = nullptr;
+    // rotary position embedding folded into the store (gemm_ws.hip fast path; the q | k columns of a fused q|k|v projection):
+    // output columns n < rope_cols are heads of 128 = one 128-wide tile, rotate-half partner d +- 64 in the same row of the
+    // tile; rope_cos / rope_sin: [M, 128] in the OUTPUT dtype (row = token position).  Same roundings as the separate
+    // launch mq_rope_inplace on the rounded Linear output: out = cast(cast(x cos) + cast(rotate_half(x) sin)).
+    const void *rope_cos = nullptr, *rope_sin = nullptr;
+    long rope_cols = 0;
     long n_groups = 0;
     int group_k = 0;
     int acc_float = 0;
@@ -112,6 +118,22 @@ inline bool geometry_in_range(const GemmArgs &p)
     unsigned long long d = p.mg > p.n_blocks ? p.mg : p.n_blocks;
     if (p.xm > d) d = p.xm;
     return total * d < (1ULL << 32) && total < (1ULL << 31);
+}
+
+// Kernel arguments up front.  hipcc loads a by-value argument block lazily, field by field next to its first use, with an
+// s_waitcnt in front of every dependent step: the tile map alone (grid size -> geometry -> operand pointers) cost FOUR serialized
+// scalar-load round trips, ~1 us between a workgroup's entry and its first LDS-DMA (profiles/r5_ws_fixed_cost_timeline.txt: 0.55-1.3 us
+// of every wave-specialised launch; the argument block of a launch is never in the scalar cache).  Naming the fields in one empty asm
+// at the top of the kernel makes them live there, so their loads go out as ONE clause with ONE wait.
+__device__ __forceinline__ void args_up_front(const GemmArgs &p)
+{
+#ifndef MQ_LAZY_ARGS
+    asm volatile("" ::"s"(p.m_blocks), "s"(p.n_blocks), "s"(p.mag_m), "s"(p.mag_n), "s"(p.kq), "s"(p.kr), "s"(p.xm), "s"(p.mg),
+                 "s"(p.mag_xm), "s"(p.splits), "s"(p.a), "s"(p.w), "s"(p.M), "s"(p.N), "s"(p.K_pad), "s"(p.n_pairs), "s"(p.n_tiles),
+                 "s"(gridDim.x));
+    asm volatile("" ::"s"(p.s_w), "s"(p.bias), "s"(p.w0), "s"(p.x0), "s"(p.sx_vec), "s"(p.w1), "s"(p.x1), "s"(p.row_sel), "s"(p.out),
+                 "s"(p.ldo));
+#endif
 }
 
 // workgroup -> (bm, bn, split): XCD-aware and bijective.  Block b runs on XCD b % 8; the remap gives

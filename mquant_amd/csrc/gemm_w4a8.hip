@@ -41,6 +41,7 @@ int launch_gemm_pp(const GemmArgs &p, int tile, hipStream_t st);   // gemm_pp.hi
 template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int W_BITS, int EPI, int DMA_POS, bool GROUPED = false>
 __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmArgs p)
 {
+    kernarg_warm<sizeof(GemmArgs)>();
     constexpr int NWAVES = WARPS_M * WARPS_N;
     constexpr int TM = BM / WARPS_M / 16;          // activation fragments per wave
     constexpr int TN = BN / WARPS_N / 16;          // weight fragments per wave
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p)
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_w4a8_pipe_kernel(GemmArgs p)
 {
+    kernarg_warm<sizeof(GemmArgs)>();
     constexpr int BM = 256, BN = 256, WARPS_N = 4, NWAVES = 8, TM = 8, TN = 4;
     constexpr int RING = 6, X_PIECES = BM / 16, W_PIECES = BN / 32, PIECES = X_PIECES + W_PIECES;
     constexpr int LPW = PIECES / NWAVES;                    // 3 DMA instructions per wave per k-tile
@@ -501,7 +503,7 @@ struct Plan {
 };
 
 static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes, int force_tile,
-                      int force_splits, bool w4 = true, bool a_tiled = false)
+                      int force_splits, bool w4 = true, bool a_tiled = false, bool ws_only = false)
 {
     const long kps = K_pad / 128;
     const long t256 = ceil_div(M, 256) * ceil_div(N, 256);
@@ -537,7 +539,9 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
             if (best < 0 || cost < best) { best = cost; pl.tile = c[0]; }
         }
     }
-    if (t256 >= 192) {
+    if (ws_only) {
+        // (an epilogue that exists in the wave-specialised kernels only -- RoPE in the store: the best of the tiles above, no split-K)
+    } else if (t256 >= 192) {
         // gate|up: with tiled activations the 8-wave ping-pong kernel (gemm_pp.hip, round 4: 93-101 us against 108-116
         // for the software-pipelined tile 13 and 110-112 for the 16-wave tile 3, profiles/r4_pp_ab.txt); with row-major
         // activations the 16-wave kernel
@@ -566,8 +570,8 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
         while (s > 1 && ((size_t)(s * M * N * 4) > ws_bytes || kps / s < 8)) --s;
         if (s > 1) { pl.tile = 3; pl.splits = (int)s; }
     }
-    if (force_tile >= 0) pl.tile = force_tile;
-    if (force_splits > 0) pl.splits = force_splits;
+    if (force_tile >= 0 && (!ws_only || (force_tile >= 40 && force_tile < 60))) pl.tile = force_tile;
+    if (force_splits > 0 && !ws_only) pl.splits = force_splits;
     if (pl.splits > kps) pl.splits = (int)kps;
     if (pl.splits < 1) pl.splits = 1;
     return pl;
@@ -631,7 +635,8 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
                        void *stream, const float *sx_vec = nullptr, const void *residual = nullptr,
                        long ldr = 0, const float *sx_groups = nullptr, long n_groups = 0, int group_k = 0,
                        const float *x1 = nullptr, const float *w1 = nullptr, const float *shift_groups = nullptr,
-                       const float *wsum_groups = nullptr, const float *sw_groups = nullptr)
+                       const float *wsum_groups = nullptr, const float *sw_groups = nullptr,
+                       const void *rope_cos = nullptr, const void *rope_sin = nullptr, long rope_cols = 0)
 {
     MQ_REQUIRE(M >= 0 && N >= 0 && K_pad >= 0, "mq_gemm_w4a8: negative shape");
     if (M == 0 || N == 0) return MQ_OK;
@@ -686,8 +691,17 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
         default: return launch_gemm<128, 128, 2, 4, 3, 8, EPI_F32, 1, true>(p, gst);
         }
     }
-    const Plan pl = make_plan(M, N, K_pad, workspace != nullptr, workspace_bytes, g_force_tile,
-                              workspace ? g_force_splits : 0, w_bits == 4, a_tiled);
+    const bool rope = rope_cos != nullptr;
+    if (rope) {
+        // RoPE in the store lives in the fast path of the wave-specialised epilogue: everything that path needs is checked HERE
+        // (a launch that fell back to the general loop would silently skip the rotation)
+        MQ_REQUIRE(rope_sin && a_tiled && (epi == EPI_F16 || epi == EPI_BF16) && !residual && rope_cols > 0 && rope_cols % 128 == 0 && rope_cols <= N
+                       && N % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)out) % 16 == 0 && ((uintptr_t)rope_cos) % 16 == 0 && ((uintptr_t)rope_sin) % 16 == 0,
+                   "mq_gemm_w4a8_rope_ws: needs tiled activations, a 16-bit 16-byte aligned output with N and ldo multiples of 8, heads of 128 (rope_cols a multiple of 128, at most N) and 16-byte aligned tables");
+        p.rope_cos = rope_cos; p.rope_sin = rope_sin; p.rope_cols = rope_cols;
+    }
+    const Plan pl = make_plan(M, N, K_pad, workspace != nullptr && !rope, workspace_bytes, g_force_tile,
+                              workspace ? g_force_splits : 0, w_bits == 4, a_tiled, rope);
     p.splits = pl.splits;
     p.partial = (int32_t *)workspace;
     auto al16 = [](const void *q) { return q == nullptr || ((uintptr_t)q) % 16 == 0; };
@@ -763,6 +777,20 @@ extern "C" int mq_gemm_w4a8_residual_ws(const int8_t *a, long lda, const void *w
     if (!residual) return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_residual_ws: residual is required");
     return mq::gemm_common(a, lda, w, w_bits, M, N, K_pad, s_x0, s_x1, row_sel, s_w, bias, x0, w0,
                            out, out_dtype, ldo, workspace, workspace_bytes, stream, nullptr, residual, ldr);
+}
+
+extern "C" int mq_gemm_w4a8_rope_ws(const int8_t *a, long lda, const void *w, int w_bits, long M, long N, long K_pad, float s_x0, float s_x1,
+                                    const uint8_t *row_sel, const float *s_w, const float *bias, const void *rope_cos, const void *rope_sin,
+                                    long rope_cols, int head_dim, void *out, int out_dtype, long ldo, void *stream)
+{
+    if (out_dtype != MQ_F16 && out_dtype != MQ_BF16)
+        return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_rope_ws: the rotation is defined on a 16-bit output (dtype %d)", out_dtype);
+    if (head_dim != 128) return mq::fail(MQ_EUNSUPPORTED, "mq_gemm_w4a8_rope_ws: head_dim %d (the fused form needs 128 = one output tile; use mq_rope_inplace)", head_dim);
+    if (M == 0 || N == 0) return MQ_OK;
+    if (!rope_cos || !rope_sin) return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_rope_ws: the cos / sin tables are required");
+    return mq::gemm_common(a, lda, w, w_bits, M, N, K_pad, s_x0, s_x1, row_sel, s_w, bias, nullptr, nullptr, out, out_dtype, ldo,
+                           nullptr, 0, stream, nullptr, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           rope_cos, rope_sin, rope_cols);
 }
 
 extern "C" int mq_gemm_w4a8_rowscale_ws(const int8_t *a, long lda, const void *w, int w_bits, long M, long N,

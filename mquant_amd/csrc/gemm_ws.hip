@@ -63,9 +63,20 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
     float *par_w1 = par_xz + BM;                                  // [BN] w1 (second rank-1 term)
     float *par_x1 = par_w1 + BN;                                  // [BM] x1 of the row
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    args_up_front(p);
+    // Roles by wave: `wave` is the LOGICAL index (0 .. NM-1 math, NM .. NM+NL-1 loaders) = the hardware wave index.  The hardware
+    // starts the waves of a workgroup one after the other (the first instruction of wave NM runs 0.45-0.5 us after wave 0's,
+    // profiles/r5_ws_fixed_cost_timeline.txt); making the loaders the FIRST hardware waves (-DMQ_WS_LOADERS_FIRST) brings their
+    // first LDS-DMA 0.2-0.3 us forward and was measured 0.6 % SLOWER over the bench's GEMM launches (6.51 against 6.47 ms,
+    // profiles/r5_bench_ab_args_and_wave_order.txt): the math waves then start last and their parameter prefetch delays B(0).
+    const int lane = threadIdx.x & 63;
+#ifndef MQ_WS_LOADERS_FIRST
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#else
+    const int hwave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = hwave < NL ? NM + hwave : hwave - NL;
+#endif
+    const int tid = wave * 64 + lane;
 #ifdef MQ_WS_TL
     // Timeline build (tools/gemm_timeline.py, profiles/r5_ws_fixed_cost_timeline.txt): 16 ints per workgroup in the
     // split-K workspace -- s_memtime at entry / first stage requested / first stage landed / B(0) / loop end / slab
@@ -110,6 +121,9 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
     if (wave >= NM) {
         // =========================== loader waves ===========================================
         const int lw = wave - NM;
+#ifdef MQ_WS_TL
+        const int tl_lentry = (int)__builtin_amdgcn_s_memtime();    // first instruction of a loader wave
+#endif
         __builtin_amdgcn_s_setprio(2);               // a loader's few instructions go ahead of the math waves' streams
         const long KT = p.K_pad >> 6, MT = (p.M + 15) >> 4;
         // piece f of a stage: wave-uniform base (SGPRs) + lane * 16
@@ -161,9 +175,18 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
         // more slowly than it arrives, so the ring fills up behind them).
         constexpr int PRE0 = 3 < S ? 3 : S;            // measured against 1, 2 and the whole ring (profiles/r3_gemm_ring_prefill_depth.txt)
         const int pre0 = nk < PRE0 ? nk : PRE0;
+#ifdef MQ_WS_TL
+        asm volatile("" ::: "memory");
+        const int tl_addr = (int)__builtin_amdgcn_s_memtime();      // piece addresses ready
+        int tl_st0 = tl_addr;
+#endif
 #pragma unroll
-        for (int s = 0; s < PRE0; ++s)
+        for (int s = 0; s < PRE0; ++s) {
             if (s < pre0) issue(s, s);
+#ifdef MQ_WS_TL
+            if (s == 0) tl_st0 = (int)__builtin_amdgcn_s_memtime();  // stage 0 requested
+#endif
+        }
 #ifdef MQ_WS_TL
         const int tl_req = (int)__builtin_amdgcn_s_memtime();       // first stages requested (kept in registers: a store
 #endif                                                              // here would sit in the counted vmcnt of the ring)
@@ -195,6 +218,9 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
         if (tl && tid == NM * 64) {
             tl[4] = tl_req;
             tl[5] = tl_land;
+            tl[14] = tl_addr;
+            tl[15] = tl_st0;
+            tl[3] = tl_lentry;
         }
 #endif
     } else {
@@ -508,6 +534,11 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
         const int lrow = tid / LPR;
         v4i q0[ITERS], q1[ITERS];
         float sxr[ITERS], xzr[ITERS], x1r[ITERS];
+        // RoPE in the store (GemmArgs::rope_cos): a 128-wide tile below rope_cols is one head; this lane's 8 channels d .. d+7
+        // of the head and the rotate-half partner's (d +- 64) sit in lanes l and l ^ 8 of the same 16-lane row group
+        constexpr bool ROPE_OK = (EPI == EPI_F16 || EPI == EPI_BF16) && BN == 128;
+        const bool rope = ROPE_OK && p.rope_cos != nullptr && n0 < p.rope_cols;
+        v4i rcs[ROPE_OK ? ITERS : 1], rsn[ROPE_OK ? ITERS : 1];
 #pragma unroll
         for (int t = 0; t < ITERS; ++t) {
             const int row = (t * RPI + lrow < BM) ? t * RPI + lrow : BM - 1;
@@ -516,6 +547,14 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
             sxr[t] = par_sx[row];
             xzr[t] = par_xz[row];
             x1r[t] = par_x1[row];
+            if constexpr (ROPE_OK) {
+                if (rope) {
+                    long mr = m0 + row;
+                    if (mr >= p.M) mr = p.M - 1;
+                    rcs[t] = *reinterpret_cast<const v4i *>(reinterpret_cast<const unsigned short *>(p.rope_cos) + mr * 128 + c8);
+                    rsn[t] = *reinterpret_cast<const v4i *>(reinterpret_cast<const unsigned short *>(p.rope_sin) + mr * 128 + c8);
+                }
+            }
         }
         // Packed fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32: two outputs per instruction, each lane
         // element rounded like the scalar form).  int4 weights: the accumulator carries a factor 16
@@ -566,6 +605,55 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     h[e] = (int)((EPI == EPI_F16) ? pack2_f16(y[2 * e], y[2 * e + 1]) : pack2_bf16(y[2 * e], y[2 * e + 1]));
+                if constexpr (ROPE_OK) {
+                    if (rope) {                      // (uniform over the workgroup: every lane takes part in the exchange)
+                        constexpr int DT = (EPI == EPI_F16) ? MQ_F16 : MQ_BF16;
+                        const float sgn = (c8 < 64) ? -1.0f : 1.0f;       // rotate_half(x) = cat(-x2, x1)
+                        if constexpr (EPI == EPI_F16) {
+                            // fp16: packed half arithmetic gives the same bits as the fp32 form below -- a product of two halves is exact
+                            // in fp32, so cast(a * c) IS the correctly rounded half product (v_pk_mul_f16); the sum of two halves is
+                            // exact in fp32 unless one is below 2^-13 of the other, and then both forms return the larger one
+                            // (v_pk_add_f16).  3 packed instructions per two outputs instead of ~20 (the fp32 form cost +4 us on the
+                            // q|k|v launch, as much as the rotation's own launch: profiles/r5_full_prefill_kernel_split.txt).
+                            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                            const int flip = (c8 < 64) ? (int)0x80008000 : 0;                 // -x2 in the low half of a head: sign bits
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int own_i = h[e];
+                                const int oth_i = __builtin_amdgcn_update_dpp(0, own_i, 0x128 /* row_ror:8 */, 0xf, 0xf, false) ^ flip;
+                                h2 own, oth, c2, s2;
+                                __builtin_memcpy(&own, &own_i, 4);
+                                __builtin_memcpy(&oth, &oth_i, 4);
+                                const int cw = rcs[t][e], sw = rsn[t][e];
+                                __builtin_memcpy(&c2, &cw, 4);
+                                __builtin_memcpy(&s2, &sw, 4);
+                                const h2 p1 = own * c2;
+                                const h2 p2 = oth * s2;                           // (+-b) * sin
+                                const h2 r = p1 + p2;
+                                int r_i;
+                                __builtin_memcpy(&r_i, &r, 4);
+                                h[e] = r_i;
+                            }
+                        } else
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned own = (unsigned)h[e];
+                            const unsigned oth = (unsigned)__builtin_amdgcn_update_dpp(0, h[e], 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+                            const unsigned cw = (unsigned)rcs[t][e], sw = (unsigned)rsn[t][e];
+                            unsigned short ob[2];
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                const float a = Elem<DT>::ld((unsigned short)(own >> (16 * k)));
+                                const float b = Elem<DT>::ld((unsigned short)(oth >> (16 * k)));
+                                const float c = Elem<DT>::ld((unsigned short)(cw >> (16 * k)));
+                                const float sn = Elem<DT>::ld((unsigned short)(sw >> (16 * k)));
+                                const float r = Elem<DT>::rnd(a * c) + Elem<DT>::rnd((sgn * b) * sn);
+                                ob[k] = Elem<DT>::st(r);
+                            }
+                            h[e] = (int)((unsigned)ob[0] | ((unsigned)ob[1] << 16));
+                        }
+                    }
+                }
                 store_out(reinterpret_cast<v4i *>(reinterpret_cast<unsigned short *>(p.out) + m * p.ldo + n), h);
             }
         }

@@ -94,6 +94,31 @@ __device__ __forceinline__ unsigned pack2_bf16(float a, float b)
     return *reinterpret_cast<const unsigned *>(&h);
 }
 
+// Kernel arguments: warm the scalar cache in ONE round trip.  hipcc loads a by-value argument block lazily, field by field next to
+// the first use, with an s_waitcnt in front of every dependent step -- three to six SERIALIZED scalar-load round trips at the top of
+// the quantizer, Hadamard and GEMM kernels (the argument block of a launch is never in the scalar cache: ~1 us between a workgroup's
+// entry and its first useful instruction, profiles/r5_ws_fixed_cost_timeline.txt).  One dword per 64-byte line of the kernarg segment,
+// all requested at once and waited for once: the compiler's own loads behind it hit the cache.  BYTES = sizeof(argument struct);
+// the implicit arguments behind it (grid size ...) share its last lines.
+template <int BYTES>
+__device__ __forceinline__ void kernarg_warm()
+{
+#ifndef MQ_LAZY_ARGS
+    constexpr int LINES = (BYTES + 24 + 63) / 64 > 8 ? 8 : (BYTES + 24 + 63) / 64;
+    const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned d0, d1, d2, d3, d4, d5, d6, d7;
+    (void)d0; (void)d1; (void)d2; (void)d3; (void)d4; (void)d5; (void)d6; (void)d7;
+    if constexpr (LINES == 1) asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(d0) : "s"(ka));
+    if constexpr (LINES == 2) asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=s"(d0), "=s"(d1) : "s"(ka));
+    if constexpr (LINES == 3) asm volatile("s_load_dword %0, %3, 0x0\n\ts_load_dword %1, %3, 0x40\n\ts_load_dword %2, %3, 0x80\n\ts_waitcnt lgkmcnt(0)" : "=s"(d0), "=s"(d1), "=s"(d2) : "s"(ka));
+    if constexpr (LINES == 4) asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\ts_waitcnt lgkmcnt(0)" : "=s"(d0), "=s"(d1), "=s"(d2), "=s"(d3) : "s"(ka));
+    if constexpr (LINES == 5) asm volatile("s_load_dword %0, %5, 0x0\n\ts_load_dword %1, %5, 0x40\n\ts_load_dword %2, %5, 0x80\n\ts_load_dword %3, %5, 0xc0\n\ts_load_dword %4, %5, 0x100\n\ts_waitcnt lgkmcnt(0)" : "=s"(d0), "=s"(d1), "=s"(d2), "=s"(d3), "=s"(d4) : "s"(ka));
+    if constexpr (LINES == 6) asm volatile("s_load_dword %0, %6, 0x0\n\ts_load_dword %1, %6, 0x40\n\ts_load_dword %2, %6, 0x80\n\ts_load_dword %3, %6, 0xc0\n\ts_load_dword %4, %6, 0x100\n\ts_load_dword %5, %6, 0x140\n\ts_waitcnt lgkmcnt(0)" : "=s"(d0), "=s"(d1), "=s"(d2), "=s"(d3), "=s"(d4), "=s"(d5) : "s"(ka));
+    if constexpr (LINES == 7) asm volatile("s_load_dword %0, %7, 0x0\n\ts_load_dword %1, %7, 0x40\n\ts_load_dword %2, %7, 0x80\n\ts_load_dword %3, %7, 0xc0\n\ts_load_dword %4, %7, 0x100\n\ts_load_dword %5, %7, 0x140\n\ts_load_dword %6, %7, 0x180\n\ts_waitcnt lgkmcnt(0)" : "=s"(d0), "=s"(d1), "=s"(d2), "=s"(d3), "=s"(d4), "=s"(d5), "=s"(d6) : "s"(ka));
+    if constexpr (LINES == 8) asm volatile("s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x40\n\ts_load_dword %2, %8, 0x80\n\ts_load_dword %3, %8, 0xc0\n\ts_load_dword %4, %8, 0x100\n\ts_load_dword %5, %8, 0x140\n\ts_load_dword %6, %8, 0x180\n\ts_load_dword %7, %8, 0x1c0\n\ts_waitcnt lgkmcnt(0)" : "=s"(d0), "=s"(d1), "=s"(d2), "=s"(d3), "=s"(d4), "=s"(d5), "=s"(d6), "=s"(d7) : "s"(ka));
+#endif
+}
+
 template <int DT> struct Elem;
 template <> struct Elem<MQ_F16> {
     typedef unsigned short T;

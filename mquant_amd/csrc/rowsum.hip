@@ -20,6 +20,7 @@ struct RsArgs {
 
 __global__ __launch_bounds__(256) void act_rowsum_kernel(RsArgs p)
 {
+    kernarg_warm<sizeof(RsArgs)>();
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.M) return;

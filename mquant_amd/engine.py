@@ -227,6 +227,14 @@ class W4A8Linear:
                              s_x1=self.s_x1, row_sel=row_sel, bias=self.bias, x0=x0, w0=w0,
                              out_dtype=out_dtype, out=out)
 
+    def gemm_rope(self, a, cos: torch.Tensor, sin: torch.Tensor, rope_cols: int, out_dtype: torch.dtype,
+                  row_sel: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+        """The Linear with the rotary embedding of its first ``rope_cols`` output columns (heads of 128: the q | k part of a
+        fused q|k|v projection) folded into the GEMM's store; plain static layers only."""
+        assert not self.split and self.w_shift is None and self.w_groups is None and self.dynamic is None
+        return ops.gemm_w4a8_rope(a, self.w_img, self.w_bits, self.N, self.s_x0, self.s_w, cos, sin, rope_cols,
+                                  s_x1=self.s_x1, row_sel=row_sel, bias=self.bias, out_dtype=out_dtype, out=out)
+
     def gemm_residual(self, a: torch.Tensor, x0: Optional[torch.Tensor], residual: torch.Tensor,
                       row_sel: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
         """residual + Linear in one launch (same rounding as torch's `hidden + linear(x)`)."""

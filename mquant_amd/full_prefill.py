@@ -79,6 +79,8 @@ class FullPrefill:
         self.attn_quant = own
         self.attn_kernel = own and self.g.head_dim == 128
         self.vis_attn_kernel = own and self.g.vis_dim // self.g.vis_heads in (80, 128)      # the vision tower's (non-causal) attention
+        #: the decoder's RoPE rides in the q|k|v GEMM's store (mq_gemm_w4a8_rope_ws) instead of its own launch (round 5)
+        self.rope_fused = fused_glue
         self.kv_cache: List[torch.Tensor] = []
         self.kv_scales: List[torch.Tensor] = []
         assert pf.share_groups, "the chained prefill uses the fused q/k/v and gate/up GEMMs"
@@ -210,9 +212,19 @@ class FullPrefill:
         T = hdn.shape[0]
         kv = KVH * HD
         for i in range(len(by["llm.q_proj"])):
-            qkv = self._norm_lin(by["llm.q_proj"][i], hdn, D)      # fused q|k|v GEMM
+            Lq = by["llm.q_proj"][i]
+            rope_in_gemm = (self.fused_glue and self.rope_fused and not self.calibrating and HD == 128 and Lq.lin.had is None
+                            and not Lq.lin.split and Lq.lin.dynamic is None and Lq.lin.w_shift is None and Lq.lin.w_groups is None
+                            and self.dtype in (torch.float16, torch.bfloat16))
+            if rope_in_gemm:
+                # RMS norm -> quantize (one launch), then the fused q|k|v GEMM whose q | k heads leave the store rotated
+                a, _ = Lq.lin.quantize_rmsn(hdn, D, 1e-6, Lq.row_sel)
+                qkv = Lq.lin.gemm_rope(a, self.lcos2, self.lsin2, D + kv, self.dtype, Lq.row_sel)
+            else:
+                qkv = self._norm_lin(Lq, hdn, D)                   # fused q|k|v GEMM
             if self.fused_glue:
-                ops.rope_inplace(qkv[:, :D + kv], H + KVH, HD, self.lcos2, self.lsin2)
+                if not rope_in_gemm:
+                    ops.rope_inplace(qkv[:, :D + kv], H + KVH, HD, self.lcos2, self.lsin2)
                 q = qkv[:, :D].view(T, H, HD)
                 k = qkv[:, D:D + kv].view(T, KVH, HD)
                 v = qkv[:, D + kv:].view(T, KVH, HD)

@@ -675,6 +675,25 @@ def quantize_act_group_asym_i8(x: torch.Tensor, groupsize: int, bits: int = 8, c
 
 
 @_on_device
+def gemm_w4a8_rope(a, w_img: torch.Tensor, w_bits: int, N: int, s_x0: float, s_w: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
+                   rope_cols: int, *, s_x1: Optional[float] = None, row_sel: Optional[torch.Tensor] = None,
+                   bias: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.float16,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """W4A8 Linear whose first ``rope_cols`` output columns (heads of 128) leave the GEMM already rotated
+    (``mq_gemm_w4a8_rope_ws``): bit-identical to ``gemm_w4a8`` + ``rope_inplace``.  cos / sin: [M, 128] in the output dtype."""
+    _need_cuda(a, w_img, s_w, row_sel, bias, cos, sin, out)
+    aptr, lda, M, K_pad = _a_args(a)
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=s_w.device)
+    assert cos.dtype == out.dtype and sin.dtype == out.dtype and cos.is_contiguous() and sin.is_contiguous()
+    assert tuple(cos.shape) == tuple(sin.shape) and cos.shape[-1] == 128 and cos.numel() >= M * 128
+    call("mq_gemm_w4a8_rope_ws", aptr, lda, w_img.data_ptr(), w_bits, M, N, K_pad, float(s_x0), float(s_x0 if s_x1 is None else s_x1),
+         _ptr(row_sel), s_w.data_ptr(), _ptr(bias), cos.data_ptr(), sin.data_ptr(), int(rope_cols), 128, out.data_ptr(),
+         dtype_code(out.dtype), out.stride(0), _stream())
+    return out
+
+
+@_on_device
 def gemm_w4a8_wgroupscale(a, w_img: torch.Tensor, w_bits: int, N: int, s_w_groups: torch.Tensor, group_k: int, *,
                           s_x0: float = 1.0, s_x1: Optional[float] = None, row_sel: Optional[torch.Tensor] = None,
                           s_x_rows: Optional[torch.Tensor] = None, s_x_groups: Optional[torch.Tensor] = None,

@@ -96,6 +96,11 @@ def run(name, M, N, K, G, dev):
     row("launch: first workgroup entry -> last workgroup done", dur[:, None])
     row("gap: last workgroup of launch g done -> first entry of g+1", torch.cat([gap[:1], gap])[:, None])
     row("dispatch ramp: workgroup entry after the launch's first entry", ramp)
+    row("math wave 0's entry -> loader wave 0's first instruction (wave launch order)", ns(d(3, 0)))
+    row("loader 0: first instruction -> piece addresses ready (tile map, 64-bit address arithmetic)", ns(d(14, 3)))
+    row("entry -> loader 0 has its piece addresses", ns(d(14, 0)))
+    row("   -> stage 0 requested (LPW LDS-DMA instructions)", ns(d(15, 14)))
+    row("   -> stages 1, 2 requested", ns(d(4, 15)))
     row("entry -> first 3 stages requested (loader 0: addresses + issue)", ns(d(4, 0)))
     row("requested -> stage 0 landed (loader 0's counted vmcnt)", ns(d(5, 4)))
     row("landed -> math wave 0 past B(0)", ns(d(6, 5)))
