@@ -424,3 +424,71 @@ def test_random_shapes_tiles_and_epilogues_against_the_oracle():
             np.testing.assert_array_equal(y.float().cpu().numpy(), y_ref, err_msg=tag)
     finally:
         o.gemm_debug_force(-1, 0)
+
+
+# ---- advisor findings r4 (tests/test_gpu_tiled.py): persistent ping-pong tiles past the CU count, special values in the epilogue ----
+@pytest.mark.parametrize("tile", [14, 15, 16, 17, 18, 19])
+def test_persistent_ping_pong_tiles_walk_past_the_cu_count_into_ragged_tail_tiles(tile):
+    """More work ids than CUs (the persistent loop hands a workgroup a second, third ... tile behind one barrier) with the LAST
+    m-block and the LAST n-block ragged: every output against the oracle, so a second tile that is an M- or N-tail tile
+    (different clamps, partial stores) is covered for every ping-pong instantiation."""
+    o = ops()
+    bm, bn = {14: (256, 256), 15: (128, 128), 16: (96, 128), 17: (192, 128), 18: (64, 128), 19: (128, 256)}[tile]
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    M = 2 * bm + bm // 3 + 5                                   # three m-blocks, the last one ragged
+    n_blocks = cus // 3 + 3                                     # 3 * n_blocks > CUs
+    N = (n_blocks - 1) * bn + 40                                # the last n-block holds 40 channels
+    K = 256
+    assert 3 * n_blocks > cus
+    rng = np.random.default_rng(tile)
+    a = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+    w = _levels(tile, (N, K), 4)
+    s_w = rng.uniform(0.001, 0.01, size=N).astype(np.float32)
+    bias = rng.normal(size=N).astype(np.float32)
+    acc_ref = oracle.gemm_i32(a, w)
+    at = o.TiledAct.from_rows(to_dev(a))
+    img = o.prepack(to_dev(w), 4)
+    try:
+        o.gemm_debug_force(tile, 1)
+        np.testing.assert_array_equal(o.gemm_w4a8_i32(at, img, 4, N).cpu().numpy(), acc_ref)
+        for dt in DTYPES:
+            y = o.gemm_w4a8(at, img, 4, N, 0.02, to_dev(s_w), bias=to_dev(bias), out_dtype=dt)
+            np.testing.assert_array_equal(y.float().cpu().numpy(), oracle.round_to(oracle.epilogue(acc_ref, np.float32(0.02), s_w, bias=bias), MODE[dt]))
+    finally:
+        o.gemm_debug_force(-1, 0)
+
+
+@pytest.mark.parametrize("out_dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("tile", [14, 13, 3, 26, 40, 44, 45, 46, 47, 48])
+def test_epilogue_overflow_infinity_and_nan_equal_the_oracles_rounding(out_dtype, tile):
+    """The straight-line epilogues convert with V_CVT_PK_F16_F32 / V_CVT_PK_BF16_F32 (pack2_f16 / pack2_bf16) where the
+    general loop uses the bit-trick conversions: both must agree with the oracle's round-to-nearest-even on results beyond the
+    largest finite value (-> inf), on infinities and on NaN (inf - inf through the bias, 0 x inf through the rank-1 term)."""
+    o = ops()
+    M, N, K = 70, 264, 256
+    rng = np.random.default_rng(5)
+    a = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+    w = _levels(9, (N, K), 4)
+    acc = oracle.gemm_i32(a, w)
+    big = np.float32(3.0e38 if out_dtype == torch.bfloat16 else 6.0e4) / np.float32(np.abs(acc).max())
+    s_w = np.full(N, 1.0, np.float32)
+    s_w[::3] = np.float32(1.13)                                   # some channels end beyond the largest finite value: inf after rounding
+    s_w[1::7] = np.float32(4.0)                                   # ... and some beyond fp32's for bf16 / far beyond fp16's
+    bias = np.zeros(N, np.float32)
+    bias[5] = -np.inf                                             # +inf + (-inf) -> NaN where the product overflowed, -inf elsewhere
+    bias[6] = np.inf
+    x0 = np.zeros(M, np.float32)
+    w0 = np.zeros(N, np.float32)
+    x0[3] = np.inf                                                # inf * 0 -> NaN across row 3
+    w0[10] = 1.0
+    at = o.TiledAct.from_rows(to_dev(a))
+    img = o.prepack(to_dev(w), 4)
+    want = oracle.round_to(oracle.epilogue(acc, big, s_w, bias=bias, x0=x0, w0=w0), MODE[out_dtype])
+    assert np.isinf(want).any() and np.isnan(want).any() and np.isfinite(want).any()
+    try:
+        o.gemm_debug_force(tile, 1)
+        aa = at if tile not in (3, 26) else to_dev(a)
+        y = o.gemm_w4a8(aa, img, 4, N, float(big), to_dev(s_w), bias=to_dev(bias), x0=to_dev(x0), w0=to_dev(w0), out_dtype=out_dtype)
+        np.testing.assert_array_equal(y.float().cpu().numpy(), want)
+    finally:
+        o.gemm_debug_force(-1, 0)
