@@ -171,8 +171,9 @@ def full_prefill_report(pf, dev, args):
     from mquant_amd import workload
     from mquant_amd.full_prefill import FullPrefill
     try:
-        def measure(fused):
+        def measure(fused, rope_fused=True):
             fp = FullPrefill(pf, fused_glue=fused)
+            fp.rope_fused = fused and rope_fused          # the decoder's RoPE in the q|k|v GEMM's store (round 5) or its own launch
             fp.calibrate()
             if args.no_graph:
                 run = fp.step
@@ -200,6 +201,7 @@ def full_prefill_report(pf, dev, args):
             return med, p90, len(times), bool(torch.isfinite(fp.logits.float()).all().item())
         med_u, p90_u, _, _ = measure(False)
         med, p90, iters, finite = measure(True)
+        med_rope = measure(True, rope_fused=False)[0]     # same process, same box: what the separate RoPE launch costs
         # informational: the same prefill with the NON-DEFAULT fast Hadamard stage (K x K stage on the half-precision matrix
         # core; ~1e-7 of the int8 levels differ from the exact kernel -- DESIGN 4.2).  The flag lives in the layer descriptors
         # of THIS model object (workload.set_had_fast); it is cleared again before returning, and nothing process-wide exists.
@@ -215,10 +217,12 @@ def full_prefill_report(pf, dev, args):
         return {"what": "whole synthetic prefill: W4A8 Linears (this repo's kernels) + attention (mq_attn_prefill on the q|k|v GEMM "
                         "outputs in place: decoder head_dim 128 causal, vision tower head_dim 80) and fp16 lm_head on the last position; "
                         "RMS norm -> quantize, SiLU*up / QuickGELU -> Hadamard -> quantize, residual adds (GEMM epilogue) and "
-                        "RoPE (one in-place launch) run fused; ttft_ms_median_unfused_glue = the same dataflow with those steps "
-                        "as separate torch ops and torch SDPA everywhere",
+                        "RoPE (the decoder's in the q|k|v GEMM's store, the vision tower's as one in-place launch) run fused; "
+                        "ttft_ms_median_unfused_glue = the same dataflow with those steps as separate torch ops and torch SDPA everywhere; "
+                        "ttft_ms_median_rope_as_its_own_launch = fused glue with the decoder's RoPE launched separately (round 4's form)",
                 "ttft_ms_median": round(med, 4), "ttft_ms_p90": round(p90, 4), "iters": iters,
                 "ttft_ms_median_unfused_glue": round(med_u, 4), "ttft_ms_p90_unfused_glue": round(p90_u, 4),
+                "ttft_ms_median_rope_as_its_own_launch": round(med_rope, 4),
                 "ttft_ms_median_fast_hadamard_NON_DEFAULT": None if med_fast is None else round(med_fast, 4),
                 "llm_tokens_per_s": round(workload.M_LLM / (med * 1e-3), 1),
                 "all_tokens_per_s": round((workload.M_LLM + workload.M_VIS) / (med * 1e-3), 1),
