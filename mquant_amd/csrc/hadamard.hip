@@ -135,7 +135,18 @@ __device__ __forceinline__ void had_kxk_unit(const HadArgs &p, long row, const R
     typedef Stage<DT, HALF_LDS> S;
     typedef typename S::T YT;
     constexpr int ESZ = (int)sizeof(YT);
-    const int K = p.K, m = p.m, ksteps = K / 4, JT = (K + 15) / 16;
+    const int K = p.K, m = p.m, JT = (K + 15) / 16;
+    // Zero padding (fake_quant/utils.py:465-471: down_proj 18944 -> 19968): the staged rows k >= ceil(n_in / m) are all +0 -- their
+    // inputs were pad and a butterfly of zeros is zeros -- so their k-steps add +-0 to every chain: skipped when the result is
+    // quantized (the chain's value is unchanged; only the SIGN of an exactly-zero sum could differ, and both signs are level 0).
+    // The plain transform (QUANT = false) keeps every step: its output bits include that sign.
+    const int kz = (int)((p.n_in + m - 1) >> __builtin_ctz((unsigned)m));
+#ifdef MQ_HAD_NO_PAD_SKIP
+    const int ksteps = K / 4;
+    (void)kz;
+#else
+    const int ksteps = (QUANT && (kz + 3) / 4 < K / 4) ? (kz + 3) / 4 : K / 4;
+#endif
     const int lc = lane & 15, lk = lane >> 4;
     jg = __builtin_amdgcn_readfirstlane(jg);        // wave-uniform: the mask loads below become scalar loads
     cg = __builtin_amdgcn_readfirstlane(cg);
@@ -339,7 +350,12 @@ __global__ __launch_bounds__(THREADS, HALF_LDS ? 4 : 1) void hadamard_kernel(Had
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = vb[u][i];
                 // 16-bit staging rounds on the store: st(rnd(t)) == st(t), the explicit round trip would be wasted work
+                // (a chunk that lies entirely in the zero padding stays +0 through every stage: no butterflies -- wave-uniform)
+#ifdef MQ_HAD_NO_PAD_SKIP
                 had_butterfly_chunk<DT>(v, lane, m, scale, mid_round && !HALF_LDS);
+#else
+                if (c * 512 < p.n_in) had_butterfly_chunk<DT>(v, lane, m, scale, mid_round && !HALF_LDS);
+#endif
                 if (idx < n) {   // n is a multiple of 8 here (m >= 8)
                     const int k = (int)(idx >> mshift), i0 = (int)idx & (m - 1);   // m = 2^mshift
                     char *dst = ybase + yoff(k, i0);
