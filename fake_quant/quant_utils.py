@@ -399,8 +399,6 @@ class ActQuantWrapper(torch.nn.Module):
         a_asym = (not qz.static) and not getattr(qz, "sym", False)
         if w_asym and not getattr(wq, "perchannel", False):
             return "asymmetric per-tensor weights"
-        if int(bool(self.split)) + int(w_asym) + int(a_asym) > 2:
-            return "split column + asymmetric weights + asymmetric activations (two rank-1 epilogue slots)"
         if getattr(wq, "groupsize", -1) and getattr(wq, "groupsize", -1) > 0:
             return self._weight_groups_because(wq)
         return ""

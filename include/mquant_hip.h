@@ -469,6 +469,13 @@ int mq_gemm_w4a8_rope_ws(const int8_t *a, long lda, const void *w, int w_bits, l
                          const uint8_t *row_sel, const float *s_w, const float *bias, const void *rope_cos, const void *rope_sin,
                          long rope_cols, int head_dim, void *out, int out_dtype, long ldo, void *stream);
 
+/* out[m][n] = cast(y32[m][n] + x[m] * w[n]): a THIRD rank-1 term behind mq_gemm_w4a8_rank2_ws, for a layer that combines the split
+ * column (--visual_split, quant_utils.py:367-376), asymmetric weights (--w_asym) and asymmetric dynamic activations (--a_asym): run
+ * the two-slot GEMM with out_dtype = MQ_F32, then this pass -- the sum continues in fp32 and is rounded to the output dtype once,
+ * exactly what a third epilogue slot would compute.  y32: fp32 [M, ldy]; out: [M, ldo] of out_dtype (may alias y32 for MQ_F32). */
+int mq_rank1_add_cast(const float *y32, long M, long N, long ldy, const float *x, const float *w, void *out, int out_dtype,
+                      long ldo, void *stream);
+
 /* The GEMM for group-wise WEIGHT scales (--w_groupsize g; reference fake_quant/gptq/gptq_utils.py:263-273: the GPTQ solver re-runs
  * WeightQuantizer.find_params on every group of g consecutive input channels, so channel n carries one scale per group; flag at
  * exam/quant_qwen2vl.py:327).  s_w_groups[g * N + n] = that scale.

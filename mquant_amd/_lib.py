@@ -44,6 +44,7 @@ SIGNATURES = {
     "mq_gemm_w4a8_groupscale": (_i, [_vp, _l, _vp, _i, _l, _l, _l, _vp, _l, _i, _vp, _vp, _vp, _i, _l, _vp]),
     "mq_quantize_act_group_asym_i8": (_i, [_vp, _i, _l, _l, _l, _i, _i, _f, _vp, _vp, _vp, _vp, _l, _l, _vp]),
     "mq_gemm_w4a8_groupscale_asym": (_i, [_vp, _l, _vp, _i, _l, _l, _l, _vp, _vp, _vp, _l, _i, _vp, _vp, _vp, _i, _l, _vp]),
+    "mq_rank1_add_cast": (_i, [_vp, _l, _l, _l, _vp, _vp, _vp, _i, _l, _vp]),
     "mq_gemm_w4a8_rope_ws": (_i, [_vp, _l, _vp, _i, _l, _l, _l, _f, _f, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp, _i, _l, _vp]),
     "mq_gemm_w4a8_wgroupscale": (_i, [_vp, _l, _vp, _i, _l, _l, _l, _vp, _l, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _l, _vp]),
     "mq_act_rowsum_scaled": (_i, [_vp, _l, _l, _l, _f, _f, _vp, _vp, _vp, _vp]),

@@ -44,7 +44,57 @@ __global__ __launch_bounds__(256) void act_rowsum_kernel(RsArgs p)
     }
 }
 
+// out[m][n] = cast(y32[m][n] + x[m] * w[n]): the THIRD rank-1 term of a layer that uses the split column, asymmetric weights and
+// asymmetric dynamic activations at once (the GEMM epilogue has two slots).  The GEMM runs with an fp32 output, so this pass
+// continues the epilogue's sum in fp32 and rounds to the output dtype once -- the same arithmetic a third slot would do.
+struct R1Args {
+    const float *y;
+    long M, N, ldy;
+    const float *x, *w;
+    void *out;
+    long ldo;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void rank1_add_cast_kernel(R1Args p)
+{
+    kernarg_warm<sizeof(R1Args)>();
+    typedef typename Elem<DT>::T T;
+    const long quads = (p.N + 3) / 4;
+    const long total = p.M * quads;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / quads, n = (i - m * quads) * 4;
+        const float xm = p.x[m];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (n + r >= p.N) break;
+            const float pr = xm * p.w[n + r];
+            const float v = p.y[m * p.ldy + n + r] + pr;
+            reinterpret_cast<T *>(p.out)[m * p.ldo + n + r] = Elem<DT>::st(v);
+        }
+    }
+}
+
 }  // namespace mq
+
+extern "C" int mq_rank1_add_cast(const float *y32, long M, long N, long ldy, const float *x, const float *w, void *out, int out_dtype,
+                                 long ldo, void *stream)
+{
+    using namespace mq;
+    if (M == 0 || N == 0) return MQ_OK;
+    MQ_REQUIRE(y32 && x && w && out && M > 0 && N > 0 && ldy >= N && ldo >= N, "mq_rank1_add_cast: bad arguments");
+    R1Args p{y32, M, N, ldy, x, w, out, ldo};
+    long blocks = ceil_div(M * ((N + 3) / 4), 256);
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t st = (hipStream_t)stream;
+    switch (out_dtype) {
+    case MQ_F16: hipLaunchKernelGGL(rank1_add_cast_kernel<MQ_F16>, dim3((unsigned)blocks), dim3(256), 0, st, p); break;
+    case MQ_BF16: hipLaunchKernelGGL(rank1_add_cast_kernel<MQ_BF16>, dim3((unsigned)blocks), dim3(256), 0, st, p); break;
+    case MQ_F32: hipLaunchKernelGGL(rank1_add_cast_kernel<MQ_F32>, dim3((unsigned)blocks), dim3(256), 0, st, p); break;
+    default: return fail(MQ_EINVAL, "mq_rank1_add_cast: unknown dtype %d", out_dtype);
+    }
+    return check_launch("rank1_add_cast");
+}
 
 extern "C" int mq_act_rowsum_scaled(const int8_t *a, long lda, long M, long K_pad, float s_x0, float s_x1,
                                     const uint8_t *row_sel, const float *s_x_rows, float *out, void *stream)

@@ -150,8 +150,9 @@ class W4A8Linear:
             if self.w_shift is not None:
                 kq = levels.shape[1] - (1 if self.split and not self.split_slice else 0)
                 self.w_colsum = (self.w_colsum + float(kq) * self.w_shift).contiguous()
-        n_terms = int(self.split) + int(self.w_shift is not None) + int(self.w_colsum is not None)
-        assert n_terms <= 2, "the epilogue has two rank-1 slots: split column, asymmetric weights and asymmetric activations do not fit together"
+        #: rank-1 terms of the layer: two ride in the GEMM epilogue, a third (all of split column, asymmetric weights and
+        #: asymmetric activations at once) is added by mq_rank1_add_cast behind an fp32 GEMM output
+        self.n_terms = int(self.split) + int(self.w_shift is not None) + int(self.w_colsum is not None)
         self.in_features = self.K if in_features is None else in_features
         if had is not None:
             assert had.n == self.K + (1 if self.split_slice else 0), "Hadamard size must equal the (padded) reduction dim"
@@ -295,6 +296,12 @@ class W4A8Linear:
             terms.append((shift, self.w_colsum))
         if self.w_shift is not None:
             terms.append((ops.act_rowsum_scaled(a, s_x_rows=s_rows), self.w_shift))
+        if len(terms) == 3:
+            # split column + asymmetric activations + asymmetric weights: two terms in the epilogue (fp32 result), the third
+            # added behind it in fp32 and rounded once -- what a third epilogue slot would compute
+            y32 = ops.gemm_w4a8_rank2(a, self.w_img, self.w_bits, self.N, self.s_w, terms[0][0], terms[0][1], terms[1][0],
+                                      terms[1][1], s_x_rows=s_rows, bias=self.bias, out_dtype=torch.float32)
+            return ops.rank1_add_cast(y32, terms[2][0], terms[2][1], x2.dtype, out=out)
         if len(terms) == 2:
             return ops.gemm_w4a8_rank2(a, self.w_img, self.w_bits, self.N, self.s_w, terms[0][0], terms[0][1], terms[1][0],
                                        terms[1][1], s_x_rows=s_rows, bias=self.bias, out_dtype=x2.dtype, out=out)

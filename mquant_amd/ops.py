@@ -835,6 +835,20 @@ def gemm_w4a8_rank2(a: torch.Tensor, w_img: torch.Tensor, w_bits: int, N: int, s
 
 
 @_on_device
+def rank1_add_cast(y32: torch.Tensor, x: torch.Tensor, w: torch.Tensor, out_dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """cast(y32 + x[m] * w[n]) (``mq_rank1_add_cast``): the third rank-1 term behind ``gemm_w4a8_rank2(..., out_dtype=float32)``."""
+    _need_cuda(y32, x, w, out)
+    M, N = y32.shape
+    assert y32.dtype == torch.float32 and y32.stride(1) == 1 and x.dtype == torch.float32 and w.dtype == torch.float32
+    assert x.numel() == M and w.numel() == N and x.is_contiguous() and w.is_contiguous()
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=y32.device)
+    call("mq_rank1_add_cast", y32.data_ptr(), M, N, y32.stride(0), x.data_ptr(), w.data_ptr(), out.data_ptr(), dtype_code(out.dtype),
+         out.stride(0), _stream())
+    return out
+
+
+@_on_device
 def gemm_w4a8_residual(a: torch.Tensor, w_img: torch.Tensor, w_bits: int, N: int, s_x0: float, s_w: torch.Tensor,
                        residual: torch.Tensor, *, s_x1: Optional[float] = None, row_sel: Optional[torch.Tensor] = None,
                        bias: Optional[torch.Tensor] = None, x0: Optional[torch.Tensor] = None,

@@ -170,6 +170,7 @@ V2_MODES = {
     "dyn_asym": dict(act=dict(sym=False)),
     "dyn_asym_w_asym": dict(act=dict(sym=False), w_asym=True),
     "dyn_asym_split": dict(act=dict(sym=False), split=True, bias=False),
+    "dyn_asym_w_asym_split_had": dict(act=dict(sym=False), w_asym=True, split=True, had=True),     # all three rank-1 terms
     "dyn_per_tensor_sym": dict(act=dict(sym=True, per_tensor=True)),
     "dyn_per_tensor_asym": dict(act=dict(sym=False, per_tensor=True)),
     "dyn_a6": dict(act=dict(sym=True, bits=6)),

@@ -140,7 +140,8 @@ def test_wrapper_asymmetric_dynamic_mode_matches_reference_forward(golden_dir, c
     np.testing.assert_array_equal(a.cpu().numpy()[:, :64], g["qx_head"])
     np.testing.assert_array_equal(ops.gemm_w4a8_i32(a, real.w_img, 4, N).cpu().numpy(), g["acc"])
     # a split wrapper runs the integer kernels in this mode too (two rank-1 epilogue slots, tests/test_gpu_rank2.py); split
-    # column + asymmetric weights + asymmetric activations would need three and stays simulated
+    # column + asymmetric weights + asymmetric activations need three: since round 5 the third is added behind an fp32 GEMM output
+    # (mq_rank1_add_cast; goldens wrapper_rank2_all3_*), and the result stays on the simulated evaluation of the same wrapper
     wrap2 = qu.ActQuantWrapper(torch.nn.Linear(256, 32).to(DEV))
     wrap2.split = True
     wrap2.split_weights()
@@ -152,8 +153,13 @@ def test_wrapper_asymmetric_dynamic_mode_matches_reference_forward(golden_dir, c
     wrap3.split_weights()
     rtn_module(wrap3, "layer", 4, False, False, [], {})
     wrap3.quantizer.configure(bits=8, sym=False)
-    assert not wrap3._real_ready(torch.zeros(4, 256, device=DEV))
-    assert torch.isfinite(wrap3(torch.from_numpy(make_x(3, (4, 256))).to(DEV))).all()
+    assert wrap3._real_ready(torch.zeros(4, 256, device=DEV)) and wrap3.backend().startswith("W4A8 integer")
+    x3 = torch.from_numpy(make_x(3, (4, 256))).to(DEV)
+    y3 = wrap3(x3)
+    assert wrap3._real is not None and wrap3._real.n_terms == 3
+    wrap3.real_quant = False
+    y3_sim = wrap3(x3.clone())
+    np.testing.assert_allclose(y3.cpu().numpy(), y3_sim.cpu().numpy(), rtol=0, atol=1e-3 * float(y3_sim.abs().max()))
 
 
 @pytest.mark.parametrize("M,K,dtype,bits,clip,asym,skip", [(768, 3584, torch.float16, 8, 1.0, False, False), (33, 1000, torch.float16, 8, 0.9, True, False),

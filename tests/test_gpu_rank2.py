@@ -99,7 +99,7 @@ def test_wrapper_runs_the_two_slot_combinations_on_the_integer_path(path):
     real = wrap._real
     assert real is not None
     n_terms = int(real.split) + int(real.w_shift is not None) + int(real.w_colsum is not None)
-    assert n_terms == 2, path
+    assert n_terms == int(bool(split)) + int(not w_sym) + int(act in ("dyn_asym", "pt_asym")) and n_terms in (2, 3), path
     np.testing.assert_allclose(y.cpu().numpy(), g["y"], rtol=0, atol=1e-3)
     # the integers of the kernels that ran
     xp = torch.nn.functional.pad(x, (0, K_pad - K_in)) if K_pad != K_in else x
@@ -121,3 +121,26 @@ def test_wrapper_runs_the_two_slot_combinations_on_the_integer_path(path):
         lv = lvq[:, :xq.shape[1]]
     np.testing.assert_array_equal(lv[:, :64].cpu().numpy(), g["qx_head"])
     np.testing.assert_array_equal(lv.to(torch.int64).sum(dim=1).cpu().numpy(), g["qx_sum"])
+
+
+@pytest.mark.parametrize("out_dtype", [torch.float16, torch.bfloat16, torch.float32])
+def test_third_rank1_term_behind_an_fp32_gemm_equals_the_oracle(out_dtype):
+    """mq_rank1_add_cast: cast(y32 + x2[m] * w2[n]) continues the epilogue's fp32 sum and rounds once."""
+    from mquant_amd import ops
+    rng = np.random.default_rng(7)
+    M, N, K = 130, 264, 640
+    a = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+    w = rng.integers(-8, 8, size=(N, K), dtype=np.int8)
+    s_w = rng.uniform(0.001, 0.01, size=N).astype(np.float32)
+    bias = rng.normal(size=N).astype(np.float32)
+    xs = [rng.normal(size=M).astype(np.float32) for _ in range(3)]
+    ws = [rng.normal(size=N).astype(np.float32) for _ in range(3)]
+    s_rows = rng.uniform(0.01, 0.05, size=M).astype(np.float32)
+    want = oracle.epilogue(oracle.gemm_i32(a, w), s_rows, s_w, bias=bias, x0=xs[0], w0=ws[0], x1=xs[1], w1=ws[1])
+    want = (want + (xs[2].reshape(-1, 1) * ws[2][None, :]).astype(np.float32)).astype(np.float32)
+    at = ops.TiledAct.from_rows(dev(a))
+    img = ops.prepack(dev(w), 4)
+    y32 = ops.gemm_w4a8_rank2(at, img, 4, N, dev(s_w), dev(xs[0]), dev(ws[0]), dev(xs[1]), dev(ws[1]), s_x_rows=dev(s_rows), bias=dev(bias),
+                              out_dtype=torch.float32)
+    y = ops.rank1_add_cast(y32, dev(xs[2]), dev(ws[2]), out_dtype)
+    np.testing.assert_array_equal(y.float().cpu().numpy(), oracle.round_to(want, MODE[out_dtype]))

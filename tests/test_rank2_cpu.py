@@ -44,7 +44,7 @@ def rank1_terms(g, s_rows, zero, qx_sum, qw_sum, Kq, w_sym, a_asym, split):
 
 
 def test_there_are_goldens(golden_dir):
-    assert len(rank2_cases(golden_dir)) == 7
+    assert len(rank2_cases(golden_dir)) == 9                     # 7 two-term combinations + 2 with all three terms (round 5)
 
 
 @pytest.mark.parametrize("path", rank2_cases(os.path.join(os.path.dirname(__file__), "golden")))
@@ -90,7 +90,9 @@ def test_two_rank1_terms_reproduce_the_reference_forward(had_table, path):
     np.testing.assert_array_equal(acc, g["acc"])
     np.testing.assert_array_equal(q.astype(np.int64).sum(axis=1), g["qx_sum"])
     terms = rank1_terms(g, s_rows, zero, g["qx_sum"], g["qw_sum"], xq.shape[1], bool(w_sym), a_asym, bool(split))
-    assert len(terms) == 2, path
+    assert len(terms) == int(bool(split)) + int(not w_sym) + int(a_asym) and len(terms) in (2, 3), path
     b = make_w(seed + 1, (N,), std=0.1) if bias else None
     y = oracle.epilogue(acc, s_rows, s_w, bias=b, x0=terms[0][0], w0=terms[0][1], x1=terms[1][0], w1=terms[1][1])
+    if len(terms) == 3:        # the third term continues the fp32 sum (mq_rank1_add_cast behind the two-slot GEMM)
+        y = (y + (terms[2][0].reshape(-1, 1) * terms[2][1][None, :]).astype(np.float32)).astype(np.float32)
     np.testing.assert_allclose(y, g["y"], rtol=0, atol=1e-3)

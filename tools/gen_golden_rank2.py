@@ -28,6 +28,10 @@ CASES = {
     "wasym_ptasym_1280": (1280, 1280, 40, 24, 2140, False, False, True, False, "pt_asym"),
     "aasym_split_had_5120": (5120, 5120, 32, 12, 2150, True, True, True, True, "dyn_asym"),
     "ptasym_split_2048": (2048, 2048, 32, 10, 2160, False, True, False, True, "pt_asym"),
+    # round 5: all THREE rank-1 terms at once (split column + asymmetric weights + asymmetric activations): two ride in the GEMM
+    # epilogue, the third is added behind an fp32 output (mq_rank1_add_cast)
+    "all3_had_5120": (5120, 5120, 32, 12, 2170, True, True, True, False, "dyn_asym"),
+    "all3_pt_1280": (1280, 1280, 40, 16, 2180, False, True, False, False, "pt_asym"),
 }
 
 
