@@ -397,8 +397,8 @@ class ActQuantWrapper(torch.nn.Module):
             return "weight bits %d" % wq.bits
         w_asym = not getattr(wq, "sym", False)
         a_asym = (not qz.static) and not getattr(qz, "sym", False)
-        if w_asym and not getattr(wq, "perchannel", False):
-            return "asymmetric per-tensor weights"
+        # (per-tensor weight quantizers -- perchannel=False, no driver uses them -- repeat their one scale / zero point per output
+        #  channel, quant_utils.py:507-509 upstream: they take the per-channel path unchanged, symmetric or not)
         if getattr(wq, "groupsize", -1) and getattr(wq, "groupsize", -1) > 0:
             return self._weight_groups_because(wq)
         return ""

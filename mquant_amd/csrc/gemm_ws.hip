@@ -800,6 +800,8 @@ int dispatch_ws(const GemmArgs &p, int tile, hipStream_t st)
     case 47: return launch_ws<64, 128, 1, 4, 4, (W_BITS == 4 ? 8 : 6), W_BITS, EPI, 1>(p, st);
     // 96 x 128 with TWO math waves per SIMD (48 x 32 per wave): the 16x16x64 form issues at full rate from two waves
     case 48: return launch_ws<96, 128, 2, 4, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI, 1>(p, st);
+    // (a 32 x 128 tile -- 320 workgroups for the ViT's 1024 x 1280 outputs instead of 160, two per CU -- was measured in round 5
+    //  and is not faster: proj 9.68 against 9.73 us, fc2 14.8 against 13.4, profiles/r5_ws_tile_32x128.txt; not instantiated)
     default: break;
     }
     return fail(MQ_EINVAL, "gemm_ws: unknown tile %d", tile);

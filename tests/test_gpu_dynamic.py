@@ -301,3 +301,33 @@ def test_wrapper_per_tensor_mode_on_half_activations_runs_the_reference_grid(gol
     lv = a.cpu().numpy()[:, 1 if split else 0:K_pad]
     np.testing.assert_array_equal(lv, g["qx"])
     np.testing.assert_array_equal(ops.gemm_w4a8_i32(a, real.w_img, 4, N).cpu().numpy(), g["acc"])
+
+
+@pytest.mark.parametrize("w_sym", [True, False])
+@pytest.mark.parametrize("act", ["static", "dyn_sym", "dyn_asym"])
+def test_per_tensor_weight_quantizers_take_the_integer_path(w_sym, act):
+    """WeightQuantizer(perchannel=False) repeats its one (scale, zero point) per output channel (reference quant_utils.py:507-509), so
+    the per-channel kernels serve it unchanged -- also with asymmetric levels (round 5; it used to simulate)."""
+    from fake_quant import quant_utils as qu
+    K, N, M = 640, 72, 33
+    lin = torch.nn.Linear(K, N, bias=True)
+    lin.weight.data = torch.from_numpy(make_w(11, (N, K)))
+    wrap = qu.ActQuantWrapper(lin.to(DEV))
+    wq = qu.WeightQuantizer()
+    wq.configure(4, perchannel=False, sym=w_sym, mse=False)
+    wq.find_params(wrap.module.weight.data)
+    wrap.module.weight.data = wq.quantize(wrap.module.weight.data)
+    qu.attach_weight_quantizer(wrap, "module", wq)
+    assert wq.scale.numel() == N and float(wq.scale.min()) == float(wq.scale.max())
+    if act == "static":
+        wrap.quantizer.configure(bits=8, sym=True, static=True, observer_type="minmax")
+        qu.calib_layer(wrap, [torch.from_numpy(make_x(20 + i, (M, K))).to(DEV) for i in range(2)])
+    else:
+        wrap.quantizer.configure(bits=8, sym=act == "dyn_sym")
+    x = torch.from_numpy(make_x(30, (M, K))).to(DEV)
+    assert wrap._real_ready(x), wrap.backend()
+    y = wrap(x)
+    assert wrap._real is not None and (wrap._real.w_shift is None) == w_sym
+    wrap.real_quant = False
+    y_sim = wrap(x.clone())
+    np.testing.assert_allclose(y.cpu().numpy(), y_sim.cpu().numpy(), rtol=0, atol=1e-3 * float(y_sim.abs().max()))
