@@ -22,6 +22,13 @@ __device__ __forceinline__ void dma16_s(const char *uniform_base, unsigned lane_
                  :: "s"(uniform_base), "v"(lane_off), "s"(lds_wave_base) : "memory");
 }
 
+// One fp32 per lane (group scales of the wave-specialised fold): lane l's word lands at lds_wave_base + 4 l.
+__device__ __forceinline__ void dma4_s(const char *uniform_base, unsigned lane_off, unsigned lds_wave_base)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0"
+                 :: "s"(uniform_base), "v"(lane_off), "s"(lds_wave_base) : "memory");
+}
+
 enum { EPI_F16 = MQ_F16, EPI_BF16 = MQ_BF16, EPI_F32 = MQ_F32, EPI_I32 = 3 };
 
 struct GemmArgs {

@@ -34,6 +34,8 @@ template <int W_BITS, int EPI>
 int dispatch_ws(const GemmArgs &p, int tile, hipStream_t st);   // gemm_ws.hip (tiled activations only)
 template <int EPI>
 int launch_gemm_pp(const GemmArgs &p, int tile, hipStream_t st);   // gemm_pp.hip (ping-pong kernels, W4, tiled activations)
+template <int W_BITS, int EPI>
+int dispatch_ws_wgroup(const GemmArgs &p, int tile, hipStream_t st);   // gemm_ws.hip (weight-group fold in the 16x16x64 math loop)
 
 // GROUPED (--a_groupsize): the int32 accumulators of one activation group (64 or a multiple of 128 k) are scaled by
 // the group's activation scale of their row and added to fp32 accumulators in ascending group order; the epilogue
@@ -678,6 +680,24 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
         auto al = [](const void *q) { return q == nullptr || ((uintptr_t)q) % 16 == 0; };
         p.par_ok = al(s_w) && al(bias) && al(w0);
         hipStream_t gst = (hipStream_t)stream;
+        if (a_tiled && !shift_groups && (!sw_groups || (N % 4 == 0 && ((uintptr_t)sw_groups) % 16 == 0)) && g_force_tile != 26) {
+            // symmetric group scales (weights, activations or both) on tiled activations, groups of 64 or of whole k-steps: the fold rides in the
+            // wave-specialised 16x16x64 kernels (5.5-9 x faster than the round-1 kernel below, profiles/r5_wgroup_gemm_*.txt);
+            // mq_gemm_debug_force(26) keeps the round-1 kernel for A/B
+            const Plan gpl = make_plan(M, N, K_pad, false, 0, g_force_tile, 0, w_bits == 4, true, true);
+            if (w_bits == 4) {
+                switch (epi) {
+                case EPI_F16: return dispatch_ws_wgroup<4, EPI_F16>(p, gpl.tile, gst);
+                case EPI_BF16: return dispatch_ws_wgroup<4, EPI_BF16>(p, gpl.tile, gst);
+                default: return dispatch_ws_wgroup<4, EPI_F32>(p, gpl.tile, gst);
+                }
+            }
+            switch (epi) {
+            case EPI_F16: return dispatch_ws_wgroup<8, EPI_F16>(p, gpl.tile, gst);
+            case EPI_BF16: return dispatch_ws_wgroup<8, EPI_BF16>(p, gpl.tile, gst);
+            default: return dispatch_ws_wgroup<8, EPI_F32>(p, gpl.tile, gst);
+            }
+        }
         if (w_bits == 4) {
             switch (epi) {
             case EPI_F16: return launch_gemm<128, 128, 2, 4, 3, 4, EPI_F16, 1, true>(p, gst);

@@ -22,6 +22,8 @@
 //   B(it+1):  stage it+1 has landed; every math wave has finished step it-1, so the slot of stage
 //             it-1 is free and the loaders refill it with stage it-1+S
 //   math, step it:  B(it+1) | read (it, kt1) | MFMA (it, kt0) | read (it+1, kt0) | MFMA (it, kt1)
+#include <type_traits>
+
 #include "gemm_common.h"
 
 namespace mq {
@@ -30,9 +32,20 @@ namespace mq {
 // package power limit the 16x16x64 form sustains 15 % more int8 ops per watt on random operands, 3.82 against 3.32 POP/s in the
 // register-only burn of tools/probes/clock_recon.hip; its accumulator tile is a quarter of the 32x32 one, half the accumulator
 // register traffic per MAC).
-template <int BM, int BN, int MW_M, int MW_N, int NL, int S, int W_BITS, int EPI, int MF = 0>
+// WG (MF == 1 only), a bit set: 1 = group-wise WEIGHT scales (--w_groupsize g; GemmArgs::sw_groups, reference
+// gptq/gptq_utils.py:263-273), 2 = group-wise ACTIVATION scales (--a_groupsize g; GemmArgs::sx_groups, quant_utils.py:181-203), 3 = both
+// with the same g (64 or a multiple of 128).  After the k-tiles of a group the math waves fold
+// (float(acc) * s_xg[row][group]) * s_wg[group][channel] into fp32 accumulators (ascending groups, one rounding per product and per
+// sum -- oracle orc_gemm_wgroup / the restated arithmetic of tests/test_gpu_groupwise.py) and the epilogue receives the float bits
+// and applies what is left (row scale, or s_w[n]).  The scales of a group are requested two groups ahead.
+#ifndef MQ_WS_WG_ABL
+#define MQ_WS_WG_ABL 0   // timing-only ablations of the group fold (wrong results): 4 no fold intervals (every interval plain), 8 no scale DMAs
+#endif
+
+template <int BM, int BN, int MW_M, int MW_N, int NL, int S, int W_BITS, int EPI, int MF = 0, int WG = 0>
 __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmArgs p)
 {
+    static_assert(WG == 0 || MF == 1, "the weight-group fold lives in the 16x16x64 math loop");
     // Math waves: MW_M x MW_N wave tiles of (BM / MW_M) x (BN / MW_N), one or two per SIMD.  (A second group of
     // math waves working the K = 32 sub-steps of the other parity, and wide 96 x 64 / 64 x 64 wave tiles, were
     // built in round 2, exact, and no faster on any model shape -- DESIGN 4.1; they are not in the tree any more.)
@@ -43,9 +56,16 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
     constexpr int A_PIECES = (BM / 16) * 2;         // 1 KiB pieces per stage (two k-tiles)
     constexpr int W_PIECES = (W_BITS == 4) ? (BN / 32) * 2 : (BN / 16) * 2;
     constexpr int PIECES = A_PIECES + W_PIECES;
-    constexpr int LPW = PIECES / NL;                // LDS-DMA instructions per loader wave per stage
+    // Group scales (WG): every stage carries three 1 KiB scale blocks behind its pieces -- [128 weight scales | 128 activation scales]
+    // of (A) the group that ended with the previous stage, (B) groups of 64: the group of this stage's first k-tile, (C) the group of
+    // this stage's last k-tile -- one fp32 per lane and loader wave (NL = 4 quarters of a block), so the math waves find the scales of
+    // a fold in the stage they are working on, as far ahead of their use as the operands themselves.
+    constexpr int SC_BLOCKS = (WG && !(MQ_WS_WG_ABL & 8)) ? 3 : 0;
+    constexpr int LPW = PIECES / NL + SC_BLOCKS;    // LDS-DMA instructions per loader wave per stage
     constexpr int A_BYTES = A_PIECES * 1024;
-    constexpr int STAGE = PIECES * 1024;
+    constexpr int SC_OFF = PIECES * 1024;
+    constexpr int STAGE = PIECES * 1024 + SC_BLOCKS * 1024;
+    static_assert(WG == 0 || (NL == 4 && BN == 128 && BM <= 128), "scale blocks: four loader waves, 128 channels, at most 128 rows");
     constexpr int RING = S * STAGE;
     constexpr int PITCH = BN * 4 + 16;              // epilogue slab row pitch (bytes)
     static_assert(MF == 1 ? (BM % (MW_M * 16) == 0 && BN % (MW_N * 16) == 0) : (BM % (MW_M * 32) == 0 && BN % (MW_N * 32) == 0), "tile shape");
@@ -127,9 +147,10 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
         __builtin_amdgcn_s_setprio(2);               // a loader's few instructions go ahead of the math waves' streams
         const long KT = p.K_pad >> 6, MT = (p.M + 15) >> 4;
         // piece f of a stage: wave-uniform base (SGPRs) + lane * 16
-        const char *src[LPW];
+        constexpr int LPP = PIECES / NL;             // pieces per loader wave and stage
+        const char *src[LPP];
 #pragma unroll
-        for (int i = 0; i < LPW; ++i) {
+        for (int i = 0; i < LPP; ++i) {
             const int f = lw + i * NL;
             if (f < A_PIECES) {
                 long mt = m0 / 16 + (f >> 1);
@@ -149,10 +170,53 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
         }
         const unsigned lane_off = lane * 16;
         const unsigned lds0 = (unsigned)(size_t)(lds_void *)smem;
+        // scale blocks: loader wave 0 / 1 = weight scales of channels n0 + lane (+ 64), wave 2 / 3 = activation scales of rows m0 + lane (+ 64)
+        const char *sc_base = nullptr;
+        long sc_stride = 0;                          // bytes from one group to the next
+        unsigned sc_voff = 0;
+        int sc_q = 0, sc_r = 0;                      // stage st = k-step st: group st / gsteps, k-step sc_r of it (groups of >= 128)
+        const int sc_gsteps = (WG && p.group_k >= 128) ? (p.group_k >> 7) : 1;
+        if (WG) {
+            const bool use_w = lw < 2 ? (WG & 1) != 0 : (WG & 2) == 0;
+            if (use_w) {                                          // weight scales (also the filler of waves 2 / 3 without activation groups)
+                long nn = n0 + (lw & 1) * 64 + lane;
+                if (nn >= p.N) nn = p.N - 1;
+                sc_base = reinterpret_cast<const char *>(p.sw_groups);
+                sc_stride = p.N * 4;
+                sc_voff = (unsigned)(nn * 4);
+            } else {                                              // activation scales (also the filler of waves 0 / 1 without weight groups)
+                long row = m0 + (lw & 1) * 64 + lane;
+                if (row >= p.M) row = p.M - 1;
+                sc_base = reinterpret_cast<const char *>(p.sx_groups);
+                sc_stride = 4;
+                sc_voff = (unsigned)(row * p.n_groups * 4);
+            }
+        }
         auto issue = [&](int slot, int st) {
             const unsigned base = lds0 + slot * STAGE;
 #pragma unroll
-            for (int i = 0; i < LPW; ++i) dma16_s(src[i] + (long)st * 2048, lane_off, base + (lw + i * NL) * 1024);
+            for (int i = 0; i < LPP; ++i) dma16_s(src[i] + (long)st * 2048, lane_off, base + (lw + i * NL) * 1024);
+            if (WG && SC_BLOCKS) {                   // stages are issued in ascending order: (sc_q, sc_r) follow st
+                long ga, gb, gc;
+                if (p.group_k == 64) {
+                    ga = 2L * st - 1; gb = 2L * st; gc = 2L * st + 1;
+                } else {
+                    ga = sc_q - 1; gb = sc_q; gc = sc_q;
+                    if (++sc_r == sc_gsteps) { sc_r = 0; ++sc_q; }
+                }
+                const long gl = p.n_groups - 1;
+                ga = ga < 0 ? 0 : (ga > gl ? gl : ga);
+                gb = gb > gl ? gl : gb;
+                gc = gc > gl ? gl : gc;
+                auto uni = [](const char *q) {      // wave-uniform by construction; tell the compiler (the DMA takes its base in SGPRs)
+                    const unsigned long long v = (unsigned long long)q;
+                    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+                    return reinterpret_cast<const char *>(((unsigned long long)hi << 32) | lo);
+                };
+                dma4_s(uni(sc_base + ga * sc_stride), sc_voff, base + SC_OFF + lw * 256);
+                dma4_s(uni(sc_base + gb * sc_stride), sc_voff, base + SC_OFF + 1024 + lw * 256);
+                dma4_s(uni(sc_base + gc * sc_stride), sc_voff, base + SC_OFF + 2048 + lw * 256);
+            }
         };
         auto wait_younger = [&](int younger) {      // at most `younger` stages may still be in flight
 #define MQ_WS_WAIT(k) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((k) * LPW < 64 ? (k) * LPW : 0) : "memory")
@@ -234,14 +298,16 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
             const int tn = tid < BN ? tid : BN - 1, tm = tid < BM ? tid : BM - 1;
             const long nc = n0 + tn < p.N ? n0 + tn : p.N - 1;
             const long mc = m0 + tm < p.M ? m0 + tm : p.M - 1;
-            pr_sw = p.s_w[nc];
-            pr_bs = (p.bias ? p.bias : p.s_w)[nc];
-            pr_wz = (p.w0 ? p.w0 : p.s_w)[nc];
-            pr_sx = (p.sx_vec ? p.sx_vec : p.s_w)[p.sx_vec ? mc : 0];
-            pr_xz = (p.x0 ? p.x0 : p.s_w)[p.x0 ? mc : 0];
-            pr_w1 = (p.w1 ? p.w1 : p.s_w)[nc];
-            pr_x1 = (p.x1 ? p.x1 : p.s_w)[p.x1 ? mc : 0];
-            pr_rs = (p.row_sel ? p.row_sel : reinterpret_cast<const uint8_t *>(p.s_w))[p.row_sel ? mc : 0];
+            // (dummy: any readable fp32 array for the parameters that are absent -- with weight groups s_w itself is absent)
+            const float *dm = (WG & 1) ? p.sw_groups : p.s_w;
+            pr_sw = (WG & 1) ? 1.0f : p.s_w[nc];                         // weight groups: the scales were applied group by group, x 1.0 is exact
+            pr_bs = (p.bias ? p.bias : dm)[p.bias ? nc : 0];
+            pr_wz = (p.w0 ? p.w0 : dm)[p.w0 ? nc : 0];
+            pr_sx = (p.sx_vec ? p.sx_vec : dm)[p.sx_vec ? mc : 0];
+            pr_xz = (p.x0 ? p.x0 : dm)[p.x0 ? mc : 0];
+            pr_w1 = (p.w1 ? p.w1 : dm)[p.w1 ? nc : 0];
+            pr_x1 = (p.x1 ? p.x1 : dm)[p.x1 ? mc : 0];
+            pr_rs = (p.row_sel ? p.row_sel : reinterpret_cast<const uint8_t *>(dm))[p.row_sel ? mc : 0];
         }
         if constexpr (MF == 1) {
             // ---- V_MFMA_I32_16X16X64_I8: one interval per 64-wide k-tile t (two per stage, so every register-set index below
@@ -253,6 +319,23 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
             for (int i = 0; i < TN16; ++i)
 #pragma unroll
                 for (int j = 0; j < TM16; ++j) acc16[i][j] = v4i{0, 0, 0, 0};
+            // Group scales: int32 -> fp32 WITHOUT v_cvt.  A group's first MFMA starts from C = 0x4B400000 (the bits of 1.5 * 2^23) in every
+            // element; while |accumulator| <= 2^22 (groups of <= 256 k: 256 * 128 * 8 * 16 = 2^22) the accumulator's bits read as a float
+            // are EXACTLY 12582912 + sum, and one packed subtraction per two elements returns float(sum) -- exact, like the conversion.
+            // Larger groups (rare, one fold per >= 4 k-steps) convert with v_cvt_f32_i32 after the group's last k-step.
+            // (W4: the levels sit in the high nibble, the accumulators are 16 x the sum -- the bias 1.5 * 2^19 has an ulp of 1/16, so the
+            //  subtraction returns sum / 16 directly and the scales are used as they come)
+            constexpr int MAGIC_BITS = (W_BITS == 4) ? 0x49400000 : 0x4B400000;
+            constexpr float MAGIC_F = (W_BITS == 4) ? 786432.0f : 12582912.0f;
+            const bool magic = WG && p.group_k <= 256;
+            const int c0 = magic ? MAGIC_BITS : 0;
+            const v4i cinit = v4i{c0, c0, c0, c0};
+            if (WG) {
+#pragma unroll
+                for (int i = 0; i < TN16; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM16; ++j) acc16[i][j] = cinit;
+            }
             v4i X[2][TM16], WU[2][TN16], F[2][TN16];       // F: W4 uses the first two words
             auto rd_x = [&](int set, int slot, int kt) {
                 const char *xs = smem + slot * STAGE + kt * 1024 + lane * 16;
@@ -273,6 +356,34 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
                     }
                 }
             };
+            auto rd_x_part = [&](int set, int slot, int kt, int j) {
+                const char *xs = smem + slot * STAGE + kt * 1024 + lane * 16;
+                X[set][j] = *reinterpret_cast<const v4i *>(xs + (wm * TM16 + j) * 2048);
+            };
+            auto rd_w_part = [&](int set, int slot, int kt, int item) {      // W4: channel tiles 2 item, 2 item + 1 (one 16-byte read)
+                const char *ws = smem + slot * STAGE + A_BYTES + kt * 1024 + lane * 16;
+                if (W_BITS == 4) {
+#pragma unroll
+                    for (int i = 2 * item; i < 2 * item + 2 && i < TN16; ++i) {
+                        const int nt = wn * TN16 + i;
+                        const v2i pk = *reinterpret_cast<const v2i *>(ws + (nt >> 1) * 2048 + (nt & 1) * 8);
+                        F[set][i][0] = pk[0];
+                        F[set][i][1] = pk[1];
+                    }
+                } else {
+                    F[set][item] = *reinterpret_cast<const v4i *>(ws + (wn * TN16 + item) * 2048);
+                }
+            };
+            auto unpack16_part = [&](int set, int part) {                    // half a channel tile: 3 vector-ALU instructions
+                const int i = part >> 1, h = part & 1;
+                if (W_BITS == 4) {
+                    const int w = F[set][i][h];
+                    WU[set][i][2 * h] = (w << 4) & 0xF0F0F0F0;
+                    WU[set][i][2 * h + 1] = w & 0xF0F0F0F0;
+                } else if (h == 0) {
+                    WU[set][i] = F[set][i];
+                }
+            };
             auto unpack16 = [&](int set) {
 #pragma unroll
                 for (int i = 0; i < TN16; ++i) {
@@ -287,6 +398,45 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
                     }
                 }
             };
+            // ---- group-wise scales (WG): fp32 accumulators; the scales of a fold come out of the stage's scale blocks ----
+            constexpr bool WGW = (WG & 1) != 0, WGX = (WG & 2) != 0;
+            v4f facc[WG ? TN16 : 1][WG ? TM16 : 1];
+            v4f swc[WGW ? TN16 : 1];                                // weight scales of the group being folded, this lane's 4 channels per tile
+            float sxc[WGX ? TM16 : 1];                              // activation scales of the group being folded, this lane's row per tile
+            const int gsteps = WG ? (p.group_k >= 128 ? (p.group_k >> 7) : 1) : 1;   // k-steps per group (groups of 64: two groups per k-step)
+            typedef __attribute__((address_space(3))) v4f lds_v4f;
+            typedef __attribute__((address_space(3))) float lds_float;
+            // per-lane offsets inside a scale block: 4 consecutive channels of the lane's quad / the lane's row
+            const unsigned sc_lane_w = (unsigned)(size_t)(lds_void *)smem + SC_OFF + ((wn * TN16) * 16 + (lane >> 4) * 4) * 4;
+            const unsigned sc_lane_x = (unsigned)(size_t)(lds_void *)smem + SC_OFF + 512 + ((wm * TM16) * 16 + (lane & 15)) * 4;
+            unsigned sc_aw = 0, sc_ax = 0;
+            auto sc_addr = [&](int slot, int block) {          // the addresses of a fold's reads, materialised BEFORE the interval's
+                const unsigned u = slot * STAGE + block * 1024; // scheduling region (the reads then lead the interval's LDS queue)
+                if (WGW) {
+                    sc_aw = sc_lane_w + u;
+                    asm volatile("" : "+v"(sc_aw));
+                }
+                if (WGX) {
+                    sc_ax = sc_lane_x + u;
+                    asm volatile("" : "+v"(sc_ax));
+                }
+            };
+            auto rd_scales = [&]() {
+                if (WGW) {
+#pragma unroll
+                    for (int i = 0; i < TN16; ++i) swc[i] = *(const lds_v4f *)(sc_aw + i * 64);
+                }
+                if (WGX) {
+#pragma unroll
+                    for (int j = 0; j < TM16; ++j) sxc[j] = *(const lds_float *)(sc_ax + j * 64);
+                }
+            };
+            if (WG) {
+#pragma unroll
+                for (int i = 0; i < TN16; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM16; ++j) facc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+            }
             // Issue order inside an interval: one fragment read and one share of the nibble unpack per MFMA gap.  The packed-weight
             // read goes out FIRST (LDS returns in order: the unpack of the NEXT interval then waits for the oldest read only, a
             // whole interval old), the activation reads behind it in the order the next interval's MFMAs consume them.
@@ -294,25 +444,97 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
             constexpr int N_DS = TM16 + ((W_BITS == 4) ? (TN16 + 1) / 2 : TN16);    // hipcc merges the two 8-byte reads of a channel-tile pair
             constexpr int N_VALU = (W_BITS == 4) ? 6 * TN16 : 0;
             constexpr int DS_PER_GAP = (N_DS + N_MFMA - 1) / N_MFMA, VALU_PER_GAP = (N_VALU + N_MFMA - 1) / N_MFMA;
-            // interval of k-tile (parity par): slotx / ktx = where activations t+1 live, slotw / ktw = where weights t+2 live
-            auto interval = [&](int par, int slotx, int ktx, int slotw, int ktw) {
+            // fold of one 16 x 16 tile: 4 conversions, then packed fp32 multiplies / adds (one rounding per product and per sum)
+            constexpr int FOLD_VALU = WG ? 2 + (WGX ? 2 : 0) + (WGW ? 2 : 0) + 2 : 0;
+            // phase 1: the group sum as fp32 (needs no scales); phase 2: scale, add
+            auto fold_sum = [&](auto magic_c, const v4i a, v2f_t &t0, v2f_t &t1) {
+                if constexpr (decltype(magic_c)::value) {
+                    const v2f_t mm = v2f_t{MAGIC_F, MAGIC_F};
+                    t0 = v2f_t{__int_as_float(a[0]), __int_as_float(a[1])} - mm;
+                    t1 = v2f_t{__int_as_float(a[2]), __int_as_float(a[3])} - mm;
+                } else {
+                    t0 = v2f_t{(float)a[0], (float)a[1]};
+                    t1 = v2f_t{(float)a[2], (float)a[3]};
+                    if (W_BITS == 4) {                   // exact: a power of two
+                        t0 = t0 * v2f_t{0.0625f, 0.0625f};
+                        t1 = t1 * v2f_t{0.0625f, 0.0625f};
+                    }
+                }
+            };
+            auto fold_add = [&](v2f_t t0, v2f_t t1, int i, int j) {
+                if (WGX) {
+                    const v2f_t sx2 = v2f_t{sxc[j], sxc[j]};
+                    t0 = t0 * sx2;
+                    t1 = t1 * sx2;
+                }
+                if (WGW) {
+                    t0 = t0 * v2f_t{swc[i][0], swc[i][1]};
+                    t1 = t1 * v2f_t{swc[i][2], swc[i][3]};
+                }
+                const v2f_t f0 = v2f_t{facc[i][j][0], facc[i][j][1]} + t0, f1 = v2f_t{facc[i][j][2], facc[i][j][3]} + t1;
+                facc[i][j] = v4f{f0[0], f0[1], f1[0], f1[1]};
+            };
+            auto fold_tile = [&](auto magic_c, const v4i a, int i, int j) {
+                v2f_t t0, t1;
+                fold_sum(magic_c, a, t0, t1);
+                fold_add(t0, t1, i, j);
+            };
+            // interval of k-tile (parity par): slotx / ktx = where activations t+1 live, slotw / ktw = where weights t+2 live.
+            // BND (group scales, groups of <= 256): this k-tile is the FIRST of a group -- every tile's accumulators are folded with the
+            // scales of the group that just ended, and the tile's first MFMA of the new group starts from the magic bias; the fold's
+            // vector-ALU work sits in the MFMA gaps (6-8 packed instructions per 16 x 16 tile against the instruction's 8 passes)
+            // instead of stopping the matrix pipe at every group boundary.
+            // The scale reads go out first (LDS returns in order: the folds then wait for nothing younger) and a tile's phase 2 runs
+            // LAG tiles behind its phase 1, so that the reads have two MFMAs' time to land.
+            constexpr int LAG = N_MFMA > 2 ? 2 : 1;
+            constexpr int N_SC = (WGW ? TN16 : 0) + (WGX ? TM16 : 0);
+            auto interval = [&](auto bnd_c, int par, int slotx, int ktx, int slotw, int ktw, int slots = 0, int block = 0) {
+                constexpr bool BND = decltype(bnd_c)::value;
+                if (BND) sc_addr(slots, block);
                 __builtin_amdgcn_sched_barrier(0);
-                rd_w(par, slotw, ktw);
-                rd_x(par ^ 1, slotx, ktx);
-                unpack16(par ^ 1);                           // weights t+1 (requested during the previous interval)
+                if constexpr (!BND) {
+                    rd_w(par, slotw, ktw);
+                    rd_x(par ^ 1, slotx, ktx);
+                    unpack16(par ^ 1);                       // weights t+1 (requested during the previous interval)
+                }
+                if constexpr (BND) {
+                    // Hand-placed: one scheduling region per MFMA (the group-barrier pipeline does not survive this many vector-ALU
+                    // instructions -- hipcc then issues the MFMAs back to back and the whole fold behind them).  Region m: one fragment
+                    // read, one share of the nibble unpack, tile m's subtractions, its MFMA, and tile m - LAG's multiplies and adds.
+                    v2f_t q0[N_MFMA], q1[N_MFMA];
+                    rd_scales();
+                    constexpr int NRW = (W_BITS == 4) ? (TN16 + 1) / 2 : TN16;      // weight-read items (W4: a channel-tile pair per item)
+                    static_assert(NRW + TM16 <= N_MFMA && 2 * TN16 <= N_MFMA + 2, "one read and one unpack share per MFMA region");
 #pragma unroll
-                for (int i = 0; i < TN16; ++i)
+                    for (int m = 0; m < N_MFMA + LAG; ++m) {
+                        if (m < N_MFMA) {
+                            if (m < NRW) rd_w_part(par, slotw, ktw, m);
+                            else if (m - NRW < TM16) rd_x_part(par ^ 1, slotx, ktx, m - NRW);
+                            if (m < 2 * TN16) unpack16_part(par ^ 1, m);
+                            const int i = m / TM16, j = m % TM16;
+                            fold_sum(std::true_type{}, acc16[i][j], q0[m], q1[m]);
+                            acc16[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(WU[par][i], X[par][j], cinit, 0, 0, 0);
+                        }
+                        if (m >= LAG) fold_add(q0[m - LAG], q1[m - LAG], (m - LAG) / TM16, (m - LAG) % TM16);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
 #pragma unroll
-                    for (int j = 0; j < TM16; ++j)
-                        acc16[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(WU[par][i], X[par][j], acc16[i][j], 0, 0, 0);
+                    for (int i = 0; i < TN16; ++i)
 #pragma unroll
-                for (int m = 0; m < N_MFMA; ++m) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // MFMA
-                    if (N_VALU) __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_GAP, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, DS_PER_GAP, 0);        // DS reads
+                        for (int j = 0; j < TM16; ++j)
+                            acc16[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(WU[par][i], X[par][j], acc16[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < N_MFMA; ++m) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // MFMA
+                        if (N_VALU) __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_GAP, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, DS_PER_GAP, 0);        // DS reads
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             };
+            int g_left = gsteps;                    // k-steps of the current group still to run
+            const bool g64 = WG && p.group_k == 64;
             __builtin_amdgcn_s_barrier();            // B(0): stage 0 landed
             MQ_TL(0, 6);
             rd_w(0, 0, 0);
@@ -320,14 +542,61 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
             rd_w(1, 0, 1);
             unpack16(0);
             int cur = 0;
-            for (int it = 0; it < nk; ++it) {
+            constexpr std::false_type PLAIN{};
+            constexpr std::true_type FIRST_OF_GROUP{};
+            auto k_step = [&](int it) {
                 __builtin_amdgcn_s_barrier();        // B(it+1): stage it+1 landed
                 int nxt = cur + 1;
                 if (nxt == S) nxt = 0;
                 if (it + 1 >= nk) nxt = cur;         // last step: harmless re-reads of a live slot
-                interval(0, cur, 1, nxt, 0);         // k-tile 2 it:     activations 2 it + 1 (this stage), weights 2 it + 2 (next stage)
-                interval(1, nxt, 0, nxt, 1);         // k-tile 2 it + 1: activations 2 it + 2,              weights 2 it + 3
+                // k-tile 2 it: activations 2 it + 1 (this stage), weights 2 it + 2 (next stage)
+                if (WG && magic && it > 0 && (g64 || g_left == gsteps) && !(MQ_WS_WG_ABL & 4)) {     // the previous k-tile completed a group
+                    interval(FIRST_OF_GROUP, 0, cur, 1, nxt, 0, cur, 0);     // block A: the group that ended with the previous stage
+                } else {
+                    interval(PLAIN, 0, cur, 1, nxt, 0);
+                }
+                // k-tile 2 it + 1: activations 2 it + 2, weights 2 it + 3
+                if (WG && g64 && !(MQ_WS_WG_ABL & 4)) {                     // groups of 64: one group per k-tile
+                    interval(FIRST_OF_GROUP, 1, nxt, 0, nxt, 1, cur, 1);     // block B: the group of this stage's first k-tile
+                } else {
+                    interval(PLAIN, 1, nxt, 0, nxt, 1);
+                }
+                const int this_slot = cur;
                 cur = nxt;
+                if (WG && !g64 && --g_left == 0) {
+                    g_left = gsteps;
+                    if (!magic && it + 1 < nk) {     // groups of > 256: convert and fold here, the matrix pipe waits (one fold per >= 4 k-steps)
+                        sc_addr(this_slot, 2);       // block C: the group of this stage's last k-tile
+                        rd_scales();
+#pragma unroll
+                        for (int i = 0; i < TN16; ++i)
+#pragma unroll
+                            for (int j = 0; j < TM16; ++j) {
+                                fold_tile(std::false_type{}, acc16[i][j], i, j);
+                                acc16[i][j] = v4i{0, 0, 0, 0};
+                            }
+                    }
+                }
+            };
+            if constexpr (WG != 0) {
+#pragma clang loop unroll(disable)               // (no peeled first step: four interval variants are code enough)
+                for (int it = 0; it < nk; ++it) k_step(it);
+            } else {
+                for (int it = 0; it < nk; ++it) k_step(it);
+            }
+            if (WG) {
+                // the last group (a zero-padded last k-tile belongs to no group: its accumulators are 0, the clamped fold adds 0)
+                sc_addr(cur, 2);                     // block C of the last stage
+                rd_scales();
+#pragma unroll
+                for (int i = 0; i < TN16; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM16; ++j) {
+                        if (magic) fold_tile(std::true_type{}, acc16[i][j], i, j);
+                        else fold_tile(std::false_type{}, acc16[i][j], i, j);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc16[i][j][r] = __float_as_int(facc[i][j][r]);
+                    }
             }
             MQ_TL(0, 7);                             // k-loop done
         } else {
@@ -472,7 +741,7 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
                     if (p.sx_vec) sx = pr_sx;
                     else if (p.row_sel && pr_rs) sx = p.sx1;
                 }
-                par_sx[tid] = sx;
+                par_sx[tid] = (WG == 2) ? 1.0f : sx;   // (activation groups alone: the row's scales went into the fold)
                 par_xz[tid] = (ok && p.x0) ? pr_xz : 0.0f;
                 par_x1[tid] = (ok && p.x1) ? pr_x1 : 0.0f;
             }
@@ -561,35 +830,35 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
         // (levels sit in the high nibble); float(16 a) * (s_x / 16) is the same real product as
         // float(a) * s_x with an exact power-of-two rescale on both sides, so one rounding, same bits,
         // and the shift is gone.
-        typedef float v2f __attribute__((ext_vector_type(2)));
+        typedef float v2f_t __attribute__((ext_vector_type(2)));
         const bool has_bias = p.bias != nullptr, has_x0 = p.x0 != nullptr, has_x1 = p.x1 != nullptr;
-        v2f sw2[4], bs2[4], wz2[4], w12[4];
+        v2f_t sw2[4], bs2[4], wz2[4], w12[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            sw2[e] = v2f{swv[2 * e], swv[2 * e + 1]};
-            bs2[e] = v2f{bsv[2 * e], bsv[2 * e + 1]};
-            wz2[e] = v2f{wzv[2 * e], wzv[2 * e + 1]};
-            w12[e] = v2f{w1v[2 * e], w1v[2 * e + 1]};
+            sw2[e] = v2f_t{swv[2 * e], swv[2 * e + 1]};
+            bs2[e] = v2f_t{bsv[2 * e], bsv[2 * e + 1]};
+            wz2[e] = v2f_t{wzv[2 * e], wzv[2 * e + 1]};
+            w12[e] = v2f_t{w1v[2 * e], w1v[2 * e + 1]};
         }
 #pragma unroll
         for (int t = 0; t < ITERS; ++t) {
             const long m = m0 + t * RPI + lrow;
             const int a[8] = {q0[t][0], q0[t][1], q0[t][2], q0[t][3], q1[t][0], q1[t][1], q1[t][2], q1[t][3]};
-            const float sxe = (W_BITS == 4) ? sxr[t] * 0.0625f : sxr[t];
-            const v2f sx2 = v2f{sxe, sxe}, xz2 = v2f{xzr[t], xzr[t]}, x12 = v2f{x1r[t], x1r[t]};
+            const float sxe = (W_BITS == 4 && !WG) ? sxr[t] * 0.0625f : sxr[t];      // (weight groups: the 1/16 went into the group scales)
+            const v2f_t sx2 = v2f_t{sxe, sxe}, xz2 = v2f_t{xzr[t], xzr[t]}, x12 = v2f_t{x1r[t], x1r[t]};
             float y[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                v2f v = v2f{(float)a[2 * e], (float)a[2 * e + 1]};
+                v2f_t v = WG ? v2f_t{__int_as_float(a[2 * e]), __int_as_float(a[2 * e + 1])} : v2f_t{(float)a[2 * e], (float)a[2 * e + 1]};
                 v = v * sx2;
                 v = v * sw2[e];
                 if (has_bias) v = v + bs2[e];
                 if (has_x0) {
-                    const v2f pr = xz2 * wz2[e];
+                    const v2f_t pr = xz2 * wz2[e];
                     v = v + pr;
                 }
                 if (has_x1) {
-                    const v2f pr = x12 * w12[e];
+                    const v2f_t pr = x12 * w12[e];
                     v = v + pr;
                 }
                 y[2 * e] = v[0];
@@ -678,7 +947,7 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
         v4i q0 = *reinterpret_cast<const v4i *>(smem + row * PITCH + c8 * 4);
         v4i q1 = *reinterpret_cast<const v4i *>(smem + row * PITCH + c8 * 4 + 16);
         int a[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
-        if (W_BITS == 4) {
+        if (W_BITS == 4 && !WG) {                    // (weight groups: the registers hold float bits, the 1/16 is in the group scales)
 #pragma unroll
             for (int e = 0; e < 8; ++e) a[e] >>= 4;
         }
@@ -720,7 +989,7 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
         float y[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float t = (float)a[e] * sx;
+            float t = (WG ? __int_as_float(a[e]) : (float)a[e]) * sx;
             t = t * swv[e];
             if (p.bias) t = t + bsv[e];
             if (p.x0) {
@@ -763,14 +1032,14 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
     }
 }
 
-template <int BM, int BN, int MW_M, int MW_N, int NL, int S, int W_BITS, int EPI, int MF = 0>
+template <int BM, int BN, int MW_M, int MW_N, int NL, int S, int W_BITS, int EPI, int MF = 0, int WG = 0>
 static int launch_ws(const GemmArgs &p, hipStream_t st)
 {
     constexpr int PIECES = (BM / 16) * 2 + ((W_BITS == 4) ? (BN / 32) * 2 : (BN / 16) * 2);
-    constexpr int RING = S * PIECES * 1024, SLAB = BM * (BN * 4 + 16);
+    constexpr int RING = S * (PIECES + ((WG && !(MQ_WS_WG_ABL & 8)) ? 3 : 0)) * 1024, SLAB = BM * (BN * 4 + 16);   // (WG: three 1 KiB scale blocks per stage)
     constexpr int SMEM = (RING > SLAB ? RING : SLAB) + (4 * BN + 3 * BM) * 4;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
-    auto kern = gemm_ws_kernel<BM, BN, MW_M, MW_N, NL, S, W_BITS, EPI, MF>;
+    auto kern = gemm_ws_kernel<BM, BN, MW_M, MW_N, NL, S, W_BITS, EPI, MF, WG>;
     int rc = ensure_dynamic_lds((const void *)kern, SMEM);
     if (rc != MQ_OK) return rc;
     GemmArgs g = p;
@@ -806,6 +1075,37 @@ int dispatch_ws(const GemmArgs &p, int tile, hipStream_t st)
     }
     return fail(MQ_EINVAL, "gemm_ws: unknown tile %d", tile);
 }
+
+// Group-wise scales (GemmArgs::sw_groups and / or sx_groups, group_k 64 or a multiple of 128, no split-K): the 16x16x64 tiles with the
+// fold.  WGM: 1 weight groups, 2 activation groups, 3 both.
+template <int W_BITS, int EPI, int WGM>
+static int dispatch_ws_group_mode(const GemmArgs &p, int tile, hipStream_t st)
+{
+    switch (tile) {
+    // (ring depths: one stage fewer than the per-channel tiles where the scale blocks would not fit the 160 KiB)
+    case 45: return launch_ws<128, 128, 2, 4, 4, (W_BITS == 4 ? 5 : 4), W_BITS, EPI, 1, WGM>(p, st);
+    case 47: return launch_ws<64, 128, 1, 4, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI, 1, WGM>(p, st);
+    case 46:     // (192 x 128: twelve waves at <= 170 registers each cannot hold the extra fp32 accumulators -- 136 bytes of scratch;
+    case 48:     //  its shapes take the 96 x 128 tile)
+        return launch_ws<96, 128, 2, 4, 4, (W_BITS == 4 ? 6 : 5), W_BITS, EPI, 1, WGM>(p, st);
+    default: break;
+    }
+    return fail(MQ_EINVAL, "gemm_ws: tile %d has no group-scale variant", tile);
+}
+
+template <int W_BITS, int EPI>
+int dispatch_ws_wgroup(const GemmArgs &p, int tile, hipStream_t st)
+{
+    if constexpr (EPI == EPI_I32) {
+        return fail(MQ_EINVAL, "gemm_ws: group scales need a floating-point output");
+    } else {
+        if (p.sw_groups && p.sx_groups) return dispatch_ws_group_mode<W_BITS, EPI, 3>(p, tile, st);
+        if (p.sw_groups) return dispatch_ws_group_mode<W_BITS, EPI, 1>(p, tile, st);
+        return dispatch_ws_group_mode<W_BITS, EPI, 2>(p, tile, st);
+    }
+}
+#define MQ_WSG_INST(B, E) template int dispatch_ws_wgroup<B, E>(const GemmArgs &, int, hipStream_t);
+MQ_WSG_INST(4, EPI_F16) MQ_WSG_INST(4, EPI_BF16) MQ_WSG_INST(4, EPI_F32) MQ_WSG_INST(8, EPI_F16) MQ_WSG_INST(8, EPI_BF16) MQ_WSG_INST(8, EPI_F32)
 
 // explicit instantiations used by gemm_w4a8.hip
 #define MQ_WS_INST(B, E) template int dispatch_ws<B, E>(const GemmArgs &, int, hipStream_t);

@@ -57,6 +57,49 @@ def test_kernel_equals_the_oracle(w_bits, out_dtype, M, N, K, g, act):
         np.testing.assert_array_equal(y.float().cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("tile", [45, 46, 47, 48, 26])
+@pytest.mark.parametrize("w_bits,out_dtype", [(4, torch.float16), (8, torch.bfloat16)])
+@pytest.mark.parametrize("mode", ["w", "x", "wx"])
+@pytest.mark.parametrize("M,N,K,g", [(300, 392, 1280, 128), (259, 136, 704, 64), (130, 260, 1024, 256)])
+def test_every_tile_of_the_fold_and_the_round1_kernel_agree_with_the_oracle(tile, w_bits, out_dtype, mode, M, N, K, g):
+    """The group scales fold inside the wave-specialised 16x16x64 tiles (gemm_ws.hip WG = 1 weights / 2 activations / 3 both);
+    tile 26 keeps the round-1 kernel.  Every one of them against the oracle (ragged M and N, K_pad > K, groups of 64 / 128 / 256)."""
+    from mquant_amd import ops
+    rng = np.random.default_rng(M + N + K + g + w_bits + len(mode))
+    K_pad = (K + 127) // 128 * 128
+    G = K // g
+    a = np.zeros((M, K_pad), np.int8)
+    a[:, :K] = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+    lim = 8 if w_bits == 4 else 128
+    w = rng.integers(-lim, lim, size=(N, K), dtype=np.int8)
+    wp = np.zeros((N, K_pad), np.int8)
+    wp[:, :K] = w
+    bias = rng.normal(size=N).astype(np.float32)
+    s_wg = (rng.random((G, N), dtype=np.float32) * 0.01 + 0.001).astype(np.float32)
+    s_xg = (rng.random((M, G), dtype=np.float32) * 0.2 + 0.01).astype(np.float32)
+    s_w = (rng.random(N, dtype=np.float32) * 0.01 + 0.001).astype(np.float32)
+    img = ops.prepack(to_dev(wp), w_bits)
+    at = ops.TiledAct.from_rows(to_dev(a))
+    try:
+        ops.gemm_debug_force(tile, 0)
+        if mode == "w":
+            y = ops.gemm_w4a8_wgroupscale(at, img, w_bits, N, to_dev(s_wg), g, bias=to_dev(bias), out_dtype=out_dtype, s_x0=0.031)
+            want = oracle.gemm_wgroup(a[:, :K], w, s_wg, g, bias=bias, sx0=0.031)
+        elif mode == "wx":
+            y = ops.gemm_w4a8_wgroupscale(at, img, w_bits, N, to_dev(s_wg), g, bias=to_dev(bias), out_dtype=out_dtype, s_x_groups=to_dev(s_xg))
+            want = oracle.gemm_wgroup(a[:, :K], w, s_wg, g, bias=bias, s_xg=s_xg)
+        else:
+            y = ops.gemm_w4a8_groupscale(at, img, w_bits, N, to_dev(s_xg), g, to_dev(s_w), bias=to_dev(bias), out_dtype=out_dtype)
+            acc = np.einsum("mgk,ngk->mgn", a[:, :K].reshape(M, G, g).astype(np.int64), w.reshape(N, G, g).astype(np.int64))
+            f = np.zeros((M, N), np.float32)
+            for gi in range(G):
+                f = (f + (acc[:, gi, :].astype(np.float32) * s_xg[:, gi:gi + 1]).astype(np.float32)).astype(np.float32)
+            want = ((f * s_w[None, :]).astype(np.float32) + bias[None, :]).astype(np.float32)
+    finally:
+        ops.gemm_debug_force(-1, 0)
+    np.testing.assert_array_equal(y.float().cpu().numpy(), oracle.round_to(want, MODE[out_dtype]))
+
+
 def test_entry_point_refuses_what_it_cannot_do():
     from mquant_amd import ops
     from mquant_amd._lib import MQuantHipError
@@ -177,3 +220,55 @@ def test_gptq_with_weight_groups_runs_end_to_end_on_the_integer_path():
     wrap.real_quant = False
     y_sim = wrap(x.clone())
     np.testing.assert_allclose(y.cpu().numpy(), y_sim.cpu().numpy(), rtol=0, atol=1e-3 * float(y_sim.abs().max()))
+
+
+def test_sibling_fusion_with_weight_groups_equals_the_per_linear_evaluation():
+    """q / k / v wrappers whose weights carry group scales of the same group size fuse into ONE quantize + ONE grouped GEMM
+    (their [groups, channels] scale tables side by side): bit-identical to evaluating every Linear on its own."""
+    import types
+    from fake_quant import quant_utils as qu
+
+    class Attn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q_proj = torch.nn.Linear(512, 256, bias=True)
+            self.k_proj = torch.nn.Linear(512, 64, bias=True)
+            self.v_proj = torch.nn.Linear(512, 64, bias=True)
+
+        def forward(self, x):
+            return self.q_proj(x), self.k_proj(x), self.v_proj(x)
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.attn = Attn()
+
+        def forward(self, x):
+            return self.attn(x)
+
+    torch.manual_seed(3)
+    model = Holder().to(DEV)
+    qu.add_actquant(model)
+    g = 128
+    for name in ("q_proj", "k_proj", "v_proj"):
+        wrap = getattr(model.attn, name)
+        W = wrap.module.weight.data.float()
+        N, K = W.shape
+        gs = W.reshape(N, K // g, g).abs().amax(dim=2).clamp(min=1e-5) / 7
+        wrap.module.weight.data = (torch.round(W.reshape(N, K // g, g) / gs[:, :, None]).clamp(-8, 7) * gs[:, :, None]).reshape(N, K)
+        wq = qu.WeightQuantizer()
+        wq.configure(4, perchannel=True, sym=True)
+        wq.scale, wq.zero = gs[:, -1:].clone(), torch.zeros(N, 1, device=DEV)
+        wq.groupsize, wq.group_permuted, wq.group_scales = g, False, gs
+        qu.attach_weight_quantizer(wrap, "module", wq)
+        wrap.quantizer.configure(bits=8, sym=True, static=True, observer_type="minmax")
+    qu.calib_layer(model, [torch.from_numpy(make_x(40 + i, (24, 512))).to(DEV) for i in range(2)], Args())
+    x = torch.from_numpy(make_x(50, (24, 512))).to(DEV)
+    fused = [t.clone() for t in model(x)]
+    grp = model.attn.q_proj.__dict__.get("_group")
+    assert grp is not None and grp.enabled and grp.engine is not None and grp.engine.w_groups is not None and grp.launches == 1
+    assert tuple(grp.engine.w_groups[0].shape) == (4, 256 + 64 + 64)
+    qu.model_quant(model, types.SimpleNamespace(skip_names=[], no_sibling_fusion=True))
+    plain = model(x)
+    assert all(torch.equal(a, b) for a, b in zip(fused, plain))
+    assert model.attn.k_proj._real is not None and model.attn.k_proj._real.w_groups is not None

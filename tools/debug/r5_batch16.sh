@@ -1,0 +1,3 @@
+cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gpu_wgroup.py tests/test_gpu_checkpoint.py tests/test_gpu_tiled.py tests/test_gpu_groupwise.py -x -q -m gpu 2>&1 | tail -12
+timeout 600 python3 tools/wgroup_bench.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r5_wgroup_bench2.txt
