@@ -1081,13 +1081,19 @@ int dispatch_ws(const GemmArgs &p, int tile, hipStream_t st)
 template <int W_BITS, int EPI, int WGM>
 static int dispatch_ws_group_mode(const GemmArgs &p, int tile, hipStream_t st)
 {
+    if (tile == 46) {
+        // 192 x 128: twelve waves at <= 168 registers each cannot hold the extra fp32 accumulators (136 bytes of scratch).  Its shapes take
+        // 128 x 128 or 96 x 128, whichever needs fewer row-rounds (gate|up: 7 x 128 against 10 x 96, measured 14-20 % ahead; ViT fc1:
+        // 2 x 128 against 2 x 96, measured 15 % behind -- profiles/r5_group_gemm_ws_fold.txt)
+        const long cus = device_cu_count(), nb = (p.N + 127) / 128;
+        const long r128 = (((p.M + 127) / 128) * nb + cus - 1) / cus * 128, r96 = (((p.M + 95) / 96) * nb + cus - 1) / cus * 96;
+        tile = r128 < r96 ? 45 : 48;
+    }
     switch (tile) {
     // (ring depths: one stage fewer than the per-channel tiles where the scale blocks would not fit the 160 KiB)
     case 45: return launch_ws<128, 128, 2, 4, 4, (W_BITS == 4 ? 5 : 4), W_BITS, EPI, 1, WGM>(p, st);
     case 47: return launch_ws<64, 128, 1, 4, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI, 1, WGM>(p, st);
-    case 46:     // (192 x 128: twelve waves at <= 170 registers each cannot hold the extra fp32 accumulators -- 136 bytes of scratch;
-    case 48:     //  its shapes take the 96 x 128 tile)
-        return launch_ws<96, 128, 2, 4, 4, (W_BITS == 4 ? 6 : 5), W_BITS, EPI, 1, WGM>(p, st);
+    case 48: return launch_ws<96, 128, 2, 4, 4, (W_BITS == 4 ? 6 : 5), W_BITS, EPI, 1, WGM>(p, st);
     default: break;
     }
     return fail(MQ_EINVAL, "gemm_ws: tile %d has no group-scale variant", tile);
