@@ -282,6 +282,9 @@ def main():
                     help="leave the per-step logits (fp16 lm_head on the last position, side stream) out of the step")
     ap.add_argument("--had-fast", action="store_true",
                     help="non-default Hadamard mode: K x K stage on the fp16 matrix core (not bit-identical; labelled)")
+    ap.add_argument("--w-groupsize", type=int, default=-1,
+                    help="NON-DEFAULT, labelled secondary line: group-wise weight scales of this many input channels (what a --w_groupsize GPTQ run "
+                         "leaves behind; synthetic weights get them from a group-wise RTN), GEMMs on mq_gemm_w4a8_wgroupscale")
     ap.add_argument("--ttft-iters", type=int, default=100)
     ap.add_argument("--batch", type=int, default=1,
                     help="image+prompt samples per GPU and step (the benchmark configuration is 1; >1 is a scaling study)")
@@ -339,14 +342,14 @@ def main():
 
     from mquant_amd import ops, workload
 
-    headline = args.workload == "qwen2vl_7b" and not args.tiny
+    headline = args.workload == "qwen2vl_7b" and not args.tiny and args.w_groupsize <= 0
     build_specs, workload_desc = workload.WORKLOADS[args.workload]
     specs = workload.tiny_specs() if args.tiny else build_specs(args.batch)
     via_wrappers = not args.direct_engines and not args.tiny      # every workload is built through the drop-in API (round 4: the secondary lines too)
     pf, via_error = None, None
     if via_wrappers:
         try:
-            pf = workload.WrapperPrefill(specs, device=dev, dtype=torch.float16, fuse_siblings=not args.no_fuse)
+            pf = workload.WrapperPrefill(specs, device=dev, dtype=torch.float16, fuse_siblings=not args.no_fuse, w_groupsize=args.w_groupsize)
         except Exception as exc:          # never lose the bench line: fall back to the directly assembled engines, and say so
             via_error, via_wrappers = repr(exc), False
             torch.cuda.empty_cache()
@@ -595,6 +598,9 @@ def main():
         desc += " (Linears fed the same tensor -- q/k/v, gate/up -- share one quantization and one GEMM)"
     if not headline and not args.tiny:
         desc = "SECONDARY LINE, not the benchmark configuration: " + desc
+    if args.w_groupsize > 0:
+        desc = (f"NON-DEFAULT group-wise weight scales (--w_groupsize {args.w_groupsize}; every Linear whose input width is a multiple of it -- "
+                "all but the vision tower's split fc2): ") + desc
     if args.had_fast:
         desc = "NON-DEFAULT fast Hadamard mode (fp16 matrix-core K x K stage, not bit-identical to the reference): " + desc
     line = {"metric": "W4A8 prefill tokens/sec (hot path: Hadamard + static quant + W4A8 Linear), "

@@ -405,7 +405,7 @@ class WrapperPrefill(_HotPath):
     ``model_quant`` groups q/k/v and gate/up into one quantize + one GEMM (``quant_utils.SiblingGroup``)."""
 
     def __init__(self, specs: List[LinearSpec], device="cuda:0", dtype=torch.float16, w_bits: int = 4,
-                 seed: int = 1234, fuse_siblings: bool = True, calib_passes: int = 2):
+                 seed: int = 1234, fuse_siblings: bool = True, calib_passes: int = 2, w_groupsize: int = -1):
         import functools
         import types
         from fake_quant import hadamard_utils as hu, quant_utils as qu, utils as fq_utils
@@ -461,7 +461,8 @@ class WrapperPrefill(_HotPath):
             wrap.quantizer.configure(bits=8, sym=True, static=True, observer_type="minmax", msq=spec.msq)
             self.calls.append((wrap, inputs[(spec.M, spec.k_in)], spec))
         self.quantizers: Dict[str, object] = {}
-        rtn_module(root, "model", w_bits, True, False, [], self.quantizers)
+        # w_groupsize > 0: group-wise weight scales as a --w_groupsize GPTQ run leaves them (fake_quant.gptq.rtn, mq_gemm_w4a8_wgroupscale)
+        rtn_module(root, "model", w_bits, True, False, [], self.quantizers, groupsize=w_groupsize)
         self.args = types.SimpleNamespace(skip_names=[], no_sibling_fusion=not fuse_siblings)
         m_llm = max([sp.M for sp in specs if sp.msq] + [0])
         self.mask = vision_text_mask(m_llm, self.device) if m_llm else None

@@ -108,3 +108,32 @@ def test_backend_line_names_the_integer_path_or_the_reason():
     assert wrap.backend().startswith("W4A8 integer")
     wrap.real_quant = False
     assert "switched off" in wrap.backend()
+
+
+def test_group_wise_rtn_leaves_what_the_gptq_solver_leaves():
+    """fake_quant.gptq.rtn.rtn_module(groupsize=g) -- the extension synthetic benchmarks use -- runs find_params + quantize on every
+    group of g columns and records group_scales / group_zeros / groupsize like this repository's GPTQ; a Linear whose width is not
+    a multiple of g (the split fc2's L2) keeps per-channel scales."""
+    from fake_quant import quant_utils as qu
+    from fake_quant.gptq.rtn import rtn_module
+
+    torch.manual_seed(3)
+    root = torch.nn.Module()
+    root.a = torch.nn.Linear(256, 24, bias=False)
+    root.b = torch.nn.Linear(255, 8, bias=False)
+    w0 = root.a.weight.data.clone()
+    qu.add_actquant(root)
+    assert isinstance(root.a, qu.ActQuantWrapper)
+    quantizers = {}
+    rtn_module(root, "m", 4, True, False, [], quantizers, groupsize=64)
+    qz = quantizers["m.a.module"]
+    assert qz.groupsize == 64 and not qz.group_permuted and tuple(qz.group_scales.shape) == (24, 4)
+    ref = qu.WeightQuantizer()
+    ref.configure(4, perchannel=True, sym=True, mse=False)
+    for gi in range(4):
+        ref.find_params(w0[:, gi * 64:(gi + 1) * 64])
+        assert torch.equal(ref.scale.reshape(-1).float(), qz.group_scales[:, gi])
+        assert torch.equal(ref.quantize(w0[:, gi * 64:(gi + 1) * 64]), root.a.module.weight.data[:, gi * 64:(gi + 1) * 64])
+    assert getattr(quantizers["m.b.module"], "group_scales", None) is None           # 255 columns: per-channel scales
+    root.a.quantizer.configure(bits=8, sym=True)                                      # dynamic per-token activations: nothing to calibrate
+    assert "weight groups of 64" in root.a.extra_repr(), root.a.extra_repr()
