@@ -128,7 +128,7 @@ __device__ __forceinline__ void had_emit_n(const HadArgs &p, long row, long col,
 // V_MFMA_F32_16X16X4_F32.  The fp32 MFMA shares the vector ALU's datapath, so every VALU instruction
 // beside it is lost matrix time: the round-1 form (one tile x four column tiles, three VALU ops per
 // sign operand) spent 8 VALU per 4 MFMAs, a 5 x 2 unit spends 7 per 10.
-template <int DT, bool QUANT, bool HALF_LDS, int UJ, int UG>
+template <int DT, bool QUANT, bool HALF_LDS, int UJ, int UG, bool CONTIG = false>
 __device__ __forceinline__ void had_kxk_unit(const HadArgs &p, long row, const RowScale &rs, const char *ybase, int row_bytes, int swz,
                                              int jg, int cg, int lane)
 {
@@ -171,6 +171,7 @@ __device__ __forceinline__ void had_kxk_unit(const HadArgs &p, long row, const R
     int jts[UJ];
 #pragma unroll
     for (int jj = 0; jj < UJ; ++jj) jts[jj] = (jg * UJ + jj < JT) ? jg * UJ + jj : JT - 1;
+    cmask_t *mrow = (cmask_t *)(p.masks) + jg * UJ;
     // Two register sets, filled one k-step AHEAD (the loop is unrolled by two, so no set is ever copied): the scalar loads
     // of the masks and the LDS read of the staged values of step t+1 are in flight while the ten MFMAs of step t issue, and
     // the wave never waits for them at the top of a step.  (Per-CU timelines, profiles/r4_hadamard_cu_timeline.txt: a
@@ -192,6 +193,26 @@ __device__ __forceinline__ void had_kxk_unit(const HadArgs &p, long row, const R
         } else {
 #pragma unroll
             for (int g = 0; g < UG; ++g) bf[set][g] = *reinterpret_cast<const float *>(src + 4 * g);
+        }
+        if constexpr (CONTIG) {
+            // no tile of this unit lies past JT: its UJ masks of a step are adjacent -- ONE address (one 64-bit add per k-step instead
+            // of UJ) and wide scalar loads (s_load_dwordx8 / x4 + x2 instead of UJ x2)
+            typedef u64 u64x4 __attribute__((ext_vector_type(4), aligned(8)));
+            typedef u64 u64x2 __attribute__((ext_vector_type(2), aligned(8)));
+            typedef const __attribute__((address_space(4))) u64x4 cmask4_t;
+            typedef const __attribute__((address_space(4))) u64x2 cmask2_t;
+            cmask_t *q = mrow + (long)t * JT;
+            static_assert(UJ == 5 || UJ == 3, "unit heights");
+            if constexpr (UJ == 5) {
+                const u64x4 a = *reinterpret_cast<cmask4_t *>(q);
+                mk[set][0] = a[0]; mk[set][1] = a[1]; mk[set][2] = a[2]; mk[set][3] = a[3];
+                mk[set][4] = q[4];
+            } else {
+                const u64x2 a = *reinterpret_cast<cmask2_t *>(q);
+                mk[set][0] = a[0]; mk[set][1] = a[1];
+                mk[set][2] = q[2];
+            }
+            return;
         }
 #pragma unroll
         for (int jj = 0; jj < UJ; ++jj) mk[set][jj] = ((cmask_t *)(p.masks))[(long)t * JT + jts[jj]];   // scalar loads
@@ -465,6 +486,10 @@ __global__ __launch_bounds__(THREADS, HALF_LDS ? 4 : 1) void hadamard_kernel(Had
             const int JT = (K + 15) / 16;
             const int JG = (JT + 2) / 3, CG = m / 32;
             for (int u = wave; u < JG * CG; u += HAD_WAVES)
+#ifndef MQ_HAD_MASKS_SEPARATE
+                if ((u / CG + 1) * 3 <= (p.K + 15) / 16) had_kxk_unit<DT, QUANT, HALF_LDS, 3, 2, true>(p, row, rs, ybase, row_bytes, swz, u / CG, u % CG, lane);
+                else
+#endif
                 had_kxk_unit<DT, QUANT, HALF_LDS, 3, 2>(p, row, rs, ybase, row_bytes, swz, u / CG, u % CG, lane);
         } else if (UNIT == 5) {
             // prepared descriptor: mask-driven 5 x 2 units (had_kxk_unit), one unit per wave for K = 156, m = 128.
@@ -473,6 +498,10 @@ __global__ __launch_bounds__(THREADS, HALF_LDS ? 4 : 1) void hadamard_kernel(Had
             const int JT = (K + 15) / 16;
             const int JG = (JT + 4) / 5, CG = m / 32;
             for (int u = wave; u < JG * CG; u += HAD_WAVES)
+#ifndef MQ_HAD_MASKS_SEPARATE
+                if ((u / CG + 1) * 5 <= (p.K + 15) / 16) had_kxk_unit<DT, QUANT, HALF_LDS, 5, 2, true>(p, row, rs, ybase, row_bytes, swz, u / CG, u % CG, lane);
+                else
+#endif
                 had_kxk_unit<DT, QUANT, HALF_LDS, 5, 2>(p, row, rs, ybase, row_bytes, swz, u / CG, u % CG, lane);
         } else if (m >= 64) {
             const int JT = (K + 15) / 16;
