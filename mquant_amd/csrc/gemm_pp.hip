@@ -228,6 +228,8 @@ __global__ __launch_bounds__(512) void gemm_w4a8_pp_kernel(GemmArgs p)
         }
     }
 #endif
+    // (Requesting one dword per 128-byte line of the NEXT tile's first RING - 1 weight steps here, in front of the epilogue, so that
+    //  its prologue's LDS-DMAs hit the L2, was measured in round 5: 0.4 % SLOWER over the bench, profiles/r5_bench_ab_pp_next_tile_prefetch.txt)
     gemm_epilogue<TM, TN, NWAVES, RING * SLOT, 4, EPI>(p, acc, smem, wave, lane, grp, wn, m0, nt0, split);
 #ifdef MQ_PP_STAMP
     if (tid == 0 && p.partial && p.splits == 1) p.partial[(long)wid * 8 + 4] = (int)__builtin_amdgcn_s_memrealtime();
