@@ -95,3 +95,48 @@ def test_quantizers_are_idempotent_at_full_size():
     assert torch.equal(ops.fakequant_act(fq, s), fq)
     qd, sr, _ = ops.quantize_act_dyn_i8(x)
     assert int(qd.abs().max()) == 127 and torch.equal(qd.abs().amax(1), torch.full((768,), 127, device=DEV, dtype=torch.int8))
+
+
+@pytest.mark.parametrize("name,M,N,K", [FULL[0], FULL[1], FULL[3]])
+@pytest.mark.parametrize("g,mode", [(128, "w"), (64, "wx"), (256, "x")])
+def test_group_scale_gemm_at_full_size(name, M, N, K, g, mode):
+    """Group-wise scales at the benchmark's full sizes: the fold inside the wave-specialised tiles (csrc/gemm_ws.hip) against the
+    round-1 grouped kernel (an independent implementation of the same arithmetic: other tile, other fold, conversions instead of the
+    magic bias, scales by global loads) bit for bit, and 2048 sampled outputs against the arithmetic restated on the host."""
+    from mquant_amd import ops
+    gen = torch.Generator(device=DEV).manual_seed(N + K + g)
+    a = torch.randint(-128, 128, (M, K), generator=gen, device=DEV, dtype=torch.int8)
+    w = _levels(N, K, 4, K + g)
+    G = K // g
+    s_wg = torch.rand((G, N), generator=gen, device=DEV) * 0.01 + 0.001
+    s_xg = torch.rand((M, G), generator=gen, device=DEV) * 0.2 + 0.01
+    s_w = torch.rand((N,), generator=gen, device=DEV) * 0.01 + 0.001
+    img = ops.prepack(w, 4)
+    at = ops.TiledAct.from_rows(a)
+
+    def run():
+        if mode == "w":
+            return ops.gemm_w4a8_wgroupscale(at, img, 4, N, s_wg, g, s_x0=0.031, out_dtype=torch.float32)
+        if mode == "wx":
+            return ops.gemm_w4a8_wgroupscale(at, img, 4, N, s_wg, g, s_x_groups=s_xg, out_dtype=torch.float32)
+        return ops.gemm_w4a8_groupscale(at, img, 4, N, s_xg, g, s_w, out_dtype=torch.float32)
+    y = run()
+    try:
+        ops.gemm_debug_force(26, 0)
+        y_round1 = run()
+    finally:
+        ops.gemm_debug_force(-1, 0)
+    assert torch.equal(y, y_round1)
+    mi = torch.randint(0, M, (2048,), generator=gen, device=DEV)
+    ni = torch.randint(0, N, (2048,), generator=gen, device=DEV)
+    acc = (a[mi].to(torch.int64).reshape(-1, G, g) * w[ni].to(torch.int64).reshape(-1, G, g)).sum(2)      # exact group sums [2048, G]
+    f = torch.zeros(2048, device=DEV, dtype=torch.float32)
+    for gi in range(G):                                              # one fp32 rounding per product and per sum, ascending groups
+        t = acc[:, gi].to(torch.float32)
+        if mode != "w":
+            t = t * s_xg[mi, gi]
+        if mode != "x":
+            t = t * s_wg[gi, ni]
+        f = f + t
+    want = f * (s_w[ni] if mode == "x" else (torch.tensor(0.031, device=DEV) if mode == "w" else torch.tensor(1.0, device=DEV)))
+    assert torch.equal(y[mi, ni], want)
