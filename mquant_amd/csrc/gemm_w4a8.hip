@@ -36,6 +36,9 @@ template <int EPI>
 int launch_gemm_pp(const GemmArgs &p, int tile, hipStream_t st);   // gemm_pp.hip (ping-pong kernels, W4, tiled activations)
 template <int W_BITS, int EPI>
 int dispatch_ws_wgroup(const GemmArgs &p, int tile, hipStream_t st);   // gemm_ws.hip (weight-group fold in the 16x16x64 math loop)
+template <int EPI>
+int launch_gemm_skinny(const GemmArgs &p, hipStream_t st);             // gemm_skinny.hip (M <= 64 rows, W4, tiled activations; tile id 60)
+int skinny_slices(long M, long N, long K_pad, size_t ws_bytes);
 
 // GROUPED (--a_groupsize): the int32 accumulators of one activation group (64 or a multiple of 128 k) are scaled by
 // the group's activation scale of their row and added to fp32 accumulators in ascending group order; the epilogue
@@ -259,8 +262,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p)
         const long n = (i - m * quads_per_row) * 4;
         v4i a = {0, 0, 0, 0};
         const bool vec = (n + 4 <= p.N) && (p.N % 4 == 0);
-        for (int s = 0; s < p.splits; ++s) {
-            const int *src = p.partial + ((long)s * p.M + m) * p.N + n;
+        const long sstride = p.M * p.N;
+        const int *src0 = p.partial + m * p.N + n;
+        int s = 0;
+        if (vec) {
+            // four partials in flight (a rolled loop waits for every load in turn: ~0.8 us per split; the skinny kernel's 14-28 K
+            // slices made that the longest part of a decode GEMM); integer sums: exact in any order
+            for (; s + 4 <= p.splits; s += 4) {
+                const v4i t0 = *reinterpret_cast<const v4i *>(src0 + (long)s * sstride);
+                const v4i t1 = *reinterpret_cast<const v4i *>(src0 + (long)(s + 1) * sstride);
+                const v4i t2 = *reinterpret_cast<const v4i *>(src0 + (long)(s + 2) * sstride);
+                const v4i t3 = *reinterpret_cast<const v4i *>(src0 + (long)(s + 3) * sstride);
+                a += (t0 + t1) + (t2 + t3);
+            }
+        }
+        for (; s < p.splits; ++s) {
+            const int *src = src0 + (long)s * sstride;
             if (vec) {
                 const v4i t = *reinterpret_cast<const v4i *>(src);
                 a += t;
@@ -543,6 +560,13 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
     }
     if (ws_only) {
         // (an epilogue that exists in the wave-specialised kernels only -- RoPE in the store: the best of the tiles above, no split-K)
+    } else if (a_tiled && w4 && ceil_div(N, 128) <= 65535 && (M <= 16 || (M <= 64 && kps >= 64 && ceil_div(N, 128) < 128))) {
+        // A few rows (generation steps of the exam scripts): the weight stream is the work -- gemm_skinny.hip, id 60; `splits` = its
+        // K slices, added up by splitk_reduce_kernel.  One row tile: every decoder shape gains (48 against 80 us per layer at M = 1);
+        // two to four row tiles: only the long reductions over few channel tiles do (down_proj: 23 against 36 us at M = 32) --
+        // profiles/r5_decode_gemm_bench.txt
+        pl.tile = 60;
+        pl.splits = have_ws ? skinny_slices(M, N, K_pad, ws_bytes) : 1;
     } else if (t256 >= 192) {
         // gate|up: with tiled activations the 8-wave ping-pong kernel (gemm_pp.hip, round 4: 93-101 us against 108-116
         // for the software-pipelined tile 13 and 110-112 for the 16-wave tile 3, profiles/r4_pp_ab.txt); with row-major
@@ -572,7 +596,10 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
         while (s > 1 && ((size_t)(s * M * N * 4) > ws_bytes || kps / s < 8)) --s;
         if (s > 1) { pl.tile = 3; pl.splits = (int)s; }
     }
-    if (force_tile >= 0 && (!ws_only || (force_tile >= 40 && force_tile < 60))) pl.tile = force_tile;
+    if (force_tile >= 0 && (!ws_only || (force_tile >= 40 && force_tile < 60))) {
+        if (pl.tile == 60 && force_tile != 60) pl.splits = 1;          // (the slices were the skinny kernel's)
+        pl.tile = force_tile;
+    }
     if (force_splits > 0 && !ws_only) pl.splits = force_splits;
     if (pl.splits > kps) pl.splits = (int)kps;
     if (pl.splits < 1) pl.splits = 1;
@@ -608,6 +635,15 @@ static int dispatch_tile(const GemmArgs &p, int tile, hipStream_t st)
         if constexpr (W_BITS == 4) {
             if (!p.a_tiled) return fail(MQ_EINVAL, "mq_gemm_w4a8: tile %d needs activations in the tiled layout (lda = MQ_LD_TILED)", tile);
             const int rc = launch_gemm_pp<EPI>(p, tile, st);
+            if (rc != MQ_OK || p.splits == 1) return rc;
+            long blocks = ceil_div(p.M * ceil_div(p.N, 4), 256);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(splitk_reduce_kernel<EPI>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+            return check_launch("splitk_reduce");
+        } else break;
+    case 60:
+        if constexpr (W_BITS == 4) {
+            const int rc = launch_gemm_skinny<EPI>(p, st);
             if (rc != MQ_OK || p.splits == 1) return rc;
             long blocks = ceil_div(p.M * ceil_div(p.N, 4), 256);
             if (blocks > 2048) blocks = 2048;

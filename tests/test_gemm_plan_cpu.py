@@ -38,3 +38,13 @@ def test_plan_of_the_model_shapes(name, M, N, K, want):
 def test_few_tiles_and_a_long_reduction_still_split_k():
     tile, splits = _plan(256, 2048, 19968)
     assert splits > 1
+
+
+@pytest.mark.parametrize("M", [1, 8, 16, 33, 64])
+def test_a_few_rows_take_the_weight_streaming_kernel(M):
+    """Generation steps (W4, tiled activations): gemm_skinny.hip (id 60), `splits` = its K slices -- about three workgroups per CU, at
+    least four 64-wide k-tiles per slice.  One row tile: every shape; up to four: the long reductions over few channel tiles only."""
+    for N, K, want in ((4608, 3584, 14), (3584, 3584, 14), (37888, 3584, 3)):
+        assert (_plan(M, N, K) == (60, want)) == (M <= 16), (M, N, K, _plan(M, N, K))
+    assert _plan(M, 3584, 19968) == (60, 28)
+    assert _plan(65, 3584, 19968)[0] != 60
