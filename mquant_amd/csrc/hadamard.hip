@@ -339,9 +339,16 @@ __global__ __launch_bounds__(THREADS, HALF_LDS ? 4 : 1) void hadamard_kernel(Had
     }
 
     // tiled int8 output: the 16 rows of a piece row are handled on one XCD (tiled_row_of, mq_common.h)
-    const bool remap = QUANT && p.ldq == MQ_LD_TILED && (gridDim.x & 7) == 0;
-    const long v_end = remap ? ceil_div(p.M, 128) * 128 : p.M;
-    for (long v = blockIdx.x; v < v_end; v += gridDim.x) {
+    // (not below one 128-row group: the map would hand ALL rows of a short batch to the workgroups of one XCD -- 16 rows took
+    //  170 us on two workgroups where 16 workgroups need 26, profiles/r5_hadamard_small_m.txt)
+    const bool remap = QUANT && p.ldq == MQ_LD_TILED && (gridDim.x & 7) == 0 && p.M >= 128;
+    // Short batches (generation steps: one row would keep ONE workgroup busy for ~24 us on down_proj): 2^parts_log2 workgroups share a
+    // row -- each stages the whole row (phase A is cheap) and runs its share of the K x K units, whose outputs it quantizes and stores.
+    const int parts = (UNIT == 5 || UNIT == 3) ? (1 << p.parts_log2) : 1;
+    const long v_end = (remap ? ceil_div(p.M, 128) * 128 : p.M) << ((UNIT == 5 || UNIT == 3) ? p.parts_log2 : 0);
+    for (long vv = blockIdx.x; vv < v_end; vv += gridDim.x) {
+        const long v = (UNIT == 5 || UNIT == 3) ? (vv >> p.parts_log2) : vv;
+        const int part = (UNIT == 5 || UNIT == 3) ? (int)(vv & (parts - 1)) : 0;
         const long row = remap ? tiled_row_of(v) : v;
         if (row >= p.M) continue;                  // uniform over the workgroup
         const T *xr = reinterpret_cast<const T *>(p.x) + row * p.ldx;
@@ -485,7 +492,7 @@ __global__ __launch_bounds__(THREADS, HALF_LDS ? 4 : 1) void hadamard_kernel(Had
             // sit on the same two SIMDs in every resident workgroup, which then carry twice the matrix work of the others.
             const int JT = (K + 15) / 16;
             const int JG = (JT + 2) / 3, CG = m / 32;
-            for (int u = wave; u < JG * CG; u += HAD_WAVES)
+            for (int u = wave * parts + part; u < JG * CG; u += HAD_WAVES * parts)
 #ifndef MQ_HAD_MASKS_SEPARATE
                 if ((u / CG + 1) * 3 <= (p.K + 15) / 16) had_kxk_unit<DT, QUANT, HALF_LDS, 3, 2, true>(p, row, rs, ybase, row_bytes, swz, u / CG, u % CG, lane);
                 else
@@ -497,7 +504,7 @@ __global__ __launch_bounds__(THREADS, HALF_LDS ? 4 : 1) void hadamard_kernel(Had
             // the occupancy) of the shapes that take the classic path below.
             const int JT = (K + 15) / 16;
             const int JG = (JT + 4) / 5, CG = m / 32;
-            for (int u = wave; u < JG * CG; u += HAD_WAVES)
+            for (int u = wave * parts + part; u < JG * CG; u += HAD_WAVES * parts)
 #ifndef MQ_HAD_MASKS_SEPARATE
                 if ((u / CG + 1) * 5 <= (p.K + 15) / 16) had_kxk_unit<DT, QUANT, HALF_LDS, 5, 2, true>(p, row, rs, ybase, row_bytes, swz, u / CG, u % CG, lane);
                 else
@@ -609,7 +616,13 @@ static int launch_hadamard_t(HadArgs p, hipStream_t st)
 #endif
     if (per_cu < 1) per_cu = 1;
     long blocks = (long)device_cu_count() * per_cu;
-    if (blocks > p.M) blocks = p.M;
+    p.parts_log2 = 0;
+    if ((UNIT == 5 || UNIT == 3) && QUANT && p.M < 128) {
+        // short batch: share a row's units among workgroups while a CU is still free (units per row: a power of two here)
+        const int JT = (p.K + 15) / 16, units = ((JT + UNIT - 1) / UNIT) * (p.m / 32);
+        while ((2 << p.parts_log2) <= units && units % (2 << p.parts_log2) == 0 && (p.M << (p.parts_log2 + 1)) <= device_cu_count()) ++p.parts_log2;
+    }
+    if (blocks > (p.M << p.parts_log2)) blocks = p.M << p.parts_log2;
     if (QUANT && p.ldq == MQ_LD_TILED) blocks = ceil_div(blocks, 8) * 8;   // XCD-consistent row map (tiled_row_of)
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), lds, st, p);
     return check_launch("hadamard");

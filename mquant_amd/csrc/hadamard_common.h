@@ -19,6 +19,7 @@ struct HadArgs {
     const unsigned long long *masks = nullptr;   // prepared descriptor (mq_hadamard_prepare): lane masks of the sign operand
     const v4i *hfrag = nullptr;                  // prepared descriptor: +-1 half operand images of the fast mode, [ceil(K/32)][ceil(K/16)][64]
     int unit_j = 1, unit_g = 4;                  // K x K stage: a wave owns unit_j 16-row tiles x unit_g 16-column tiles
+    int parts_log2 = 0;                          // short batches: 2^parts_log2 workgroups share a row's K x K units (set by the launcher)
     int fp32_had;
     void *out;
     long ldo;

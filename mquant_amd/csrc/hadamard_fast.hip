@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, 3) void hadamard_fast_kernel(HadArgs p)
     for (int b = tid * 16; b < (16 * KS - K) * row_bytes; b += 256 * 16)
         *reinterpret_cast<v4i *>(ybase + K * row_bytes + b) = v4i{0, 0, 0, 0};
 
-    const bool remap = QUANT && p.ldq == MQ_LD_TILED && (gridDim.x & 7) == 0;
+    const bool remap = QUANT && p.ldq == MQ_LD_TILED && (gridDim.x & 7) == 0 && p.M >= 128;   // (short batches: hadamard.hip)
     const long v_end = remap ? ceil_div(p.M, 128) * 128 : p.M;
     for (long v = blockIdx.x; v < v_end; v += gridDim.x) {
         const long row = remap ? tiled_row_of(v) : v;
