@@ -622,7 +622,9 @@ static int launch_hadamard_t(HadArgs p, hipStream_t st)
         const int JT = (p.K + 15) / 16, units = ((JT + UNIT - 1) / UNIT) * (p.m / 32);
         while ((2 << p.parts_log2) <= units && units % (2 << p.parts_log2) == 0 && (p.M << (p.parts_log2 + 1)) <= device_cu_count()) ++p.parts_log2;
     }
-    if (blocks > (p.M << p.parts_log2)) blocks = p.M << p.parts_log2;
+    // (with the row map the VIRTUAL rows count: 130 rows are 256 virtual ones, and 136 workgroups would walk two of them each)
+    const long vrows = (QUANT && p.ldq == MQ_LD_TILED && p.M >= 128) ? ceil_div(p.M, 128) * 128 : (p.M << p.parts_log2);
+    if (blocks > vrows) blocks = vrows;
     if (QUANT && p.ldq == MQ_LD_TILED) blocks = ceil_div(blocks, 8) * 8;   // XCD-consistent row map (tiled_row_of)
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), lds, st, p);
     return check_launch("hadamard");

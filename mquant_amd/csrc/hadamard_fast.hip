@@ -268,7 +268,8 @@ static int launch_fast_t(HadArgs p, hipStream_t st)
     if (per_cu > 4) per_cu = 4;
     if (per_cu < 1) per_cu = 1;
     long blocks = 256L * per_cu;
-    if (blocks > p.M) blocks = p.M;
+    const long vrows = (QUANT && p.ldq == MQ_LD_TILED && p.M >= 128) ? ceil_div(p.M, 128) * 128 : p.M;   // (virtual rows of the row map)
+    if (blocks > vrows) blocks = vrows;
     if (QUANT && p.ldq == MQ_LD_TILED) blocks = ceil_div(blocks, 8) * 8;   // XCD-consistent row map (tiled_row_of)
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, p);
     return check_launch("hadamard_fast");
