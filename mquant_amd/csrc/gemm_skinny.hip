@@ -130,6 +130,99 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p)
     }
 }
 
+// Short reductions (K <= 4096: q|k|v, o_proj, gate|up): the K slices are the EIGHT WAVES of one workgroup, all on the same channel
+// pair; their partial sums meet in LDS and the waves share the epilogue -- no workspace, no second launch (8.2 -> ~5 us for q|k|v
+// at M = 1, profiles/r5_decode_gemm_bench.txt).  Plan id 61.
+template <int EPI, int TMX>
+__global__ __launch_bounds__(512) void gemm_skinny_wg_kernel(GemmArgs p)
+{
+    kernarg_warm<sizeof(GemmArgs)>();
+    __shared__ v4i red[8][TMX * 2][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long kts = p.K_pad >> 6;
+    const long ntp = blockIdx.x;                            // one channel pair per workgroup (grid = n_pairs)
+    const int kq = (int)(kts >> 3), kr = (int)(kts & 7);    // wave w owns kq (+1 if w < kr) k-tiles
+    const int kt0 = wave * kq + (wave < kr ? wave : kr);
+    const int nkt = kq + (wave < kr ? 1 : 0);
+    const long MT = (p.M + 15) >> 4;
+    const char *wp = reinterpret_cast<const char *>(p.w) + (ntp * kts + kt0) * 1024 + lane * 16;
+    const char *xp[TMX];
+#pragma unroll
+    for (int t = 0; t < TMX; ++t) {
+        const long mt = t < MT ? t : MT - 1;
+        xp[t] = reinterpret_cast<const char *>(p.a) + (mt * kts + kt0) * 1024 + lane * 16;
+    }
+    v4i acc[TMX][2];
+#pragma unroll
+    for (int t = 0; t < TMX; ++t) acc[t][0] = acc[t][1] = v4i{0, 0, 0, 0};
+    auto mac = [&](const v4i wq, const v4i (&x)[TMX]) {
+        const v4i w0 = v4i{(wq[0] << 4) & (int)0xF0F0F0F0, wq[0] & (int)0xF0F0F0F0, (wq[1] << 4) & (int)0xF0F0F0F0, wq[1] & (int)0xF0F0F0F0};
+        const v4i w1 = v4i{(wq[2] << 4) & (int)0xF0F0F0F0, wq[2] & (int)0xF0F0F0F0, (wq[3] << 4) & (int)0xF0F0F0F0, wq[3] & (int)0xF0F0F0F0};
+#pragma unroll
+        for (int t = 0; t < TMX; ++t) {
+            acc[t][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, x[t], acc[t][0], 0, 0, 0);
+            acc[t][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1, x[t], acc[t][1], 0, 0, 0);
+        }
+    };
+    constexpr int U = 4;
+    int kt = 0;
+    for (; kt + U <= nkt; kt += U) {
+        v4i wq[U], x[U][TMX];
+#pragma unroll
+        for (int u = 0; u < U; ++u) wq[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(wp + (long)(kt + u) * 1024));
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < TMX; ++t) x[u][t] = *reinterpret_cast<const v4i *>(xp[t] + (long)(kt + u) * 1024);
+#pragma unroll
+        for (int u = 0; u < U; ++u) mac(wq[u], x[u]);
+    }
+    for (; kt < nkt; ++kt) {
+        v4i x[TMX];
+        const v4i wq = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(wp + (long)kt * 1024));
+#pragma unroll
+        for (int t = 0; t < TMX; ++t) x[t] = *reinterpret_cast<const v4i *>(xp[t] + (long)kt * 1024);
+        mac(wq, x);
+    }
+#pragma unroll
+    for (int t = 0; t < TMX; ++t) {
+        red[wave][t * 2][lane] = acc[t][0];
+        red[wave][t * 2 + 1][lane] = acc[t][1];
+    }
+    __syncthreads();
+    if (wave >= TMX * 2) return;                            // wave (2 t + e) finishes tile e of row tile t
+    const int t = wave >> 1, e = wave & 1;
+    v4i a = red[0][wave][lane];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) a += red[w][wave][lane];   // integers: exact in any order
+    const long m = t * 16 + (lane & 15), n = (ntp * 2 + e) * 16 + (lane >> 4) * 4;
+    if (m >= p.M || n >= p.N) return;
+    float sx = p.sx0, xz = 0.0f, x1v = 0.0f;
+    if (EPI != EPI_I32) {
+        if (p.sx_vec) sx = p.sx_vec[m];
+        else if (p.row_sel && p.row_sel[m]) sx = p.sx1;
+        if (p.x0) xz = p.x0[m];
+        if (p.x1) x1v = p.x1[m];
+    }
+    store_quad<EPI>(p, m, n, a >> 4, sx, xz, x1v);          // (levels x 16: the shift is exact)
+}
+
+template <int EPI>
+int launch_gemm_skinny_wg(const GemmArgs &p, hipStream_t st)
+{
+    if (!p.a_tiled || p.M > 32 || p.M < 1 || p.n_pairs > 0x7fffffffL || p.K_pad < 512)
+        return fail(MQ_EINVAL, "gemm_skinny_wg: needs tiled activations, 1 <= M <= 32, K_pad >= 512");
+    if (p.M <= 16) hipLaunchKernelGGL((gemm_skinny_wg_kernel<EPI, 1>), dim3((unsigned)p.n_pairs), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((gemm_skinny_wg_kernel<EPI, 2>), dim3((unsigned)p.n_pairs), dim3(512), 0, st, p);
+    return check_launch("gemm_skinny_wg");
+}
+
+template int launch_gemm_skinny_wg<EPI_F16>(const GemmArgs &, hipStream_t);
+template int launch_gemm_skinny_wg<EPI_BF16>(const GemmArgs &, hipStream_t);
+template int launch_gemm_skinny_wg<EPI_F32>(const GemmArgs &, hipStream_t);
+template int launch_gemm_skinny_wg<EPI_I32>(const GemmArgs &, hipStream_t);
+
 // K slices for a skinny launch: enough workgroups to stream the image from every CU (~3 per CU), at least four 64-wide k-tiles each
 int skinny_slices(long M, long N, long K_pad, size_t ws_bytes)
 {

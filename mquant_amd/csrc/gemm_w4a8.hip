@@ -39,6 +39,8 @@ int dispatch_ws_wgroup(const GemmArgs &p, int tile, hipStream_t st);   // gemm_w
 template <int EPI>
 int launch_gemm_skinny(const GemmArgs &p, hipStream_t st);             // gemm_skinny.hip (M <= 64 rows, W4, tiled activations; tile id 60)
 int skinny_slices(long M, long N, long K_pad, size_t ws_bytes);
+template <int EPI>
+int launch_gemm_skinny_wg(const GemmArgs &p, hipStream_t st);          // gemm_skinny.hip (M <= 16, K <= 4096: the K slices are a workgroup's waves; id 61)
 
 // GROUPED (--a_groupsize): the int32 accumulators of one activation group (64 or a multiple of 128 k) are scaled by
 // the group's activation scale of their row and added to fp32 accumulators in ascending group order; the epilogue
@@ -560,13 +562,18 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
     }
     if (ws_only) {
         // (an epilogue that exists in the wave-specialised kernels only -- RoPE in the store: the best of the tiles above, no split-K)
-    } else if (a_tiled && w4 && ceil_div(N, 128) <= 65535 && (M <= 16 || (M <= 64 && kps >= 64 && ceil_div(N, 128) < 128))) {
+    } else if (a_tiled && w4 && ceil_div(N, 128) <= 65535 &&
+               (M <= 16 || (M <= 32 && K_pad >= 512 && K_pad <= 4096 && N >= 2048) || (M <= 64 && kps >= 64 && ceil_div(N, 128) < 128))) {
         // A few rows (generation steps of the exam scripts): the weight stream is the work -- gemm_skinny.hip, id 60; `splits` = its
         // K slices, added up by splitk_reduce_kernel.  One row tile: every decoder shape gains (48 against 80 us per layer at M = 1);
         // two to four row tiles: only the long reductions over few channel tiles do (down_proj: 23 against 36 us at M = 32) --
         // profiles/r5_decode_gemm_bench.txt
         pl.tile = 60;
         pl.splits = have_ws ? skinny_slices(M, N, K_pad, ws_bytes) : 1;
+        if (M <= 32 && K_pad >= 512 && K_pad <= 4096 && N >= 2048) {   // short reduction, enough pairs: the slices are the eight waves of a workgroup
+            pl.tile = 61;
+            pl.splits = 1;
+        }
     } else if (t256 >= 192) {
         // gate|up: with tiled activations the 8-wave ping-pong kernel (gemm_pp.hip, round 4: 93-101 us against 108-116
         // for the software-pipelined tile 13 and 110-112 for the 16-wave tile 3, profiles/r4_pp_ab.txt); with row-major
@@ -601,6 +608,7 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
         pl.tile = force_tile;
     }
     if (force_splits > 0 && !ws_only) pl.splits = force_splits;
+    if (pl.tile == 61) pl.splits = 1;                                  // (its K slices are the waves of a workgroup)
     if (pl.splits > kps) pl.splits = (int)kps;
     if (pl.splits < 1) pl.splits = 1;
     return pl;
@@ -650,6 +658,9 @@ static int dispatch_tile(const GemmArgs &p, int tile, hipStream_t st)
             hipLaunchKernelGGL(splitk_reduce_kernel<EPI>, dim3((unsigned)blocks), dim3(256), 0, st, p);
             return check_launch("splitk_reduce");
         } else break;
+    case 61:
+        if constexpr (W_BITS == 4) return launch_gemm_skinny_wg<EPI>(p, st);
+        else break;
     case 10: return launch_gemm<64, 128, 2, 2, 3, W_BITS, EPI>(p, st);
     case 11: return launch_gemm<128, 64, 2, 2, 3, W_BITS, EPI>(p, st);
     case 12: return launch_gemm<128, 128, 4, 2, 3, W_BITS, EPI>(p, st);
