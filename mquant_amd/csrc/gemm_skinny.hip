@@ -141,9 +141,13 @@ __global__ __launch_bounds__(512) void gemm_skinny_wg_kernel(GemmArgs p)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long kts = p.K_pad >> 6;
-    const long ntp = blockIdx.x;                            // one channel pair per workgroup (grid = n_pairs)
-    const int kq = (int)(kts >> 3), kr = (int)(kts & 7);    // wave w owns kq (+1 if w < kr) k-tiles
-    const int kt0 = wave * kq + (wave < kr ? wave : kr);
+    const long ntp = blockIdx.x;                            // one channel pair per workgroup (grid.x = n_pairs)
+    // grid.y > 1 (long reductions): workgroup slice gs owns p.kq (+1 if gs < p.kr) k-tiles, its eight waves share them; the
+    // workgroups' sums then go through the workspace and splitk_reduce_kernel like the other kernel's
+    const int gs = (int)blockIdx.y;
+    const int g0 = gs * p.kq + (gs < p.kr ? gs : p.kr), gn = p.kq + (gs < p.kr ? 1 : 0);
+    const int kq = gn >> 3, kr = gn & 7;                    // wave w owns kq (+1 if w < kr) of them
+    const int kt0 = g0 + wave * kq + (wave < kr ? wave : kr);
     const int nkt = kq + (wave < kr ? 1 : 0);
     const long MT = (p.M + 15) >> 4;
     const char *wp = reinterpret_cast<const char *>(p.w) + (ntp * kts + kt0) * 1024 + lane * 16;
@@ -198,6 +202,18 @@ __global__ __launch_bounds__(512) void gemm_skinny_wg_kernel(GemmArgs p)
     for (int w = 1; w < 8; ++w) a += red[w][wave][lane];   // integers: exact in any order
     const long m = t * 16 + (lane & 15), n = (ntp * 2 + e) * 16 + (lane >> 4) * 4;
     if (m >= p.M || n >= p.N) return;
+    if (gridDim.y > 1) {                                    // one of several workgroup slices: park the exact partial sums
+        const v4i q = a >> 4;
+        int *dst = p.partial + ((long)gs * p.M + m) * p.N + n;
+        if ((p.N % 4) == 0) {
+            *reinterpret_cast<v4i *>(dst) = q;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < p.N) dst[r] = q[r];
+        }
+        return;
+    }
     float sx = p.sx0, xz = 0.0f, x1v = 0.0f;
     if (EPI != EPI_I32) {
         if (p.sx_vec) sx = p.sx_vec[m];
@@ -213,8 +229,14 @@ int launch_gemm_skinny_wg(const GemmArgs &p, hipStream_t st)
 {
     if (!p.a_tiled || p.M > 32 || p.M < 1 || p.n_pairs > 0x7fffffffL || p.K_pad < 512)
         return fail(MQ_EINVAL, "gemm_skinny_wg: needs tiled activations, 1 <= M <= 32, K_pad >= 512");
-    if (p.M <= 16) hipLaunchKernelGGL((gemm_skinny_wg_kernel<EPI, 1>), dim3((unsigned)p.n_pairs), dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((gemm_skinny_wg_kernel<EPI, 2>), dim3((unsigned)p.n_pairs), dim3(512), 0, st, p);
+    if (p.splits < 1 || p.splits > 65535) return fail(MQ_EINVAL, "gemm_skinny_wg: bad slice count %d", p.splits);
+    GemmArgs g = p;
+    const long kts = p.K_pad / 64;
+    g.kq = (int)(kts / p.splits);
+    g.kr = (int)(kts % p.splits);
+    const dim3 grid((unsigned)p.n_pairs, (unsigned)p.splits);
+    if (p.M <= 16) hipLaunchKernelGGL((gemm_skinny_wg_kernel<EPI, 1>), grid, dim3(512), 0, st, g);
+    else hipLaunchKernelGGL((gemm_skinny_wg_kernel<EPI, 2>), grid, dim3(512), 0, st, g);
     return check_launch("gemm_skinny_wg");
 }
 
@@ -222,6 +244,17 @@ template int launch_gemm_skinny_wg<EPI_F16>(const GemmArgs &, hipStream_t);
 template int launch_gemm_skinny_wg<EPI_BF16>(const GemmArgs &, hipStream_t);
 template int launch_gemm_skinny_wg<EPI_F32>(const GemmArgs &, hipStream_t);
 template int launch_gemm_skinny_wg<EPI_I32>(const GemmArgs &, hipStream_t);
+
+// workgroup slices of the eight-wave kernel on a long reduction: ~2 workgroups per CU, at least 32 k-tiles (four per wave) each
+int skinny_wg_slices(long M, long N, long K_pad, size_t ws_bytes)
+{
+    const long pairs = ceil_div(N, 32), kts = K_pad / 64;
+    long s = ceil_div(2L * device_cu_count(), pairs);
+    if (s > kts / 32) s = kts / 32;
+    if (s > 64) s = 64;
+    while (s > 1 && (size_t)(s * M * N * 4) > ws_bytes) --s;
+    return s > 1 ? (int)s : 1;
+}
 
 // K slices for a skinny launch: enough workgroups to stream the image from every CU (~3 per CU), at least four 64-wide k-tiles each
 int skinny_slices(long M, long N, long K_pad, size_t ws_bytes)

@@ -39,6 +39,7 @@ int dispatch_ws_wgroup(const GemmArgs &p, int tile, hipStream_t st);   // gemm_w
 template <int EPI>
 int launch_gemm_skinny(const GemmArgs &p, hipStream_t st);             // gemm_skinny.hip (M <= 64 rows, W4, tiled activations; tile id 60)
 int skinny_slices(long M, long N, long K_pad, size_t ws_bytes);
+int skinny_wg_slices(long M, long N, long K_pad, size_t ws_bytes);
 template <int EPI>
 int launch_gemm_skinny_wg(const GemmArgs &p, hipStream_t st);          // gemm_skinny.hip (M <= 16, K <= 4096: the K slices are a workgroup's waves; id 61)
 
@@ -573,6 +574,9 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
         if (M <= 32 && K_pad >= 512 && K_pad <= 4096 && N >= 2048) {   // short reduction, enough pairs: the slices are the eight waves of a workgroup
             pl.tile = 61;
             pl.splits = 1;
+        } else if (M <= 32 && K_pad > 4096 && have_ws) {               // long reduction: a few workgroup slices of eight waves each
+            pl.tile = 61;
+            pl.splits = skinny_wg_slices(M, N, K_pad, ws_bytes);
         }
     } else if (t256 >= 192) {
         // gate|up: with tiled activations the 8-wave ping-pong kernel (gemm_pp.hip, round 4: 93-101 us against 108-116
@@ -604,11 +608,10 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
         if (s > 1) { pl.tile = 3; pl.splits = (int)s; }
     }
     if (force_tile >= 0 && (!ws_only || (force_tile >= 40 && force_tile < 60))) {
-        if (pl.tile == 60 && force_tile != 60) pl.splits = 1;          // (the slices were the skinny kernel's)
+        if ((pl.tile == 60 || pl.tile == 61) && force_tile != pl.tile) pl.splits = 1;   // (the slices were the skinny kernel's)
         pl.tile = force_tile;
     }
     if (force_splits > 0 && !ws_only) pl.splits = force_splits;
-    if (pl.tile == 61) pl.splits = 1;                                  // (its K slices are the waves of a workgroup)
     if (pl.splits > kps) pl.splits = (int)kps;
     if (pl.splits < 1) pl.splits = 1;
     return pl;
@@ -659,8 +662,14 @@ static int dispatch_tile(const GemmArgs &p, int tile, hipStream_t st)
             return check_launch("splitk_reduce");
         } else break;
     case 61:
-        if constexpr (W_BITS == 4) return launch_gemm_skinny_wg<EPI>(p, st);
-        else break;
+        if constexpr (W_BITS == 4) {
+            const int rc = launch_gemm_skinny_wg<EPI>(p, st);
+            if (rc != MQ_OK || p.splits == 1) return rc;
+            long blocks = ceil_div(p.M * ceil_div(p.N, 4), 256);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(splitk_reduce_kernel<EPI>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+            return check_launch("splitk_reduce");
+        } else break;
     case 10: return launch_gemm<64, 128, 2, 2, 3, W_BITS, EPI>(p, st);
     case 11: return launch_gemm<128, 64, 2, 2, 3, W_BITS, EPI>(p, st);
     case 12: return launch_gemm<128, 128, 4, 2, 3, W_BITS, EPI>(p, st);

@@ -44,7 +44,7 @@ def test_plan_and_every_slice_count_are_exact(M, N, K):
     o.call("mq_gemm_debug_plan", M, N, at.K_pad, 4, 1, 1, tile[0:].data_ptr(), tile[1:].data_ptr())
     assert (tile[0].item() in (60, 61)) == (M <= 16 or K >= 8192 or (M <= 32 and K <= 4096 and N >= 2048)), (M, N, K, tile)
     try:
-        for force in ((-1, 0), (60, 1), (60, 2), (60, 5), (47, 1)) + (((61, 0),) if M <= 32 else ()):   # the plan, forced slice counts, the tiled kernel, the in-workgroup split
+        for force in ((-1, 0), (60, 1), (60, 2), (60, 5), (47, 1)) + (((61, 1), (61, 3)) if M <= 32 else ()):   # the plan, forced slice counts, the tiled kernel, the in-workgroup split
             o.gemm_debug_force(*force)
             for _ in range(2):                                                 # twice: back-to-back launches over the same workspace
                 acc = o.gemm_w4a8_i32(at, img, 4, N)
