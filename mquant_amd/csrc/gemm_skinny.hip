@@ -8,9 +8,11 @@
 // work: a wave owns one 32-channel pair of the W4 image and a slice of K, pulls its 1 KiB pieces straight from HBM into
 // registers (one global_load_dwordx4 per 64-wide k-tile: the piece is already in the MFMA fragment order, no LDS), reads the
 // matching activation pieces (L2-resident, shared by every wave), unpacks the nibbles and issues V_MFMA_I32_16X16X64_I8.
-// (pairs / 4) x slices workgroups of four waves: several hundred to a few thousand waves stream the image together.
+// Two kernels: gemm_skinny_wg_kernel (plan id 61, up to two row tiles) -- one workgroup per pair, its EIGHT WAVES are the K slices and
+// meet in LDS (short reductions: one launch, no workspace; long ones: a few workgroup slices on top) -- and gemm_skinny_kernel
+// (plan id 60, up to four row tiles on long reductions) -- (pairs / 4) x slices workgroups of four waves, one wave per pair and slice.
 //
-// Reduction over the K slices: every workgroup parks its exact int32 partial sums in the split-K workspace ([slice][M][N], the
+// Reduction over slices of DIFFERENT workgroups: every workgroup parks its exact int32 partial sums in the split-K workspace ([slice][M][N], the
 // layout of the tiled kernels' split-K) and splitk_reduce_kernel (gemm_w4a8.hip) adds them and runs the common epilogue in a
 // second launch.  (Reducing inside the launch -- the last workgroup to count itself on a per-channel-block counter adds the
 // slices -- was built first and is exact, but the agent-scope release / acquire it needs writes back and invalidates a whole
