@@ -530,7 +530,7 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
     const long kps = K_pad / 128;
     const long t256 = ceil_div(M, 256) * ceil_div(N, 256);
     Plan pl = {10, 1};
-    long best = -1;
+    long best = -1, best_tiles = 0;
     if (a_tiled) {
         // wave-specialised kernels (gemm_ws.hip), every operand byte arrives as contiguous KiB pieces:
         // the bytes the busiest CU has to pull decide, ceil(tiles/256) x (BM + BN/2) per unit of K
@@ -548,7 +548,7 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
             if (c[0] == WS192 && !w4) continue;
             const long tiles = ceil_div(M, c[1]) * ceil_div(N, c[2]);
             const long cost = ceil_div(tiles, 256) * (c[1] + (w4 ? c[2] / 2 : c[2]));
-            if (best < 0 || cost < best) { best = cost; pl.tile = c[0]; }
+            if (best < 0 || cost < best) { best = cost; pl.tile = c[0]; best_tiles = tiles; }
         }
     } else {
         // Row-major activations: small GEMMs are bound by the row gather (~14.5 B/clk/CU out of L2,
@@ -601,6 +601,14 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
     } else if (a_tiled && best >= 0 && ceil_div(M, 96) * ceil_div(N, 128) >= 128) {
         // enough 96..192 x 128 tiles for most CUs: the wave-specialised kernel walks the whole reduction
         // (down_proj, K = 19968: 64 us against 60 + 14 us for split-K partials plus the reduce kernel)
+    } else if (have_ws && kps >= 64 && a_tiled && best_tiles > 0 && M <= 256) {
+        // few tiles and a long reduction on tiled activations (down_proj of a short prompt): split K over the wave-specialised tile the
+        // cost model chose, ~2 workgroups per CU, at least eight k-steps each (M = 65 / 128: 36 / 38 us on the 16-wave tile below ->
+        // 29 / 33 us; level at 256 rows, behind at 384: profiles/r5_midm_gemm_bench.txt)
+        long s = ceil_div(2L * 256, best_tiles);
+        if (s > 16) s = 16;
+        while (s > 1 && ((size_t)(s * M * N * 4) > ws_bytes || kps / s < 8)) --s;
+        if (s > 1) pl.splits = (int)s;
     } else if (have_ws && kps >= 64 && t256 >= 8) {
         long s = (252 + t256 - 1) / t256;
         if (s > 8) s = 8;
