@@ -603,9 +603,9 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
         // (down_proj, K = 19968: 64 us against 60 + 14 us for split-K partials plus the reduce kernel)
     } else if (have_ws && kps >= 64 && a_tiled && best_tiles > 0 && M <= 256) {
         // few tiles and a long reduction on tiled activations (down_proj of a short prompt): split K over the wave-specialised tile the
-        // cost model chose, ~2 workgroups per CU, at least eight k-steps each (M = 65 / 128: 36 / 38 us on the 16-wave tile below ->
-        // 29 / 33 us; level at 256 rows, behind at 384: profiles/r5_midm_gemm_bench.txt)
-        long s = ceil_div(2L * 256, best_tiles);
+        // cost model chose, one round of workgroups (each fills a CU's LDS), at least eight k-steps each (M = 65 / 128 / 256: 36 / 38 / 44.5 us on the 16-wave tile
+        // below -> 19.7 / 21.7 / 31.4 us: profiles/r5_midm_gemm_bench.txt)
+        long s = (long)device_cu_count() / best_tiles;      // ONE round: a workgroup of these kernels fills a CU's LDS
         if (s > 16) s = 16;
         while (s > 1 && ((size_t)(s * M * N * 4) > ws_bytes || kps / s < 8)) --s;
         if (s > 1) pl.splits = (int)s;
