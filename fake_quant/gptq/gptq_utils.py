@@ -130,9 +130,12 @@ class GPTQ:
             W[:, i2:] -= E1 @ Hinv[i1:i2, i2:]
         if groupsize != -1 and not static_groups:
             qz.groupsize = int(groupsize)
-            qz.group_permuted = bool(actorder)          # groups of PERMUTED columns: no contiguous-k scale, simulated path only
-            qz.group_scales = None if actorder else torch.stack(group_scales, dim=1)
-            qz.group_zeros = None if actorder else torch.stack(group_zeros, dim=1)
+            # --act_order: the groups are runs of PERMUTED columns (column j of the solver's order is column perm[j] of the weight);
+            # the permutation is kept with the scales, and the integer backend gathers the activation columns the same way
+            qz.group_permuted = bool(actorder)
+            qz.group_perm = perm.clone() if actorder else None
+            qz.group_scales = torch.stack(group_scales, dim=1)
+            qz.group_zeros = torch.stack(group_zeros, dim=1)
         if actorder:
             Q = Q[:, invperm]
         self.layer.weight.data = Q.reshape(self.layer.weight.shape).to(self.layer.weight.data.dtype)

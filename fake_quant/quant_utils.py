@@ -409,7 +409,13 @@ class ActQuantWrapper(torch.nn.Module):
         qz = self.quantizer
         g = int(wq.groupsize)
         if getattr(wq, "group_scales", None) is None:
-            return "weight groups over --act_order's permuted columns" if getattr(wq, "group_permuted", False) else "weight group scales not recorded"
+            return "weight group scales not recorded"
+        if getattr(wq, "group_permuted", False):
+            # --act_order: the groups are runs of PERMUTED columns; the engine gathers the activation columns the same way
+            if getattr(wq, "group_perm", None) is None:
+                return "weight groups over --act_order's permuted columns, permutation not recorded"
+            if (not qz.static) and getattr(qz, "groupsize", -1) > 0:
+                return "--act_order weight groups with group-wise activations (the activation groups would follow the permutation)"
         if not getattr(wq, "sym", False):
             return "asymmetric weights with --w_groupsize"
         if self.split:
@@ -521,11 +527,17 @@ class ActQuantWrapper(torch.nn.Module):
             scale = scale.expand(W2.shape[0]).contiguous()
         w_shift = None
         w_groups = None
+        col_perm = None
         if getattr(wq, "group_scales", None) is not None:
             # --w_groupsize: one scale per (channel, group of g consecutive input channels); levels on each group's own grid
             g = int(wq.groupsize)
             gs = wq.group_scales.to(device=device, dtype=torch.float32)                  # [N, K / g]
             assert gs.shape == (W2.shape[0], W2.shape[1] // g), "group scales do not match the weight"
+            if getattr(wq, "group_permuted", False):
+                # --act_order: group j holds columns perm[j g .. (j + 1) g - 1]; the image keeps the solver's column order
+                col_perm = wq.group_perm.to(device=device, dtype=torch.long).contiguous()
+                assert col_perm.numel() == W2.shape[1]
+                W2 = W2.index_select(1, col_perm)
             half = 1 << (wq.bits - 1)
             levels = torch.round(W2.float().reshape(W2.shape[0], -1, g) / gs[:, :, None]).clamp(-half, half - 1)
             levels = levels.reshape(W2.shape).to(torch.int8)
@@ -583,14 +595,14 @@ class ActQuantWrapper(torch.nn.Module):
             scale = w_groups[0][-1].contiguous()                                         # (unused by the kernels; the last group's, as upstream keeps)
         return dict(levels=levels, scale=scale, bits=wq.bits,
                     bias=None if bias is None else bias.data.to(device), s0=s0, s1=s1,
-                    had=had, w0=w0, dynamic=dynamic, w_shift=w_shift, split_slice=split_slice, w_groups=w_groups)
+                    had=had, w0=w0, dynamic=dynamic, w_shift=w_shift, split_slice=split_slice, w_groups=w_groups, col_perm=col_perm)
 
     def _build_real(self, device):
         from mquant_amd.engine import W4A8Linear
         p = self._real_parts(device)
         self._real = W4A8Linear(p["levels"], p["scale"], p["bits"], p["bias"], p["s0"], p["s1"],
                                 had=p["had"], w0=p["w0"], dynamic=p["dynamic"], w_shift=p["w_shift"],
-                                split_slice=p["split_slice"], w_groups=p["w_groups"])
+                                split_slice=p["split_slice"], w_groups=p["w_groups"], col_perm=p["col_perm"])
         return self._real
 
     def _forward_real(self, x):
@@ -776,7 +788,7 @@ class SiblingGroup:
         p0 = parts[0]
         if any(p["s0"] != p0["s0"] or p["s1"] != p0["s1"] or p["bits"] != p0["bits"] or p["dynamic"] is not None
                or p["w_shift"] is not None or p["levels"].shape[1] != p0["levels"].shape[1]
-               or (p["w_groups"] is None) != (p0["w_groups"] is None)
+               or (p["w_groups"] is None) != (p0["w_groups"] is None) or p["col_perm"] is not None
                or (p["w_groups"] is not None and p["w_groups"][1] != p0["w_groups"][1]) for p in parts):
             return False
         w_groups = None

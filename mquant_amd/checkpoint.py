@@ -17,6 +17,7 @@ files, static + symmetric only, still load):
     <n>.w0              fp32 [N]        (optional) the fp32 column of a ``split`` layer (L1)
     <n>.w_shift         fp32 [N]        (optional, --w_asym) s_w (2^(bits-1) - z_w): the rank-1 epilogue factor of the zero points
     <n>.w_group_scales  fp32 [K/g, N]   (optional, --w_groupsize g) one scale per (group, channel)
+    <n>.col_perm        int64 [K]       (optional, --act_order with --w_groupsize) image column j = input channel col_perm[j]
     <n>.act_clip        fp32 [1]        (dynamic activation modes) clip_ratio
     <n>.meta            int64 [20]      see META below (dynamic modes: act_mode = 1 and a_sym / a_per_tensor / a_groupsize)
 
@@ -90,6 +91,8 @@ def export_wrapper(wrapper, device=None) -> Dict[str, torch.Tensor]:
         out["w_shift"] = p["w_shift"].float().cpu()
     if p["w_groups"] is not None:
         out["w_group_scales"] = p["w_groups"][0].float().cpu()
+    if p.get("col_perm") is not None:
+        out["col_perm"] = p["col_perm"].to(torch.int64).cpu()
     dyn = p["dynamic"]
     if dyn is not None:
         out["act_clip"] = torch.tensor([float(dyn["clip_ratio"])], dtype=torch.float32)
@@ -146,9 +149,10 @@ def build_linear(rec: Dict[str, torch.Tensor], device):
                        per_tensor=bool(m["a_per_tensor"]), groupsize=m["a_groupsize"])
     w_shift = rec["w_shift"].to(device) if "w_shift" in rec else None
     w_groups = (rec["w_group_scales"].to(device).contiguous(), m["w_groupsize"]) if m["w_groupsize"] > 0 else None
+    col_perm = rec["col_perm"].to(device=device, dtype=torch.long) if "col_perm" in rec else None
     return W4A8Linear(levels, rec["w_scale"].to(device), m["w_bits"], bias, s0, s1 if m["msq"] else None,
                       had=had, w0=w0, in_features=m["in_features"], dynamic=dynamic, w_shift=w_shift,
-                      split_slice=bool(m["split_slice"]), w_groups=w_groups)
+                      split_slice=bool(m["split_slice"]), w_groups=w_groups, col_perm=col_perm)
 
 
 def split_records(tensors: Dict[str, torch.Tensor], prefix: str = "") -> Dict[str, Dict[str, torch.Tensor]]:

@@ -103,7 +103,7 @@ class W4A8Linear:
                  had: Optional[HadamardSpec] = None, w0: Optional[torch.Tensor] = None,
                  in_features: Optional[int] = None, dynamic: Optional[dict] = None,
                  w_shift: Optional[torch.Tensor] = None, split_slice: bool = False,
-                 w_groups: Optional[Tuple[torch.Tensor, int]] = None):
+                 w_groups: Optional[Tuple[torch.Tensor, int]] = None, col_perm: Optional[torch.Tensor] = None):
         assert levels.is_cuda and levels.dtype == torch.int8 and levels.dim() == 2
         self.N, self.K = levels.shape
         self.K_pad = ops.ceil_to(self.K, 128)
@@ -129,6 +129,14 @@ class W4A8Linear:
             assert tbl.dtype == torch.float32 and tuple(tbl.shape) == (self.K // g, self.N) and self.K % g == 0
             assert w0 is None and w_shift is None, "weight groups: no split column, symmetric levels"
             self.w_groups = (tbl.contiguous(), int(g))
+        #: --act_order with --w_groupsize (reference gptq/gptq_utils.py:228-233, 263-273): the weight image keeps the solver's column
+        #: order (column j = input channel col_perm[j]; its groups are runs of those columns), so the activation columns are gathered
+        #: the same way -- after the pad and the online Hadamard, in front of the quantizer (a gather of the fp tensor: elementwise
+        #: quantizers and per-row scales commute with a column permutation).
+        self.col_perm = None
+        if col_perm is not None:
+            assert col_perm.dtype == torch.long and col_perm.numel() == self.K and w0 is None and not split_slice
+            self.col_perm = col_perm.contiguous()
         self.s_x0 = float(s_x0)
         self.s_x1 = None if s_x1 is None else float(s_x1)
         self.had = had
@@ -176,6 +184,9 @@ class W4A8Linear:
         M = x2.shape[0]
         a = WORKSPACE.act(x2.device, M, self.K_pad)
         x0 = WORKSPACE.x0(x2.device, M) if self.split else None
+        if self.col_perm is not None:
+            ops.quantize_act_i8(self._gathered(x2), self.s_x0, self.s_x1, row_sel=row_sel, out=a)
+            return a, None
         if self.had is not None:
             ops.hadamard_quant_i8(x2, self.had.n, self.had.K, self.had.bits, self.s_x0, self.s_x1,
                                   fp32_had=self.had.fp32_had, row_sel=row_sel,
@@ -184,6 +195,14 @@ class W4A8Linear:
             ops.quantize_act_i8(x2, self.s_x0, self.s_x1, row_sel=row_sel, skip_col0=self.split,
                                 out=a, x0_out=x0)
         return a, x0
+
+    def _gathered(self, x2: torch.Tensor) -> torch.Tensor:
+        """The Linear's input in the weight image's column order (--act_order): pad, online Hadamard (its own launch), gather."""
+        if x2.shape[1] < self.K and self.had is None:
+            x2 = torch.nn.functional.pad(x2, (0, self.K - x2.shape[1]))
+        if self.had is not None:
+            x2 = ops.hadamard(x2, self.had.n, self.had.K, self.had.bits, self.had.fp32_had, fast=self.had.fast)
+        return x2.index_select(1, self.col_perm)
 
     def act_buffer(self, M: int):
         """The workspace destination a quantizer of this layer's input writes (for producers that quantize themselves)."""
@@ -250,7 +269,9 @@ class W4A8Linear:
     def forward_dynamic(self, x2: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """[Hadamard ->] dynamic per-token quantize -> GEMM with per-row scales.  The row maximum
         needs the whole rotated row, so the Hadamard runs as its own launch here."""
-        if self.had is not None:
+        if self.col_perm is not None:
+            x2 = self._gathered(x2)
+        elif self.had is not None:
             x2 = ops.hadamard(x2, self.had.n, self.had.K, self.had.bits, self.had.fp32_had, fast=self.had.fast)
         a = WORKSPACE.act(x2.device, x2.shape[0], self.K_pad)
         g = int(self.dynamic.get("groupsize", -1) or -1)

@@ -369,14 +369,23 @@ def test_group_wise_gptq_attaches_every_groups_scale():
         assert "weight group size 8" in w._simulated_because() or w._simulated_because()
 
 
-def test_group_wise_gptq_with_act_order_stays_simulated_and_says_so():
+def test_group_wise_gptq_with_act_order_keeps_the_permutation_with_the_scales():
+    """--act_order + --w_groupsize: the groups are runs of permuted columns; the solver keeps the permutation next to every group's
+    scale (the integer backend gathers the activation columns the same way).  Groups of 8 are below the kernels' 64: the wrapper
+    says so instead of silently simulating."""
     llm = _llm_wrappers_after_gptq(w_groupsize=8, act_order=True)
     for w in llm:
         for wq in w.weight_quantizers.values():
-            assert wq.group_scales is None and wq.group_permuted
+            K = w.module.in_features
+            assert wq.group_permuted and wq.group_scales is not None and tuple(wq.group_scales.shape)[1] == K // 8
+            assert sorted(wq.group_perm.tolist()) == list(range(K))
+            # the stored weight, gathered into the solver's order, sits on the groups' grids
+            Wp = w.module.weight.data.float()[:, wq.group_perm]
+            lv = torch.round(Wp.reshape(Wp.shape[0], -1, 8) / wq.group_scales[:, :, None])
+            assert float((lv * wq.group_scales[:, :, None] - Wp.reshape(Wp.shape[0], -1, 8)).abs().max()) < 1e-5
     w = llm[0]
     w.quantizer.configure(bits=8, sym=True)
-    assert "permuted" in w._simulated_because() and "simulated" in w.backend() and "Backend:" in w.extra_repr()
+    assert "group size 8" in w._simulated_because() and "simulated" in w.backend() and "Backend:" in w.extra_repr()
     assert not w._real_ready(torch.zeros(2, w.module.in_features))
 
 

@@ -133,6 +133,8 @@ def _wrapper_from_golden(g, c):
     gs = torch.from_numpy(g["group_scales"].copy())
     wq.scale, wq.zero = gs[:, -1:].clone(), torch.zeros(c["N"], 1)            # what the reference's solver leaves behind ...
     wq.groupsize, wq.group_permuted, wq.group_scales = c["g"], False, gs      # ... and what this repository's keeps
+    if "perm" in g:                                                            # --act_order: the solver's column permutation
+        wq.group_permuted, wq.group_perm = True, torch.from_numpy(g["perm"].copy())
     qu.attach_weight_quantizer(wrap, "module", wq)
     return wrap
 
@@ -145,7 +147,7 @@ def test_wrapper_over_the_references_gptq_weights_matches_the_references_forward
     from fake_quant import quant_utils as qu
     from mquant_amd import ops
     paths = cases(golden_dir)
-    assert len(paths) == 8
+    assert len(paths) == 11
     for path in paths:
         g, c = load(path)
         dt = DT[c["dtc"]]
@@ -177,6 +179,9 @@ def test_wrapper_over_the_references_gptq_weights_matches_the_references_forward
         rows = torch.nn.functional.pad(rows, (0, c["K_pad"] - c["K_in"])) if c["K_pad"] != c["K_in"] else rows
         xr = ops.hadamard(rows, real.had.n, real.had.K, real.had.bits) if c["had"] else rows
         bias = None if not c["bias"] else wrap.module.bias.data.float().cpu().numpy()
+        if "perm" in g:                                # --act_order: the engine gathers the (rotated) columns into the solver's order
+            assert real.col_perm is not None and torch.equal(real.col_perm.cpu(), torch.from_numpy(g["perm"]))
+            xr = xr.index_select(1, real.col_perm)
         if c["mode"] == "static":
             a, _ = real.quantize(rows)
             qx = a.to_rows() if isinstance(a, ops.TiledAct) else a
@@ -196,8 +201,9 @@ def test_wrapper_over_the_references_gptq_weights_matches_the_references_forward
         np.testing.assert_array_equal(y.float().cpu().numpy().reshape(c["M"], c["N"]), oracle.round_to(want, c["dtc"]), err_msg=path)
 
 
-def test_gptq_with_weight_groups_runs_end_to_end_on_the_integer_path():
-    """This repository's solver on the GPU (groups of 128, no activation ordering) -> attach -> static calibration -> the wrapper
+@pytest.mark.parametrize("actorder", [False, True])
+def test_gptq_with_weight_groups_runs_end_to_end_on_the_integer_path(actorder):
+    """This repository's solver on the GPU (groups of 128, with and without --act_order) -> attach -> static calibration -> the wrapper
     runs mq_gemm_w4a8_wgroupscale and stays on the simulated evaluation of the same wrapper."""
     from fake_quant import quant_utils as qu
     from fake_quant.gptq.gptq_utils import GPTQ
@@ -210,13 +216,14 @@ def test_gptq_with_weight_groups_runs_end_to_end_on_the_integer_path():
     solver.quantizer.configure(4, perchannel=True, sym=True, mse=False)
     for i in range(3):
         solver.add_batch(torch.from_numpy(make_x(50 + i, (1, 80, K))).to(DEV))
-    solver.fasterquant(percdamp=0.01, groupsize=128, actorder=False, static_groups=False)
+    solver.fasterquant(percdamp=0.01, groupsize=128, actorder=actorder, static_groups=False)
     qu.attach_weight_quantizer(wrap, "module", solver.quantizer)
     wrap.quantizer.configure(bits=8, sym=True, static=True, observer_type="minmax")
     qu.calib_layer(wrap, [torch.from_numpy(make_x(60 + i, (M, K))).to(DEV) for i in range(2)], Args())
     x = torch.from_numpy(make_x(70, (M, K))).to(DEV)
     assert wrap._real_ready(x) and "weight groups of 128" in wrap.backend()
     y = wrap(x)
+    assert (wrap._real.col_perm is not None) == actorder
     wrap.real_quant = False
     y_sim = wrap(x.clone())
     np.testing.assert_allclose(y.cpu().numpy(), y_sim.cpu().numpy(), rtol=0, atol=1e-3 * float(y_sim.abs().max()))
@@ -272,3 +279,22 @@ def test_sibling_fusion_with_weight_groups_equals_the_per_linear_evaluation():
     plain = model(x)
     assert all(torch.equal(a, b) for a, b in zip(fused, plain))
     assert model.attn.k_proj._real is not None and model.attn.k_proj._real.w_groups is not None
+
+
+def test_act_order_groups_round_trip_through_the_flat_checkpoint(golden_dir):
+    """--act_order + --w_groupsize: the record keeps the column permutation (``col_perm``) and the rebuilt engine gives the wrapper's bits."""
+    import os
+    from fake_quant import quant_utils as qu
+    from mquant_amd import checkpoint
+    path = os.path.join(golden_dir, "wrapper_wgrp_ao_g128_static_1024_f32.npz")
+    g, c = load(path)
+    wrap = _wrapper_from_golden(g, c)
+    wrap.quantizer.configure(bits=8, sym=True, static=True, observer_type="minmax")
+    qu.calib_layer(wrap, [torch.from_numpy(make_x(c["seed"] + 10 + i, (c["M"], c["K_in"]))).to(DEV) for i in range(3)], Args())
+    x = torch.from_numpy(make_x(c["seed"] + 20, (c["M"], c["K_in"]))).to(DEV)
+    y = wrap(x)
+    assert "weight groups of 128" in wrap.backend()
+    rec = checkpoint.export_wrapper(wrap)
+    assert "col_perm" in rec and rec["col_perm"].dtype == torch.int64 and rec["col_perm"].numel() == c["K_pad"]
+    eng = checkpoint.build_linear(rec, torch.device(DEV))
+    assert torch.equal(eng.forward(x), y)

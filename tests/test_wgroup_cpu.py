@@ -29,13 +29,15 @@ def load(path):
 
 
 def levels_of(g, c):
+    """The levels in the SOLVER's column order (--act_order cases: columns gathered by ``perm``; ``qx`` is stored in that order)."""
     G = c["K_pad"] // c["g"]
-    lv = np.rint(g["W"].reshape(c["N"], G, c["g"]) / g["group_scales"][:, :, None]).astype(np.int8)
+    W = g["W"][:, g["perm"]] if "perm" in g else g["W"]
+    lv = np.rint(W.reshape(c["N"], G, c["g"]) / g["group_scales"][:, :, None]).astype(np.int8)
     return lv.reshape(c["N"], c["K_pad"])
 
 
 def test_fixture_set_is_complete(golden_dir):
-    assert len(cases(golden_dir)) == 8
+    assert len(cases(golden_dir)) == 11 and sum("wrapper_wgrp_ao_" in p for p in cases(golden_dir)) == 3
 
 
 def test_oracle_equals_the_reference_forward(golden_dir):
@@ -75,9 +77,12 @@ def test_this_repositorys_solver_keeps_every_groups_scale_and_equals_the_referen
                 Kh = had_table["n2k"][c["K_pad"]]
                 xin = torch.from_numpy(oracle.hadamard(xin.numpy(), c["K_pad"], Kh, had_table["mats"][Kh]))
             solver.add_batch(xin.reshape(1, -1, c["K_pad"]))
-        solver.fasterquant(percdamp=0.01, groupsize=c["g"], actorder=False, static_groups=False)
+        actorder = "perm" in g
+        solver.fasterquant(percdamp=0.01, groupsize=c["g"], actorder=actorder, static_groups=False)
         qz = solver.quantizer
-        assert qz.groupsize == c["g"] and not qz.group_permuted
+        assert qz.groupsize == c["g"] and qz.group_permuted == actorder
+        if actorder:                                   # the reference's permutation, kept with the scales
+            np.testing.assert_array_equal(qz.group_perm.numpy(), g["perm"], err_msg=path)
         np.testing.assert_array_equal(qz.group_scales.numpy(), g["group_scales"], err_msg=path)
         np.testing.assert_array_equal(lin.weight.data.numpy(), g["W"], err_msg=path)
 

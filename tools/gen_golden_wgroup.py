@@ -37,6 +37,10 @@ CASES = {
     "g128_agrp_1024_f32": (1024, 1024, 32, 12, 3150, False, True, 128, "agrp", 0, 4),
     "g128_agrp_had_1280_f16": (1280, 1280, 24, 8, 3160, True, False, 128, "agrp", 1, 4),
     "g128_static_pad_896_f32": (896, 1024, 24, 8, 3170, False, False, 128, "static", 0, 4),
+    # --act_order (tags "ao_..."): the groups are runs of the solver's PERMUTED columns (gptq_utils.py:226-230, 263-273)
+    "ao_g128_static_1024_f32": (1024, 1024, 40, 16, 3180, False, True, 128, "static", 0, 4),
+    "ao_g64_dyn_512_f16": (512, 512, 24, 10, 3190, False, False, 64, "dyn", 1, 4),
+    "ao_g128_static_had_1280_f16": (1280, 1280, 32, 12, 3200, True, True, 128, "static", 1, 4),
 }
 
 
@@ -83,13 +87,21 @@ def main():
             _f(x)
             _rec.append(_q.scale.reshape(-1).float().clone())
         solver.quantizer.find_params = recording_find
-        solver.fasterquant(percdamp=0.01, groupsize=g, actorder=False, static_groups=False)
+        actorder = tag.startswith("ao_")
+        perm = torch.arange(K_pad)
+        if actorder:                                              # the permutation the solver is about to take (gptq_utils.py:210-227)
+            Hc = solver.H.clone()
+            dead = torch.diag(Hc) == 0
+            Hc[dead, dead] = 1
+            perm = torch.argsort(torch.diag(Hc), descending=True)
+        solver.fasterquant(percdamp=0.01, groupsize=g, actorder=actorder, static_groups=False)
         G = K_pad // g
         group_scales = torch.stack(rec[-G:], dim=1)               # the first recorded call is the whole-row warm-up of :208
         assert len(rec) in (G, G + 1) and torch.equal(group_scales[:, -1], solver.quantizer.scale.reshape(-1).float())
         Wq = lin.weight.data.float().clone()
-        lv = torch.round(Wq.reshape(N, G, g) / group_scales[:, :, None])
-        assert float((lv * group_scales[:, :, None] - Wq.reshape(N, G, g)).abs().max()) < 1e-6 and float(lv.abs().max()) <= 2 ** (w_bits - 1)
+        Wp = Wq[:, perm]                                          # the solver's column order: group j = columns perm[j g .. (j + 1) g - 1]
+        lv = torch.round(Wp.reshape(N, G, g) / group_scales[:, :, None])
+        assert float((lv * group_scales[:, :, None] - Wp.reshape(N, G, g)).abs().max()) < 1e-6 and float(lv.abs().max()) <= 2 ** (w_bits - 1)
         # ---- the reference's wrapper over the solved weights
         lin = lin.to(dt)
         wrap = qu.ActQuantWrapper(lin)
@@ -135,8 +147,11 @@ def main():
                 out["s_x_groups"] = scale.reshape(M, G, g)[:, :, 0].float().numpy().astype(np.float32)
             else:
                 out["s_x_rows"] = scale.reshape(M, K_pad)[:, 0].float().numpy().astype(np.float32)
+        qx = qx[:, perm]                                          # activation levels in the solver's column order
         acc = torch.einsum("mgk,ngk->mgn", qx.reshape(M, G, g), lv.reshape(N, G, g).to(torch.int64))
         assert int(acc.abs().max()) < 2 ** 31
+        if actorder:
+            out["perm"] = perm.numpy().astype(np.int64)
         gen_golden.save(f"wrapper_wgrp_{tag}", y=y.float().numpy().reshape(M, N), W=Wq.numpy(),
                         group_scales=group_scales.numpy().astype(np.float32), qx=qx.numpy().astype(np.int8),
                         acc_groups=acc.numpy().astype(np.int32), mode=np.array(mode),
