@@ -76,3 +76,31 @@ def test_epilogue_terms(out_dtype, M, N, K):
     o.splitk_workspace(torch.device(DEV), 64 << 20)
     y = o.gemm_w4a8_rowscale(at, img, 4, N, to_dev(rows), to_dev(s_w), bias=to_dev(bias), x0=to_dev(x0), w0=to_dev(w0), out_dtype=out_dtype)
     np.testing.assert_array_equal(y.float().cpu().numpy(), y_ref)
+
+
+@pytest.mark.parametrize("shape", ["qkv", "down"])
+def test_a_rows_result_does_not_depend_on_the_batch_it_came_in(shape):
+    """Static quantization is row-local, so a row's output must be the same bits whether it arrives alone (generation: the weight-streaming
+    GEMM, a Hadamard row shared by eight workgroups), in a short batch, or inside a 300-row prefill (tiled GEMMs, one workgroup per
+    Hadamard row, the XCD row map) -- the Qwen2-VL-7B q|k|v shape and down_proj with its padded online Hadamard (MSQ scales)."""
+    from fake_quant import hadamard_utils as hu
+    from mquant_amd import ops as o
+    from mquant_amd.engine import HadamardSpec, W4A8Linear
+    dev = torch.device(DEV)
+    o.splitk_workspace(dev, 64 << 20)
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    if shape == "qkv":
+        N, K, k_in, had = 4608, 3584, 3584, None
+    else:
+        N, K, k_in = 3584, 19968, 18944
+        _, Kh = hu.get_hadK(K)
+        had = HadamardSpec(K, Kh, hu.had_sign_bits(Kh, dev), False)
+    w = torch.randn((N, K), generator=gen, device=DEV) * 0.02
+    lin = W4A8Linear.from_float(w, 4, 0.05, 0.02, bias=torch.randn((N,), generator=gen, device=DEV), had=had, in_features=k_in)
+    x = torch.randn((300, k_in), generator=gen, device=DEV, dtype=torch.float16)
+    sel = (torch.arange(300, device=DEV) % 3 == 0).to(torch.uint8)
+    full = lin.forward(x, sel)
+    for rows in ([7], [0, 1, 2, 3, 4], list(range(16, 40)), list(range(100, 164))):
+        idx = torch.tensor(rows, device=DEV)
+        part = lin.forward(x.index_select(0, idx).contiguous(), sel.index_select(0, idx).contiguous())
+        assert torch.equal(part, full.index_select(0, idx)), (shape, rows[:2], len(rows))
