@@ -234,13 +234,13 @@ def full_prefill_report(pf, dev, args):
 
 def sustained_int8_peak(pf, dev):
     """The dense int8 matrix rate THIS box sustains under its package power limit on the benchmark's own operand bytes
-    (mq_bench_mfma_burn, csrc/bench_probe.hip: register-only MFMA chains on every CU, no memory traffic).  The GEMM family runs
+    (mq_bench_mfma_burn, csrc/bench_probe.hip -> libmquant_bench.so, bench-only: register-only MFMA chains on every CU, no memory traffic).  The GEMM family runs
     at the power limit -- the same launch is 10-30 % slower on real operand bytes than on zeros,
     profiles/r5_clock_reconciliation.txt -- so this, not the nominal 5 POP/s at 2.4 GHz, is what the matrix cores can deliver here.
     Reported beside the nominal peak; the nominal stays the denominator of ``frac``."""
     import ctypes
     import torch
-    from mquant_amd import ops
+    from mquant_amd import _lib, ops
     L = max(pf.layers, key=lambda l: l.lin.gemm_ops(l.spec.M))           # the dominant launch (gate|up)
     a, _ = L.lin.quantize(L.x, L.row_sel)
     a_bytes = (a.data if isinstance(a, ops.TiledAct) else a).reshape(-1)[: 4 * 1024].contiguous().view(torch.int32)
@@ -252,11 +252,11 @@ def sustained_int8_peak(pf, dev):
     out = {}
     for kind, name in ((1, "mfma_i32_16x16x64_i8"), (0, "mfma_i32_32x32x32_i8")):
         rate = ctypes.c_double(0.0)
-        ops.call("mq_bench_mfma_burn", kind, operands.data_ptr(), 2000, 60, sink.data_ptr(), ctypes.addressof(rate), ops._stream())
+        _lib.call_bench("mq_bench_mfma_burn", kind, operands.data_ptr(), 2000, 60, sink.data_ptr(), ctypes.addressof(rate), ops._stream())
         out[name] = round(rate.value / 1e12, 1)
     zeros = torch.zeros_like(operands)
     rate = ctypes.c_double(0.0)
-    ops.call("mq_bench_mfma_burn", 1, zeros.data_ptr(), 2000, 60, sink.data_ptr(), ctypes.addressof(rate), ops._stream())
+    _lib.call_bench("mq_bench_mfma_burn", 1, zeros.data_ptr(), 2000, 60, sink.data_ptr(), ctypes.addressof(rate), ops._stream())
     out["mfma_i32_16x16x64_i8_all_zero_operands"] = round(rate.value / 1e12, 1)
     return out
 

@@ -95,8 +95,9 @@ def gptq_group(block_call: Callable[[Sample], object], samples: Sequence[Sample]
         quantizers[key(name)] = solver.quantizer
         # with --w_groupsize > 0 fasterquant re-runs find_params per column group: ``scale`` holds the LAST group's as in the
         # reference, every group's is kept in ``group_scales`` (gptq_utils.py here) and the wrapper runs
-        # mq_gemm_w4a8_wgroupscale.  With --act_order on top the groups are runs of PERMUTED columns: ``group_scales`` is None
-        # and the wrapper stays on the simulated path (ActQuantWrapper.extra_repr says which backend runs).
+        # mq_gemm_w4a8_wgroupscale.  With --act_order on top the groups are runs of PERMUTED columns: the solver keeps the
+        # permutation next to the scales (``group_perm``), the wrapper's engine gathers the activation columns the same way
+        # (engine.W4A8Linear.col_perm) and stays on the integer path (ActQuantWrapper.extra_repr says which backend runs).
         _attach(subset[name], solver.quantizer)
         solver.free()
 

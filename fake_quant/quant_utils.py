@@ -159,6 +159,12 @@ class ActQuantizer(torch.nn.Module):
         self.static = False
         self.msq = False
 
+    def __setattr__(self, name, value):
+        # every attribute write bumps a version counter: ActQuantWrapper.forward keeps its "the integer backend runs this
+        # configuration" decision only while the counter stands still (flags are flipped from outside: model_quant & co.)
+        super().__setattr__(name, value)
+        self.__dict__["_ver"] = self.__dict__.get("_ver", 0) + 1
+
     def free(self):
         self.zero = None
         self.scale = None
@@ -290,6 +296,9 @@ class ActQuantizer(torch.nn.Module):
 
 
 # =============================================================================== ActQuantWrapper
+_REAL_DTYPES = (torch.float16, torch.bfloat16, torch.float32)
+
+
 class _NullHandle:
     def remove(self):
         pass
@@ -329,6 +338,13 @@ class ActQuantWrapper(torch.nn.Module):
         self._real = None
         self._real_frozen = False       # engine installed from a flat checkpoint (no float weights)
         self._group = None              # SiblingGroup: q/k/v, gate/up ... sharing one quantize + one GEMM
+        self._fast = None               # cached "integer backend, plain nn.Linear" decision of forward (see _remember_fast)
+
+    def __setattr__(self, name, value):
+        # any attribute write (flags, sub-modules, engine, group) voids the cached forward decision
+        super().__setattr__(name, value)
+        if name != "_fast":
+            self.__dict__["_fast"] = None
 
     # pickled checkpoints must not drag device handles along
     def __getstate__(self):
@@ -336,6 +352,7 @@ class ActQuantWrapper(torch.nn.Module):
         state["_real"] = None
         state["_real_frozen"] = False
         state["_group"] = None
+        state["_fast"] = None
         return state
 
     def extra_repr(self) -> str:
@@ -395,8 +412,6 @@ class ActQuantWrapper(torch.nn.Module):
             return "no weight quantizer attached (run the RTN / GPTQ pass of fake_quant.gptq)"
         if wq.bits not in (4, 8):
             return "weight bits %d" % wq.bits
-        w_asym = not getattr(wq, "sym", False)
-        a_asym = (not qz.static) and not getattr(qz, "sym", False)
         # (per-tensor weight quantizers -- perchannel=False, no driver uses them -- repeat their one scale / zero point per output
         #  channel, quant_utils.py:507-509 upstream: they take the per-channel path unchanged, symmetric or not)
         if getattr(wq, "groupsize", -1) and getattr(wq, "groupsize", -1) > 0:
@@ -457,6 +472,7 @@ class ActQuantWrapper(torch.nn.Module):
 
     # ------------------------------------------------------------------ real-integer backend
     def invalidate_real(self):
+        self.__dict__["_fast"] = None
         if not getattr(self, "_real_frozen", False):
             self._real = None
         grp = self.__dict__.get("_group")
@@ -479,7 +495,7 @@ class ActQuantWrapper(torch.nn.Module):
             return self.real_quant
         if qz.bits >= 16 or self._simulated_because():
             return False
-        if x.dtype not in (torch.float16, torch.bfloat16, torch.float32):
+        if x.dtype not in _REAL_DTYPES:
             return False
         mod = self.module
         if isinstance(mod, torch.nn.Linear):
@@ -605,11 +621,28 @@ class ActQuantWrapper(torch.nn.Module):
                                 split_slice=p["split_slice"], w_groups=p["w_groups"], col_perm=p["col_perm"])
         return self._real
 
-    def _forward_real(self, x):
+    def _forward_real(self, x, fast=None):
         if not x.is_cuda:
             from mquant_amd._lib import MQuantHipError
             raise MQuantHipError("ActQuantWrapper: the quantized W4A8 path runs on the GPU only; "
                                  "there is no CPU fallback (got a CPU tensor)")
+        if fast is not None:
+            # the cached decision: a plain nn.Linear on the integer backend (same launches as the general path below)
+            msq, grp = fast[4], fast[5]
+            two_d = x.dim() == 2
+            rows = x if two_d else x.reshape(-1, x.shape[-1])
+            sel = _row_mask(rows.shape[0], x.device) if msq else None
+            if grp is not None and grp.enabled:
+                y = grp.forward(self, rows, sel)
+                if y is not None:
+                    return y if two_d else y.reshape(*x.shape[:-1], y.shape[-1])
+            real = self.__dict__["_real"]
+            if real is None:
+                real = self._build_real(x.device)
+                self._remember_fast()               # (_build_real wrote self._real: the entry was voided)
+            real.in_features = rows.shape[1]
+            y = real.forward(rows, sel)
+            return y if two_d else y.reshape(*x.shape[:-1], real.N)
         grp = self.__dict__.get("_group")
         if grp is not None and grp.enabled:
             rows = x.reshape(-1, x.shape[-1])
@@ -662,8 +695,25 @@ class ActQuantWrapper(torch.nn.Module):
             qz.free()
         return x
 
+    def _remember_fast(self):
+        """Cache the decision "a quantized forward of this wrapper runs the integer backend" (plain nn.Linear only: the
+        convolution check needs the input's shape).  ``_real_ready`` re-reads ~20 attributes through nn.Module's __getattr__ and
+        rebuilds its reason strings on every call -- ~10 us of host time per Linear in an eager run
+        (profiles/r5_decode_host_overhead.txt).  The entry dies with any attribute write on the wrapper, any attribute write on
+        either activation quantizer (version counters), ``invalidate_real`` (weight passes, model_* toggles) and a dissolved
+        sibling group."""
+        if isinstance(self.module, torch.nn.Linear):
+            qz, oq = self.quantizer, self.out_quantizer
+            self.__dict__["_fast"] = (qz, qz.__dict__.get("_ver", 0), oq, oq.__dict__.get("_ver", 0),
+                                      bool(getattr(qz, "msq", False)), self.__dict__.get("_group"))
+
     def forward(self, x):
+        f = self.__dict__.get("_fast")
+        if (f is not None and f[0].__dict__.get("_ver", 0) == f[1] and f[2].__dict__.get("_ver", 0) == f[3]
+                and x.dtype in _REAL_DTYPES):
+            return self._forward_real(x, f)
         if self._real_ready(x):
+            self._remember_fast()
             return self._forward_real(x)
         qz = self.quantizer
         if qz.static and qz.quant and not x.is_cuda and not getattr(self, "simulate_on_cpu", False):

@@ -508,15 +508,6 @@ int mq_gemm_debug_force(int tile, int splits);
 /* TEST-ONLY: the plan (tile id, split-K factor) the dispatcher takes for a shape; host arithmetic only. */
 int mq_gemm_debug_plan(long M, long N, long K_pad, int w_bits, int a_tiled, int have_workspace, int *tile, int *splits);
 
-/* BENCH-ONLY, not part of the drop-in surface: the dense int8 matrix rate the device sustains under its package power limit.
- * Register-only V_MFMA_I32_32X32X32_I8 (kind 0) / V_MFMA_I32_16X16X64_I8 (kind 1) chains, two waves per SIMD on every CU, no memory or
- * LDS traffic; operands: 8 x 64 x 16 bytes on the device (four A and four B fragment register sets, rotated over the MFMAs --
- * the caller supplies bytes with the statistics of its workload: the clock the part holds depends on them,
- * profiles/r5_clock_reconciliation.txt).  Runs 3 + launches launches of iters x 16 (kind 0) / x 32 (kind 1) MFMAs per wave, times
- * the last `launches` with HIP events on `stream` (blocking) and returns the achieved int8 ops per second.  sink: 4 bytes of
- * device scratch.  bench.py reports the result as roofline.peak_sustained_measured beside the nominal peak. */
-int mq_bench_mfma_burn(int kind, const void *operands, int iters, int launches, int *sink, double *ops_per_s, void *stream);
-
 /* ---------------------------------------------------------------------------
  * Min/max observer reduction.  Replaces the two reductions of
  * MinmaxObserver.update, fake_quant/observer/minmax.py:13-28 (after

@@ -71,13 +71,20 @@ SIGNATURES = {
     "mq_gemm_w4a8_ws": (_i, [_vp, _l, _vp, _i, _l, _l, _l, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _l, _vp, C.c_size_t, _vp]),
     "mq_gemm_w4a8_i32_ws": (_i, [_vp, _l, _vp, _i, _l, _l, _l, _vp, _l, _vp, C.c_size_t, _vp]),
     "mq_gemm_debug_force": (_i, [_i, _i]),
-    "mq_bench_mfma_burn": (_i, [_i, _vp, _i, _i, _vp, _vp, _vp]),
     "mq_gemm_debug_plan": (_i, [_l, _l, _l, _i, _i, _i, _vp, _vp]),
     "mq_minmax_channels": (_i, [_vp, _i, _l, _l, _l, _l, _vp, _vp, _vp]),
     "mq_minmax_tensor": (_i, [_vp, _i, _l, _l, _l, _l, _vp, _vp]),
 }
 
+#: bench-only library (include/mquant_bench.h, csrc/bench_probe.hip): loaded by bench.py alone
+BENCH_LIB_PATH = os.path.join(_HERE, "libmquant_bench.so")
+BENCH_SIGNATURES = {
+    "mq_bench_mfma_burn": (_i, [_i, _vp, _i, _i, _vp, _vp, _vp]),
+    "mq_bench_last_error": (C.c_char_p, []),
+}
+
 _lib = None
+_bench = None
 
 
 class MQuantHipError(RuntimeError):
@@ -108,3 +115,25 @@ def call(name: str, *args) -> None:
     if rc != 0:
         msg = lib.mq_last_error().decode("utf-8", "replace")
         raise MQuantHipError(f"{name} failed (status {rc}): {msg}")
+
+
+def load_bench() -> C.CDLL:
+    """The bench-only probe library (register-only MFMA burn); raises if it has not been built."""
+    global _bench
+    if _bench is None:
+        if not os.path.exists(BENCH_LIB_PATH):
+            raise MQuantHipError(f"{BENCH_LIB_PATH} not found: build it with `make -C mquant_amd/csrc`")
+        lib = C.CDLL(BENCH_LIB_PATH)
+        for name, (res, args) in BENCH_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _bench = lib
+    return _bench
+
+
+def call_bench(name: str, *args) -> None:
+    lib = load_bench()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise MQuantHipError(f"{name} failed (status {rc}): {lib.mq_bench_last_error().decode('utf-8', 'replace')}")

@@ -287,7 +287,7 @@ struct GqArgs {
 template <int DT, bool ASYM = false>
 __global__ __launch_bounds__(256) void act_quant_group_kernel(GqArgs p)
 {
-    kernarg_warm<sizeof(GqArgs)>();
+    kernarg_warm<sizeof(GqArgs), true>();
     typedef typename Elem<DT>::T T;
     const long cpr = p.K_pad / 16;                                  // 16-channel chunks per row (a multiple of lanes_per_group)
     const long total = p.M * cpr;

@@ -1,4 +1,4 @@
-// bench_probe.hip -- BENCH-ONLY: the dense int8 matrix rate the box SUSTAINS under its package power limit.
+// bench_probe.hip -- BENCH-ONLY (libmquant_bench.so, include/mquant_bench.h; not part of libmquant_hip.so): the dense int8 matrix rate the box SUSTAINS under its package power limit.
 //
 // The W4A8 GEMM family runs at the power limit: the same instruction stream is 10-30 % slower on real operand bytes than on
 // zeros (profiles/r5_clock_reconciliation.txt).  The nominal 5 POP/s (2.4 GHz x 256 CUs x 8192 op/clk) therefore is not what
@@ -8,6 +8,7 @@
 // int8 activation levels and int4 weight levels in the high nibble, as the GEMMs see them) and rotated so that consecutive
 // MFMAs see different bits on both ports.  bench.py reports it as roofline.peak_sustained_measured next to the nominal peak.
 #include "mq_common.h"
+#include "../../include/mquant_bench.h"
 
 namespace mq {
 
@@ -60,6 +61,8 @@ __global__ __launch_bounds__(512) void mfma_burn_kernel(int iters, const v4i *da
 }
 
 }  // namespace mq
+
+extern "C" const char *mq_bench_last_error(void) { return mq::last_error_buf(); }
 
 extern "C" int mq_bench_mfma_burn(int kind, const void *operands, int iters, int launches, int *sink, double *ops_per_s, void *stream)
 {

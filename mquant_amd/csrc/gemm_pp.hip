@@ -43,7 +43,7 @@ namespace mq {
 template <int BM, int BN, int KT, int RING, int EPI>
 __global__ __launch_bounds__(512) void gemm_w4a8_pp_kernel(GemmArgs p)
 {
-    kernarg_warm<sizeof(GemmArgs)>();        // one scalar-load round trip instead of six (mq_common.h)
+    kernarg_warm<sizeof(GemmArgs), true>();        // one scalar-load round trip instead of six (mq_common.h)
     constexpr int NWAVES = 8;
     constexpr int TM = BM / 32;                              // 16-row activation fragments per wave (two groups over M)
     constexpr int TN = BN / 64;                              // 16-channel weight fragments per wave (four waves over N)

@@ -29,7 +29,7 @@ constexpr int SK_MAX_BLOCKS = 65535;                       // channel blocks of 
 template <int EPI, int TMX>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p)
 {
-    kernarg_warm<sizeof(GemmArgs)>();
+    kernarg_warm<sizeof(GemmArgs), true>();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned pb = blockIdx.x, ks = blockIdx.y;       // channel block (4 pairs = 128 channels), K slice
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p)
 template <int EPI, int TMX>
 __global__ __launch_bounds__(512) void gemm_skinny_wg_kernel(GemmArgs p)
 {
-    kernarg_warm<sizeof(GemmArgs)>();
+    kernarg_warm<sizeof(GemmArgs), true>();
     __shared__ v4i red[8][TMX * 2][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -49,7 +49,7 @@ int launch_gemm_skinny_wg(const GemmArgs &p, hipStream_t st);          // gemm_s
 template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int W_BITS, int EPI, int DMA_POS, bool GROUPED = false>
 __global__ __launch_bounds__(WARPS_M *WARPS_N * 64) void gemm_w4a8_kernel(GemmArgs p)
 {
-    kernarg_warm<sizeof(GemmArgs)>();
+    kernarg_warm<sizeof(GemmArgs), true>();
     constexpr int NWAVES = WARPS_M * WARPS_N;
     constexpr int TM = BM / WARPS_M / 16;          // activation fragments per wave
     constexpr int TN = BN / WARPS_N / 16;          // weight fragments per wave
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p)
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_w4a8_pipe_kernel(GemmArgs p)
 {
-    kernarg_warm<sizeof(GemmArgs)>();
+    kernarg_warm<sizeof(GemmArgs), true>();
     constexpr int BM = 256, BN = 256, WARPS_N = 4, NWAVES = 8, TM = 8, TN = 4;
     constexpr int RING = 6, X_PIECES = BM / 16, W_PIECES = BN / 32, PIECES = X_PIECES + W_PIECES;
     constexpr int LPW = PIECES / NWAVES;                    // 3 DMA instructions per wave per k-tile

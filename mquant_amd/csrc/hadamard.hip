@@ -302,7 +302,7 @@ __device__ __forceinline__ void had_kxk_unit(const HadArgs &p, long row, const R
 template <int DT, bool QUANT, bool HALF_LDS, int THREADS, bool ACT = false, int UNIT = 0>
 __global__ __launch_bounds__(THREADS, HALF_LDS ? 4 : 1) void hadamard_kernel(HadArgs p)
 {
-    kernarg_warm<sizeof(HadArgs)>();         // one scalar-load round trip instead of three to six (mq_common.h)
+    kernarg_warm<sizeof(HadArgs), true>();         // one scalar-load round trip instead of three to six (mq_common.h)
     constexpr int HAD_THREADS = THREADS;
     constexpr int HAD_WAVES = THREADS / 64;
     typedef typename Elem<DT>::T T;

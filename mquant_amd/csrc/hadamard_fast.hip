@@ -52,7 +52,7 @@ template <> struct HalfMma<MQ_BF16> {
 template <int DT, bool QUANT, bool ACT, int KS, int JT>
 __global__ __launch_bounds__(256, 3) void hadamard_fast_kernel(HadArgs p)
 {
-    kernarg_warm<sizeof(HadArgs)>();
+    kernarg_warm<sizeof(HadArgs), true>();
     typedef typename Elem<DT>::T T;
     typedef HalfMma<DT> MM;
     constexpr int WAVES = 4;

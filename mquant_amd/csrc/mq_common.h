@@ -98,24 +98,30 @@ __device__ __forceinline__ unsigned pack2_bf16(float a, float b)
 // the first use, with an s_waitcnt in front of every dependent step -- three to six SERIALIZED scalar-load round trips at the top of
 // the quantizer, Hadamard and GEMM kernels (the argument block of a launch is never in the scalar cache: ~1 us between a workgroup's
 // entry and its first useful instruction, profiles/r5_ws_fixed_cost_timeline.txt).  One dword per 64-byte line of the kernarg segment,
-// all requested at once and waited for once: the compiler's own loads behind it hit the cache.  BYTES = sizeof(argument struct);
-// the implicit arguments behind it (grid size ...) share its last lines.
-template <int BYTES>
+// all requested at once and waited for once: the compiler's own loads behind it hit the cache.  BYTES = sizeof(argument struct).
+template <int ARG_BYTES, bool READS_GRID = false>
 __device__ __forceinline__ void kernarg_warm()
 {
 #ifndef MQ_LAZY_ARGS
-    constexpr int LINES = (BYTES + 24 + 63) / 64 > 8 ? 8 : (BYTES + 24 + 63) / 64;
+    // One dword per 64-byte line of the argument block; no load leaves it (the last line's dword is the block's last one, whatever
+    // follows in the segment), outputs early-clobber so that none is placed on the base pair.  READS_GRID: the kernel reads
+    // gridDim, so the three implicit block counts (12 bytes at the next 8-byte boundary) exist behind the struct and are warmed too.
+    static_assert(ARG_BYTES >= 4 && ARG_BYTES % 4 == 0, "argument block: whole dwords");
+    constexpr int BYTES = READS_GRID ? (ARG_BYTES + 7) / 8 * 8 + 12 : ARG_BYTES;
+    constexpr int LINES = (BYTES + 63) / 64 > 8 ? 8 : (BYTES + 63) / 64;
+#define MQ_KA_OFF(i) ((i) * 64 + 4 <= BYTES ? (i) * 64 : BYTES - 4)
     const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
     unsigned d0, d1, d2, d3, d4, d5, d6, d7;
     (void)d0; (void)d1; (void)d2; (void)d3; (void)d4; (void)d5; (void)d6; (void)d7;
-    if constexpr (LINES == 1) asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(d0) : "s"(ka));
-    if constexpr (LINES == 2) asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=s"(d0), "=s"(d1) : "s"(ka));
-    if constexpr (LINES == 3) asm volatile("s_load_dword %0, %3, 0x0\n\ts_load_dword %1, %3, 0x40\n\ts_load_dword %2, %3, 0x80\n\ts_waitcnt lgkmcnt(0)" : "=s"(d0), "=s"(d1), "=s"(d2) : "s"(ka));
-    if constexpr (LINES == 4) asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\ts_waitcnt lgkmcnt(0)" : "=s"(d0), "=s"(d1), "=s"(d2), "=s"(d3) : "s"(ka));
-    if constexpr (LINES == 5) asm volatile("s_load_dword %0, %5, 0x0\n\ts_load_dword %1, %5, 0x40\n\ts_load_dword %2, %5, 0x80\n\ts_load_dword %3, %5, 0xc0\n\ts_load_dword %4, %5, 0x100\n\ts_waitcnt lgkmcnt(0)" : "=s"(d0), "=s"(d1), "=s"(d2), "=s"(d3), "=s"(d4) : "s"(ka));
-    if constexpr (LINES == 6) asm volatile("s_load_dword %0, %6, 0x0\n\ts_load_dword %1, %6, 0x40\n\ts_load_dword %2, %6, 0x80\n\ts_load_dword %3, %6, 0xc0\n\ts_load_dword %4, %6, 0x100\n\ts_load_dword %5, %6, 0x140\n\ts_waitcnt lgkmcnt(0)" : "=s"(d0), "=s"(d1), "=s"(d2), "=s"(d3), "=s"(d4), "=s"(d5) : "s"(ka));
-    if constexpr (LINES == 7) asm volatile("s_load_dword %0, %7, 0x0\n\ts_load_dword %1, %7, 0x40\n\ts_load_dword %2, %7, 0x80\n\ts_load_dword %3, %7, 0xc0\n\ts_load_dword %4, %7, 0x100\n\ts_load_dword %5, %7, 0x140\n\ts_load_dword %6, %7, 0x180\n\ts_waitcnt lgkmcnt(0)" : "=s"(d0), "=s"(d1), "=s"(d2), "=s"(d3), "=s"(d4), "=s"(d5), "=s"(d6) : "s"(ka));
-    if constexpr (LINES == 8) asm volatile("s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x40\n\ts_load_dword %2, %8, 0x80\n\ts_load_dword %3, %8, 0xc0\n\ts_load_dword %4, %8, 0x100\n\ts_load_dword %5, %8, 0x140\n\ts_load_dword %6, %8, 0x180\n\ts_load_dword %7, %8, 0x1c0\n\ts_waitcnt lgkmcnt(0)" : "=s"(d0), "=s"(d1), "=s"(d2), "=s"(d3), "=s"(d4), "=s"(d5), "=s"(d6), "=s"(d7) : "s"(ka));
+    if constexpr (LINES == 1) asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(d0) : "s"(ka), "n"(MQ_KA_OFF(0)));
+    if constexpr (LINES == 2) asm volatile("s_load_dword %0, %2, %3\n\ts_load_dword %1, %2, %4\n\ts_waitcnt lgkmcnt(0)" : "=&s"(d0), "=&s"(d1) : "s"(ka), "n"(MQ_KA_OFF(0)), "n"(MQ_KA_OFF(1)));
+    if constexpr (LINES == 3) asm volatile("s_load_dword %0, %3, %4\n\ts_load_dword %1, %3, %5\n\ts_load_dword %2, %3, %6\n\ts_waitcnt lgkmcnt(0)" : "=&s"(d0), "=&s"(d1), "=&s"(d2) : "s"(ka), "n"(MQ_KA_OFF(0)), "n"(MQ_KA_OFF(1)), "n"(MQ_KA_OFF(2)));
+    if constexpr (LINES == 4) asm volatile("s_load_dword %0, %4, %5\n\ts_load_dword %1, %4, %6\n\ts_load_dword %2, %4, %7\n\ts_load_dword %3, %4, %8\n\ts_waitcnt lgkmcnt(0)" : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3) : "s"(ka), "n"(MQ_KA_OFF(0)), "n"(MQ_KA_OFF(1)), "n"(MQ_KA_OFF(2)), "n"(MQ_KA_OFF(3)));
+    if constexpr (LINES == 5) asm volatile("s_load_dword %0, %5, %6\n\ts_load_dword %1, %5, %7\n\ts_load_dword %2, %5, %8\n\ts_load_dword %3, %5, %9\n\ts_load_dword %4, %5, %10\n\ts_waitcnt lgkmcnt(0)" : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4) : "s"(ka), "n"(MQ_KA_OFF(0)), "n"(MQ_KA_OFF(1)), "n"(MQ_KA_OFF(2)), "n"(MQ_KA_OFF(3)), "n"(MQ_KA_OFF(4)));
+    if constexpr (LINES == 6) asm volatile("s_load_dword %0, %6, %7\n\ts_load_dword %1, %6, %8\n\ts_load_dword %2, %6, %9\n\ts_load_dword %3, %6, %10\n\ts_load_dword %4, %6, %11\n\ts_load_dword %5, %6, %12\n\ts_waitcnt lgkmcnt(0)" : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5) : "s"(ka), "n"(MQ_KA_OFF(0)), "n"(MQ_KA_OFF(1)), "n"(MQ_KA_OFF(2)), "n"(MQ_KA_OFF(3)), "n"(MQ_KA_OFF(4)), "n"(MQ_KA_OFF(5)));
+    if constexpr (LINES == 7) asm volatile("s_load_dword %0, %7, %8\n\ts_load_dword %1, %7, %9\n\ts_load_dword %2, %7, %10\n\ts_load_dword %3, %7, %11\n\ts_load_dword %4, %7, %12\n\ts_load_dword %5, %7, %13\n\ts_load_dword %6, %7, %14\n\ts_waitcnt lgkmcnt(0)" : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6) : "s"(ka), "n"(MQ_KA_OFF(0)), "n"(MQ_KA_OFF(1)), "n"(MQ_KA_OFF(2)), "n"(MQ_KA_OFF(3)), "n"(MQ_KA_OFF(4)), "n"(MQ_KA_OFF(5)), "n"(MQ_KA_OFF(6)));
+    if constexpr (LINES == 8) asm volatile("s_load_dword %0, %8, %9\n\ts_load_dword %1, %8, %10\n\ts_load_dword %2, %8, %11\n\ts_load_dword %3, %8, %12\n\ts_load_dword %4, %8, %13\n\ts_load_dword %5, %8, %14\n\ts_load_dword %6, %8, %15\n\ts_load_dword %7, %8, %16\n\ts_waitcnt lgkmcnt(0)" : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6), "=&s"(d7) : "s"(ka), "n"(MQ_KA_OFF(0)), "n"(MQ_KA_OFF(1)), "n"(MQ_KA_OFF(2)), "n"(MQ_KA_OFF(3)), "n"(MQ_KA_OFF(4)), "n"(MQ_KA_OFF(5)), "n"(MQ_KA_OFF(6)), "n"(MQ_KA_OFF(7)));
+#undef MQ_KA_OFF
 #endif
 }
 

@@ -58,7 +58,7 @@ struct R1Args {
 template <int DT>
 __global__ __launch_bounds__(256) void rank1_add_cast_kernel(R1Args p)
 {
-    kernarg_warm<sizeof(R1Args)>();
+    kernarg_warm<sizeof(R1Args), true>();
     typedef typename Elem<DT>::T T;
     const long quads = (p.N + 3) / 4;
     const long total = p.M * quads;

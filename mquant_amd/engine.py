@@ -35,6 +35,8 @@ class HadamardSpec:
 #: contiguous KiB per MFMA fragment, what the wave-specialised GEMM kernels stream) or "rows"
 #: (row-major, the round-1 layout; kept for A/B measurements).
 ACT_LAYOUT = os.environ.get("MQ_ACT_LAYOUT", "tiled")
+#: MQ_DEBUG_WORKSPACE=1: every activation image carries a hand-out counter and gemm() refuses a stale handle (Workspace CONTRACT)
+DEBUG_WORKSPACE = os.environ.get("MQ_DEBUG_WORKSPACE", "0") == "1"
 
 
 class Workspace:
@@ -46,13 +48,20 @@ class Workspace:
 
     Everything is stream-ordered: a buffer is written by a quantizer and read by the GEMM behind it on the same stream.
     hipGraph users are pinned: a buffer handed out during stream capture is never released when the workspace grows
-    (the graph replays into it), it just stops being handed out."""
+    (the graph replays into it), it just stops being handed out.
+
+    CONTRACT: at most ONE outstanding activation image per (device, K_pad, layout).  Two layers of the same input width (or two
+    row counts) share the buffer, so a quantizer's output must be consumed by its GEMM before the next quantizer of that width
+    is enqueued -- which is what every call site does (quantize -> gemm back to back on one stream).  A handle kept across
+    another quantize() of the same width is stale; ``TiledAct.generation`` lets ``gemm`` catch that under MQ_DEBUG_WORKSPACE=1."""
 
     def __init__(self):
         self._a: Dict[Tuple[int, int, str], torch.Tensor] = {}
         self._x0: Dict[int, torch.Tensor] = {}
         self._captured = set()          # ids of buffers handed out while a stream was capturing
         self._pinned = []               # outgrown buffers a graph may still replay into
+        self._gen: Dict[Tuple[int, int, str], int] = {}     # hand-outs per key (debug: stale-handle check)
+        self._views: Dict[Tuple[int, int, int], tuple] = {}  # (device, K_pad, M) -> (TiledAct over the live buffer, id(buffer))
 
     @staticmethod
     def _capturing() -> bool:
@@ -70,11 +79,38 @@ class Workspace:
         return buf
 
     def act(self, device, M: int, K_pad: int):
+        idx = device.index or 0
+        if ACT_LAYOUT == "tiled" and not DEBUG_WORKSPACE:
+            # the view of (buffer, M) is built once: slicing + view + TiledAct cost ~3 us of host time per call otherwise
+            hit = self._views.get((idx, K_pad, M))
+            if hit is not None:
+                if hit[1] not in self._captured and self._capturing():
+                    self._captured.add(hit[1])
+                return hit[0]
         rows = ops.ceil_to(max(M, 1), 16) if ACT_LAYOUT == "tiled" else M
-        buf = self._grow(self._a, (device.index or 0, K_pad, ACT_LAYOUT), rows * K_pad, torch.int8, device)
+        key = (idx, K_pad, ACT_LAYOUT)
+        before = self._a.get(key)
+        buf = self._grow(self._a, key, rows * K_pad, torch.int8, device)
+        if buf is not before:
+            self._views = {k: v for k, v in self._views.items() if k[:2] != (idx, K_pad)}
         if ACT_LAYOUT == "tiled":
-            return ops.TiledAct(buf[: rows * K_pad].view(rows // 16, K_pad // 64, 64, 16), M, K_pad)
+            t = ops.TiledAct(buf[: rows * K_pad].view(rows // 16, K_pad // 64, 64, 16), M, K_pad)
+            if DEBUG_WORKSPACE:
+                self._gen[key] = self._gen.get(key, 0) + 1
+                t.generation = (key, self._gen[key])
+            else:
+                if len(self._views) > 4096:
+                    self._views.clear()
+                self._views[(idx, K_pad, M)] = (t, id(buf))
+            return t
         return buf[: M * K_pad].view(M, K_pad)
+
+    def check_fresh(self, a) -> None:
+        """MQ_DEBUG_WORKSPACE=1: the image a GEMM is about to read is the LATEST hand-out of its buffer (see CONTRACT)."""
+        gen = getattr(a, "generation", None)
+        if gen is not None and self._gen.get(gen[0]) != gen[1]:
+            raise ops._lib.MQuantHipError(f"stale activation image: buffer {gen[0]} was handed out again (hand-out {self._gen.get(gen[0])}) "
+                                     f"after this handle ({gen[1]}) -- one outstanding image per (device, K_pad)")
 
     def x0(self, device, M: int) -> torch.Tensor:
         return self._grow(self._x0, device.index or 0, M, torch.float32, device)[:M]
@@ -90,6 +126,7 @@ class Workspace:
         self._x0.clear()
         self._captured.clear()
         self._pinned.clear()
+        self._views.clear()
 
 
 WORKSPACE = Workspace()
@@ -204,14 +241,24 @@ class W4A8Linear:
             x2 = ops.hadamard(x2, self.had.n, self.had.K, self.had.bits, self.had.fp32_had, fast=self.had.fast)
         return x2.index_select(1, self.col_perm)
 
+    def _no_col_perm(self, what: str) -> None:
+        """Producer-side entry points hand out / fill the activation image in the ORIGINAL column order; an --act_order layer's
+        weight image is in the solver's order (col_perm), so only quantize() / forward_dynamic(), which gather, may feed it."""
+        assert self.col_perm is None, (f"{what}: this layer's weight image is in --act_order column order (col_perm); "
+                                       "use quantize() + gemm(), which gather the activation columns")
+
     def act_buffer(self, M: int):
-        """The workspace destination a quantizer of this layer's input writes (for producers that quantize themselves)."""
+        """The workspace destination a quantizer of this layer's input writes (for producers that quantize themselves).
+        Contract (Workspace): at most ONE outstanding activation image per (device, K_pad) -- the buffer is shared by every
+        layer of that width and every row count, so the producer's launch and this layer's GEMM must be back to back on the stream."""
+        self._no_col_perm("act_buffer")
         return WORKSPACE.act(self.w_img.device, M, self.K_pad)
 
     def quantize_rmsn(self, x: torch.Tensor, mean_dim: float, eps: float,
                       row_sel: Optional[torch.Tensor] = None):
         """Weight-less RMS norm + quantize in one launch (layers without an online Hadamard)."""
         assert self.had is None and not self.split
+        self._no_col_perm("quantize_rmsn")
         a = WORKSPACE.act(x.device, x.shape[0], self.K_pad)
         ops.rmsn_quantize_i8(x, mean_dim, eps, self.s_x0, self.s_x1, row_sel=row_sel, out=a)
         return a, None
@@ -221,6 +268,7 @@ class W4A8Linear:
         """Activation (silu(x)*x2 / quick_gelu(x)) + Hadamard + quantize in one launch: the input of a
         rotated Linear straight from the producer's output (needs an online Hadamard on this layer)."""
         assert self.had is not None, "the fused activation prologue lives in the Hadamard kernel"
+        self._no_col_perm("quantize_act")
         M = x.shape[0]
         a = WORKSPACE.act(x.device, M, self.K_pad)
         x0 = WORKSPACE.x0(x.device, M) if self.split else None
@@ -232,6 +280,8 @@ class W4A8Linear:
     def gemm(self, a: torch.Tensor, x0: Optional[torch.Tensor], out_dtype: torch.dtype,
              row_sel: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
         w0 = self.w0
+        if DEBUG_WORKSPACE:
+            WORKSPACE.check_fresh(a)
         if self.w_groups is not None:
             return ops.gemm_w4a8_wgroupscale(a, self.w_img, self.w_bits, self.N, self.w_groups[0], self.w_groups[1],
                                              s_x0=self.s_x0, s_x1=self.s_x1, row_sel=row_sel, bias=self.bias,
@@ -252,6 +302,7 @@ class W4A8Linear:
         """The Linear with the rotary embedding of its first ``rope_cols`` output columns (heads of 128: the q | k part of a
         fused q|k|v projection) folded into the GEMM's store; plain static layers only."""
         assert not self.split and self.w_shift is None and self.w_groups is None and self.dynamic is None
+        self._no_col_perm("gemm_rope")
         return ops.gemm_w4a8_rope(a, self.w_img, self.w_bits, self.N, self.s_x0, self.s_w, cos, sin, rope_cols,
                                   s_x1=self.s_x1, row_sel=row_sel, bias=self.bias, out_dtype=out_dtype, out=out)
 
@@ -259,6 +310,9 @@ class W4A8Linear:
                       row_sel: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
         """residual + Linear in one launch (same rounding as torch's `hidden + linear(x)`)."""
         assert self.w_groups is None, "the residual epilogue is not in the weight-group kernel"
+        self._no_col_perm("gemm_residual")
+        if DEBUG_WORKSPACE:
+            WORKSPACE.check_fresh(a)
         w0 = self.w0
         if self.w_shift is not None:
             assert not self.split, "the residual epilogue carries one rank-1 term"
@@ -330,14 +384,81 @@ class W4A8Linear:
         return ops.gemm_w4a8_rowscale(a, self.w_img, self.w_bits, self.N, s_rows, self.s_w, bias=self.bias,
                                       x0=xt, w0=wt, out_dtype=x2.dtype, out=out)
 
+    # -- eager fast path ---------------------------------------------------------------------
+    # The reference's scripts run eager, one ActQuantWrapper.forward per Linear and token step: at M = 768 a Linear has ~38 us of
+    # GPU work and the generic ops (decorator, argument checks, layout helpers, keyword marshalling) cost ~25 us of host time per
+    # forward (profiles/r5_decode_host_overhead.txt).  A plain static layer (per-channel symmetric weights, static scale set(s),
+    # optional online Hadamard / split column) binds its two entry points and their constant arguments ONCE; per call only the
+    # input pointer, the row count, the output and the stream are marshalled.  Same two launches, same arguments.
+    def _bind_fast(self):
+        from . import _lib
+        lib = _lib.load()
+        plain = (self.dynamic is None and self.col_perm is None and self.w_groups is None and self.w_shift is None
+                 and ACT_LAYOUT == "tiled" and not DEBUG_WORKSPACE)
+        self._fast = None
+        if plain:
+            dev = self.w_img.device
+            s0 = float(self.s_x0)
+            s1 = float(self.s_x0 if self.s_x1 is None else self.s_x1)
+            had = self.had
+            self._fast = dict(
+                dev=dev, idx=dev.index or 0, s0=s0, s1=s1, scales=(self.s_x0, self.s_x1),
+                quant=lib.mq_hadamard_quant_i8 if had is not None else lib.mq_quantize_act_i8,
+                gemm=lib.mq_gemm_w4a8_ws, err=lib.mq_last_error,
+                had=None if had is None else (had.n, had.K, ops._ptr(had.bits), had.fp32_had, had.fast),
+                had_obj=had, w=self.w_img.data_ptr(), s_w=self.s_w.data_ptr(), bias=ops._ptr(self.bias), w0=ops._ptr(self.w0),
+                skip=int(self.split))
+        return self._fast
+
+    def _forward_fast(self, f, x2: torch.Tensor, row_sel, out):
+        M, K = x2.shape
+        dev = f["dev"]
+        a = WORKSPACE.act(dev, M, self.K_pad)
+        x0 = WORKSPACE.x0(dev, M) if self.split else None
+        stream = torch._C._cuda_getCurrentRawStream(f["idx"])
+        sel = None if row_sel is None else row_sel.data_ptr()
+        x0p = None if x0 is None else x0.data_ptr()
+        dt = ops._DT[x2.dtype]
+        h = f["had"]
+        if h is None:
+            rc = f["quant"](x2.data_ptr(), dt, M, K, x2.stride(0), f["s0"], f["s1"], None, None, sel, f["skip"], x0p,
+                            a.data.data_ptr(), self.K_pad, 0, stream)
+        else:
+            flags = (ops.HAD_FP32 if h[3] else 0) | (ops.HAD_PREPARED if f["had_obj"].bits is not None and f["had_obj"].bits.dtype == torch.int64 else 0) \
+                | (ops.HAD_FAST if f["had_obj"].fast else 0)
+            rc = f["quant"](x2.data_ptr(), dt, M, K, x2.stride(0), h[0], h[1], h[2], flags, f["s0"], f["s1"], sel, f["skip"], x0p,
+                            a.data.data_ptr(), self.K_pad, 0, stream)
+        if rc:
+            raise ops._lib.MQuantHipError(f"quantize failed (status {rc}): {f['err']().decode('utf-8', 'replace')}")
+        if out is None:
+            out = torch.empty((M, self.N), dtype=x2.dtype, device=dev)
+        ws = ops.splitk_workspace(dev)
+        rc = f["gemm"](a.data.data_ptr(), 0, f["w"], self.w_bits, M, self.N, self.K_pad, f["s0"], f["s1"], sel, f["s_w"],
+                       f["bias"], x0p, f["w0"], out.data_ptr(), ops._DT[out.dtype], out.stride(0), ws.data_ptr(), ws.numel(), stream)
+        if rc:
+            raise ops._lib.MQuantHipError(f"mq_gemm_w4a8_ws failed (status {rc}): {f['err']().decode('utf-8', 'replace')}")
+        return out
+
     def forward(self, x: torch.Tensor, row_sel: Optional[torch.Tensor] = None,
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        x2 = x.reshape(-1, x.shape[-1])
+        two_d = x.dim() == 2
+        x2 = x if two_d else x.reshape(-1, x.shape[-1])
         if self.dynamic is not None:
-            return self.forward_dynamic(x2, out).reshape(*x.shape[:-1], self.N)
-        a, x0 = self.quantize(x2, row_sel)
-        y = self.gemm(a, x0, x.dtype, row_sel, out)
-        return y.reshape(*x.shape[:-1], self.N)
+            y = self.forward_dynamic(x2, out)
+            return y if two_d else y.reshape(*x.shape[:-1], self.N)
+        f = self.__dict__.get("_fast", False)
+        if f is False:
+            f = self._bind_fast()
+        if (f is not None and f["scales"] == (self.s_x0, self.s_x1) and x2.is_cuda and x2.stride(1) == 1 and x2.dtype in ops._DT
+                and x2.device == f["dev"] and f["idx"] == torch.cuda.current_device()
+                and (row_sel is None or row_sel.is_cuda) and (out is None or out.is_cuda)):
+            y = self._forward_fast(f, x2, row_sel, out)
+        else:
+            if f is not None and f["scales"] != (self.s_x0, self.s_x1):
+                self.__dict__.pop("_fast", None)        # the scale set was swapped (calibration): bind again next time
+            a, x0 = self.quantize(x2, row_sel)
+            y = self.gemm(a, x0, x.dtype, row_sel, out)
+        return y if two_d else y.reshape(*x.shape[:-1], self.N)
 
     __call__ = forward
 

@@ -30,12 +30,15 @@ class TiledAct:
     """int8 activations in the TILED layout (``MQ_LD_TILED``): ``data`` is [ceil(M/16), K_pad/64, 64, 16],
     one 1 KiB piece = the MFMA operand fragment of a 16-row x 64-k tile in lane order.  The GEMM
     fetches a piece with one contiguous LDS-DMA (3x the L2 rate of gathering rows)."""
-    __slots__ = ("data", "M", "K_pad")
+    __slots__ = ("data", "M", "K_pad", "generation")
 
     def __init__(self, data: torch.Tensor, M: int, K_pad: int):
         assert data.dtype == torch.int8 and data.is_contiguous() and K_pad % 64 == 0
         assert data.numel() >= ceil_to(M, 16) * K_pad
         self.data, self.M, self.K_pad = data, M, K_pad
+        #: (workspace key, hand-out counter) when the image lives in engine.Workspace: a handle whose counter is no longer the
+        #: key's latest has been overwritten by a later quantizer of the same width (checked under MQ_DEBUG_WORKSPACE=1)
+        self.generation = None
 
     @staticmethod
     def empty(M: int, K_pad: int, device) -> "TiledAct":

@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "mquant_hip.h")).read()
+def declared_symbols(header="mquant_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(mq_[a-z0-9_]+)\s*\(", text)))
 
@@ -39,6 +39,19 @@ def test_python_binding_covers_the_header():
     from mquant_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_symbols()
     _lib.load()
+
+
+def test_bench_probe_is_its_own_library():
+    """The MFMA burn probe is bench-only code: declared in include/mquant_bench.h, built into libmquant_bench.so, absent
+    from the product library and from its binding table."""
+    from mquant_amd import _lib
+    assert sorted(_lib.BENCH_SIGNATURES) == declared_symbols("mquant_bench.h")
+    assert not set(_lib.BENCH_SIGNATURES) & set(_lib.SIGNATURES)
+    if not os.path.exists(_lib.BENCH_LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    _lib.load_bench()
+    assert not hasattr(ctypes.CDLL(_lib.LIB_PATH), "mq_bench_mfma_burn")
 
 
 def test_missing_library_is_a_loud_error(monkeypatch, tmp_path):
