@@ -163,16 +163,17 @@ def cpu_baseline(prefill_ops_total: float):
                       f"extrapolated by GEMM ops to the full 327-Linear prefill"}
 
 
-def full_prefill_report(pf, dev, args):
+def full_prefill_report(pf, dev, args, geometry=None, kv_fp8=False, attn_fp8=False, variants=True):
     """TTFT of the WHOLE synthetic prefill -- the W4A8 Linears chained through
     torch glue (RMS norm, RoPE, SDPA, activations, fp16 lm_head on the last position) -- one
-    hipGraph replay per sample, HIP events around each replay.  Secondary to ``value``."""
+    hipGraph replay per sample, HIP events around each replay.  Secondary to ``value``.
+    ``variants`` = False: the fused form only (the secondary lines' budget)."""
     import torch
     from mquant_amd import workload
     from mquant_amd.full_prefill import FullPrefill
     try:
         def measure(fused, rope_fused=True):
-            fp = FullPrefill(pf, fused_glue=fused)
+            fp = FullPrefill(pf, fused_glue=fused, geometry=geometry, kv_fp8=kv_fp8, attn_fp8=attn_fp8)
             fp.rope_fused = fused and rope_fused          # the decoder's RoPE in the q|k|v GEMM's store (round 5) or its own launch
             fp.calibrate()
             if args.no_graph:
@@ -199,6 +200,12 @@ def full_prefill_report(pf, dev, args):
             med = times[len(times) // 2]
             p90 = times[min(len(times) - 1, int(round(0.9 * (len(times) - 1))))]
             return med, p90, len(times), bool(torch.isfinite(fp.logits.float()).all().item())
+        if not variants:
+            med, p90, iters, finite = measure(True)
+            return {"what": "whole synthetic prefill, fused glue" + (", fp8 (e4m3) KV cache written by the q|k|v GEMM's consumers and READ by the "
+                            "prefill attention (mq_attn_prefill_fp8kv)" if kv_fp8 and attn_fp8 else ""),
+                    "ttft_ms_median": round(med, 4), "ttft_ms_p90": round(p90, 4), "iters": iters, "kv_fp8": bool(kv_fp8),
+                    "attn_fp8": bool(attn_fp8), "llm_tokens_per_s": round(workload.M_LLM / (med * 1e-3), 1), "logits_finite": finite}
         med_u, p90_u, _, _ = measure(False)
         med, p90, iters, finite = measure(True)
         med_rope = measure(True, rope_fused=False)[0]     # same process, same box: what the separate RoPE launch costs
@@ -230,6 +237,62 @@ def full_prefill_report(pf, dev, args):
     except Exception as exc:      # a report, never a reason to lose the bench line
         return {"error": repr(exc)}
 
+
+
+#: the other BASELINE.json configurations and the reference's FIRST canonical command (docs/qwen2vl.md:19: W8A8 vision tower +
+#: W4A8 LLM), run as bounded CHILD processes behind the headline so that the driver's one bench line carries them
+#: (VERDICT r5 "next" 3).  name -> (extra command line, what it is)
+SECONDARY = {
+    "qwenvl_7b": (["--workload", "qwenvl_7b"], "BASELINE config 2: Qwen-VL-7B W4A8 full prefill Linears, online Hadamard 172x64 + 2^13"),
+    "internvl2_8b_batch4": (["--workload", "internvl2_8b", "--batch", "4"],
+                            "BASELINE config 4, the per-GPU share of batch 32 over 8 GPUs: InternVL2-8B W4A8, 4 samples per step"),
+    "qwen2vl_72b_kv_fp8": (["--workload", "qwen2vl_72b", "--ttft-kv-fp8"],
+                           "BASELINE config 5 on ONE GPU: Qwen2-VL-72B W4A8 MSQ (35.8 GB of W4) + whole-prefill TTFT with the fp8 KV cache"),
+    "qwen2vl_7b_visual_w8": (["--workload", "qwen2vl_7b", "--visual-w-bits", "8"],
+                             "the reference's first canonical command (docs/qwen2vl.md:19): W8A8 vision tower + W4A8 LLM, Qwen2-VL-7B"),
+}
+
+
+def run_secondary(budget_s: float, t_start: float, steps: int = 10, warmup: int = 3):
+    """Each entry of SECONDARY as a fresh child process (its own GPU context; a crash, a hang or an out-of-memory kill costs
+    that entry only), bounded by what is left of ``budget_s`` since ``t_start``.  Returns name -> compact summary."""
+    out = {}
+    for name, (extra, what) in SECONDARY.items():
+        left = budget_s - (time.perf_counter() - t_start)
+        if left < 30.0:
+            out[name] = {"what": what, "skipped": f"time budget spent ({budget_s:.0f} s for the whole bench)"}
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline",
+               "--no-secondary"] + (["--no-full-prefill"] if "--ttft-kv-fp8" not in extra else []) + extra
+        t0 = time.perf_counter()
+        try:
+            env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+            proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
+            try:
+                so, se = proc.communicate(timeout=left - 10.0)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, 9)                      # the exact process group this call started
+                proc.communicate()
+                out[name] = {"what": what, "error": f"timed out after {time.perf_counter() - t0:.0f} s"}
+                continue
+            js = [ln for ln in so.splitlines() if ln.startswith("{")]
+            if proc.returncode != 0 or not js:
+                out[name] = {"what": what, "error": f"rc {proc.returncode}: {se.strip().splitlines()[-1] if se.strip() else 'no output'}"}
+                continue
+            d = json.loads(js[-1])
+            r = d.get("roofline", {})
+            ent = {"what": what, "value": d.get("value"), "unit": d.get("unit"), "ms_per_step": d.get("ms_per_step"),
+                   "frac": r.get("frac"), "step_frac": r.get("step_frac"), "gemm_ms_per_step": r.get("gemm_ms_per_step"),
+                   "quant_hadamard_ms_per_step": r.get("quant_hadamard_ms_per_step"),
+                   "gemm_TOP_per_step": d.get("config", {}).get("gemm_TOP_per_step"), "weights_GB": d.get("config", {}).get("weights_GB"),
+                   "steps": d.get("steps"), "path": d.get("config", {}).get("path"), "wall_s": round(time.perf_counter() - t0, 1),
+                   "command": "python bench.py " + " ".join(cmd[2:])}
+            if "full_prefill_kv_fp8" in d:
+                ent["full_prefill_kv_fp8"] = d["full_prefill_kv_fp8"]
+            out[name] = ent
+        except Exception as exc:      # a report, never a reason to lose the bench line
+            out[name] = {"what": what, "error": repr(exc)}
+    return out
 
 
 def sustained_int8_peak(pf, dev):
@@ -285,12 +348,24 @@ def main():
     ap.add_argument("--w-groupsize", type=int, default=-1,
                     help="NON-DEFAULT, labelled secondary line: group-wise weight scales of this many input channels (what a --w_groupsize GPTQ run "
                          "leaves behind; synthetic weights get them from a group-wise RTN), GEMMs on mq_gemm_w4a8_wgroupscale")
+    ap.add_argument("--visual-w-bits", type=int, default=None, choices=[4, 8],
+                    help="weight bits of everything in front of the language model (the reference's --visual_w_bits; default = 4 like the "
+                         "LLM: the benchmark configuration is W4A8 + W4A8).  8 = the reference's first canonical command, docs/qwen2vl.md:19: "
+                         "a labelled secondary line")
+    ap.add_argument("--ttft-kv-fp8", action="store_true",
+                    help="secondary lines: also report the whole-prefill TTFT with the fp8 (e4m3) KV cache read by the prefill attention "
+                         "(Qwen2-VL geometries only)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the bounded secondary block (the other BASELINE configurations + the W8A8-vision line as child processes)")
+    ap.add_argument("--secondary-budget", type=float, default=420.0,
+                    help="wall-clock seconds the WHOLE default bench may take; secondary entries that would not fit are skipped")
     ap.add_argument("--ttft-iters", type=int, default=100)
     ap.add_argument("--batch", type=int, default=1,
                     help="image+prompt samples per GPU and step (the benchmark configuration is 1; >1 is a scaling study)")
     ap.add_argument("--cpu-selftest", action="store_true",
                     help="launcher / sharding self-test without a GPU: the ranks gather fake logits over gloo")
     args = ap.parse_args()
+    t_process = time.perf_counter()
 
     # ---- rank launcher: before torch.cuda / HIP is touched, and never by re-exec ---------------------
     # a rank of torch.distributed.run (any world size, 1 included) carries the whole rendezvous environment; a scheduler that only
@@ -342,19 +417,20 @@ def main():
 
     from mquant_amd import ops, workload
 
-    headline = args.workload == "qwen2vl_7b" and not args.tiny and args.w_groupsize <= 0
+    headline = args.workload == "qwen2vl_7b" and not args.tiny and args.w_groupsize <= 0 and args.visual_w_bits in (None, 4)
     build_specs, workload_desc = workload.WORKLOADS[args.workload]
     specs = workload.tiny_specs() if args.tiny else build_specs(args.batch)
     via_wrappers = not args.direct_engines and not args.tiny      # every workload is built through the drop-in API (round 4: the secondary lines too)
     pf, via_error = None, None
     if via_wrappers:
         try:
-            pf = workload.WrapperPrefill(specs, device=dev, dtype=torch.float16, fuse_siblings=not args.no_fuse, w_groupsize=args.w_groupsize)
+            pf = workload.WrapperPrefill(specs, device=dev, dtype=torch.float16, fuse_siblings=not args.no_fuse, w_groupsize=args.w_groupsize,
+                                         vis_w_bits=args.visual_w_bits)
         except Exception as exc:          # never lose the bench line: fall back to the directly assembled engines, and say so
             via_error, via_wrappers = repr(exc), False
             torch.cuda.empty_cache()
     if pf is None:
-        pf = workload.Prefill(specs, device=dev, dtype=torch.float16, share_groups=not args.no_fuse)
+        pf = workload.Prefill(specs, device=dev, dtype=torch.float16, share_groups=not args.no_fuse, vis_w_bits=args.visual_w_bits)
     if args.had_fast:
         pf.set_had_fast(True)            # NON-DEFAULT, labelled secondary line: per-layer flag MQ_HAD_FAST (include/mquant_hip.h)
     tokens_per_step = workload.M_LLM * args.batch if not args.tiny else specs[-1].M
@@ -601,6 +677,9 @@ def main():
     if args.w_groupsize > 0:
         desc = (f"NON-DEFAULT group-wise weight scales (--w_groupsize {args.w_groupsize}; every Linear whose input width is a multiple of it -- "
                 "all but the vision tower's split fc2): ") + desc
+    if args.visual_w_bits == 8:
+        desc = ("W8A8 vision tower + merger (--visual_w_bits 8) with the W4A8 LLM -- the reference's first canonical command, "
+                "docs/qwen2vl.md:19; NOT the benchmark configuration (W4A8 + W4A8): ") + desc
     if args.had_fast:
         desc = "NON-DEFAULT fast Hadamard mode (fp16 matrix-core K x K stage, not bit-identical to the reference): " + desc
     line = {"metric": "W4A8 prefill tokens/sec (hot path: Hadamard + static quant + W4A8 Linear), "
@@ -630,6 +709,10 @@ def main():
             "roofline": roofline}
     if headline and not (args.no_full_prefill or args.no_fuse or args.batch != 1):
         line["full_prefill"] = full_prefill_report(pf, dev, args)
+    if args.ttft_kv_fp8 and not args.tiny and args.workload in ("qwen2vl_7b", "qwen2vl_72b") and not args.no_fuse and args.batch == 1:
+        from mquant_amd import full_prefill as fpm
+        line["full_prefill_kv_fp8"] = full_prefill_report(pf, dev, args, geometry=fpm.QWEN2VL_72B if args.workload == "qwen2vl_72b" else fpm.QWEN2VL_7B,
+                                                          kv_fp8=True, attn_fp8=True, variants=False)
     if stray_world:
         line["config"]["launcher_note"] = ("WORLD_SIZE was set without RANK / LOCAL_RANK / MASTER_PORT (not a torch.distributed.run "
                                            "rank): ran as a single process")
@@ -645,6 +728,14 @@ def main():
             line["cpu_baseline_port"] = cpu_baseline(float(pf.gemm_ops()))
         except Exception as exc:
             line["cpu_baseline_port"] = {"value": None, "kind": "port", "sample": f"failed: {exc!r}"}
+    if rank == 0 and world == 1 and headline and not args.no_secondary and not args.no_fuse and args.batch == 1 and not args.had_fast:
+        # the headline is complete; the other configurations follow as bounded child processes (this process keeps its line)
+        try:
+            pf = None
+            torch.cuda.empty_cache()
+            line["secondary"] = run_secondary(args.secondary_budget, t_process)
+        except Exception as exc:
+            line["secondary"] = {"error": repr(exc)}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if distributed:

@@ -713,8 +713,9 @@ class ActQuantWrapper(torch.nn.Module):
                 and x.dtype in _REAL_DTYPES):
             return self._forward_real(x, f)
         if self._real_ready(x):
-            self._remember_fast()
-            return self._forward_real(x)
+            y = self._forward_real(x)
+            self._remember_fast()                   # (after the call: building the engine writes self._real, which voids the entry)
+            return y
         qz = self.quantizer
         if qz.static and qz.quant and not x.is_cuda and not getattr(self, "simulate_on_cpu", False):
             # There is no CPU fallback.  ``simulate_on_cpu`` is an explicit opt-in used by bench.py's

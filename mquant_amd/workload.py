@@ -158,6 +158,13 @@ def tiny_specs() -> List[LinearSpec]:
     ]
 
 
+def tower_of(spec_name: str) -> str:
+    """"llm" for the language model's Linears, "visual" for everything in front of it (vision tower, patch embedding, merger /
+    resampler / mlp1): the split the reference's --visual_w_bits / --llm_w_bits make (gptq/qwen2vl_gptq_plus.py:14-100, 268-300
+    use args.visual_w_bits for visual.patch_embed, visual.blocks and visual.merger; :394, :490 args.llm_w_bits)."""
+    return "llm" if spec_name.split(".")[0] == "llm" else "visual"
+
+
 def load_had_bits(K: int, device) -> Optional[torch.Tensor]:
     if K <= 1:
         return None
@@ -304,12 +311,13 @@ class Prefill(_HotPath):
     """All wrapped Linears of one image+prompt prefill, in execution order."""
 
     def __init__(self, specs: List[LinearSpec], device="cuda:0", dtype=torch.float16,
-                 w_bits: int = 4, seed: int = 1234, share_groups: bool = True):
+                 w_bits: int = 4, seed: int = 1234, share_groups: bool = True, vis_w_bits: Optional[int] = None):
         self.device = torch.device(device)
         self.dtype = dtype
         self.specs = specs
         self.share_groups = share_groups
         self.layers: List[Layer] = []
+        llm_w_bits, vis_w_bits = w_bits, (w_bits if vis_w_bits is None else vis_w_bits)
         inputs = synth_inputs(specs, self.device, dtype)
         outs: Dict[tuple, torch.Tensor] = {}
         sels: Dict[int, torch.Tensor] = {}
@@ -333,6 +341,7 @@ class Prefill(_HotPath):
             if skey not in scales:
                 scales[skey] = self._calibrate(x, spec, had, row_sel)
             s0, s1 = scales[skey]
+            w_bits = llm_w_bits if tower_of(spec.name) == "llm" else vis_w_bits      # --llm_w_bits / --visual_w_bits
             for c in range(spec.count):
                 w, bias = synth_weight(spec, li, seed, self.device, dtype)
                 li += 1
@@ -349,7 +358,7 @@ class Prefill(_HotPath):
                     # Linears fed by the same tensor (q/k/v, gate/up) carry identical static scales
                     # (their observers saw the same activations): quantize once, ONE GEMM over the
                     # concatenated output channels.
-                    pending.setdefault((spec.group, c), []).append((spec, q, s_w, bias, s0, s1, x, row_sel))
+                    pending.setdefault((spec.group, c), []).append((spec, q, s_w, bias, s0, s1, x, row_sel, w_bits))
                     continue
                 lin = W4A8Linear(q, s_w, w_bits, bias, s0, s1 if spec.msq else None, had=had, w0=w0,
                                  in_features=spec.k_in)
@@ -371,7 +380,7 @@ class Prefill(_HotPath):
             okey = (fused.M, n_total)
             if okey not in outs:
                 outs[okey] = torch.empty((fused.M, n_total), dtype=dtype, device=self.device)
-            lin = W4A8Linear(q, s_w, w_bits, bias, members[0][4],
+            lin = W4A8Linear(q, s_w, members[0][8], bias, members[0][4],
                              members[0][5] if spec0.msq else None, in_features=spec0.k_in)
             L = Layer(fused, c, lin, members[0][6], members[0][7], outs[okey])
             L.order_name = spec0.name
@@ -405,7 +414,8 @@ class WrapperPrefill(_HotPath):
     ``model_quant`` groups q/k/v and gate/up into one quantize + one GEMM (``quant_utils.SiblingGroup``)."""
 
     def __init__(self, specs: List[LinearSpec], device="cuda:0", dtype=torch.float16, w_bits: int = 4,
-                 seed: int = 1234, fuse_siblings: bool = True, calib_passes: int = 2, w_groupsize: int = -1):
+                 seed: int = 1234, fuse_siblings: bool = True, calib_passes: int = 2, w_groupsize: int = -1,
+                 vis_w_bits: Optional[int] = None):
         import functools
         import types
         from fake_quant import hadamard_utils as hu, quant_utils as qu, utils as fq_utils
@@ -462,7 +472,11 @@ class WrapperPrefill(_HotPath):
             self.calls.append((wrap, inputs[(spec.M, spec.k_in)], spec))
         self.quantizers: Dict[str, object] = {}
         # w_groupsize > 0: group-wise weight scales as a --w_groupsize GPTQ run leaves them (fake_quant.gptq.rtn, mq_gemm_w4a8_wgroupscale)
-        rtn_module(root, "model", w_bits, True, False, [], self.quantizers, groupsize=w_groupsize)
+        # per tower like the reference's RTN / GPTQ drivers: --visual_w_bits for everything in front of the language model,
+        # --llm_w_bits for its layers (docs/qwen2vl.md:19 is W8A8 vision + W4A8 LLM, :26 W4A8 + W4A8)
+        for tower in sorted({sp.name.partition(".")[0] for sp in specs}):
+            bits = w_bits if tower_of(tower) == "llm" else (w_bits if vis_w_bits is None else vis_w_bits)
+            rtn_module(getattr(root, tower), "model." + tower, bits, True, False, [], self.quantizers, groupsize=w_groupsize)
         self.args = types.SimpleNamespace(skip_names=[], no_sibling_fusion=not fuse_siblings)
         m_llm = max([sp.M for sp in specs if sp.msq] + [0])
         self.mask = vision_text_mask(m_llm, self.device) if m_llm else None

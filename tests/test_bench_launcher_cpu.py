@@ -50,3 +50,14 @@ def test_launcher_runs_before_any_gpu_import():
     src = open(BENCH).read()
     main = src[src.index("def main():"):]
     assert main.index("subprocess.call(cmd") < main.index("import torch")
+
+
+def test_secondary_block_respects_its_time_budget():
+    """The bounded secondary block of the default bench line (the other BASELINE configurations as child processes): with no
+    time left every entry is reported as skipped and nothing is started."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    out = bench.run_secondary(0.0, time.perf_counter())
+    assert set(out) == set(bench.SECONDARY) and all("skipped" in v for v in out.values())
+    assert {"qwenvl_7b", "internvl2_8b_batch4", "qwen2vl_72b_kv_fp8", "qwen2vl_7b_visual_w8"} <= set(out)
