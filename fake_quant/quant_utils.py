@@ -707,6 +707,11 @@ class ActQuantWrapper(torch.nn.Module):
             self.__dict__["_fast"] = (qz, qz.__dict__.get("_ver", 0), oq, oq.__dict__.get("_ver", 0),
                                       bool(getattr(qz, "msq", False)), self.__dict__.get("_group"))
 
+    def fast_path_active(self) -> bool:
+        """True while the cached forward decision is still valid (nothing written to the wrapper or its quantizers since)."""
+        f = self.__dict__.get("_fast")
+        return f is not None and f[0].__dict__.get("_ver", 0) == f[1] and f[2].__dict__.get("_ver", 0) == f[3]
+
     def forward(self, x):
         f = self.__dict__.get("_fast")
         if (f is not None and f[0].__dict__.get("_ver", 0) == f[1] and f[2].__dict__.get("_ver", 0) == f[3]

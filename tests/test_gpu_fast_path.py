@@ -39,7 +39,7 @@ def _wrapped(K=512, N=256, had=False, msq=False, bias=True, seed=0):
 def test_fast_forward_equals_general_forward(had):
     qu, root, wrap, args, x = _wrapped(had=had)
     y1 = wrap(x)                      # builds the engine, remembers the decision
-    assert wrap.__dict__["_fast"] is not None and "integer" in wrap.backend()
+    assert wrap.fast_path_active() and "integer" in wrap.backend()
     y2 = wrap(x)                      # cached decision + bound entry points
     eng = wrap._real
     a, x0 = eng.quantize(x)           # the general ops
@@ -56,13 +56,14 @@ def test_fast_forward_equals_general_forward(had):
 def test_state_changes_void_the_cached_decision():
     qu, root, wrap, args, x = _wrapped()
     y_int = wrap(x)
-    assert wrap.__dict__["_fast"] is not None
+    assert wrap.fast_path_active()
     qu.model_no_quant(root, args)                     # the reference's toggle: forward returns the unquantized Linear
+    assert not wrap.fast_path_active()
     y_float = wrap(x)
-    assert wrap.__dict__["_fast"] is None
+    assert not wrap.fast_path_active()
     assert torch.equal(y_float, torch.nn.functional.linear(x, wrap.module.weight, wrap.module.bias))
     qu.model_quant(root, args)
-    assert torch.equal(wrap(x), y_int) and wrap.__dict__["_fast"] is not None
+    assert torch.equal(wrap(x), y_int) and wrap.fast_path_active()
     wrap.quantizer.quant = False                      # a direct flag write on the quantizer (version counter)
     assert torch.equal(wrap(x), y_float)
     wrap.quantizer.quant = True
@@ -75,7 +76,7 @@ def test_state_changes_void_the_cached_decision():
     wrap.out_quantizer.configure(bits=8, sym=True)    # an output quantizer: simulated path
     assert "simulated" in wrap.backend()
     wrap(x)
-    assert wrap.__dict__["_fast"] is None
+    assert not wrap.fast_path_active()
 
 
 def test_engine_rebinds_when_the_scale_set_is_swapped():
