@@ -469,6 +469,22 @@ int mq_gemm_w4a8_rope_ws(const int8_t *a, long lda, const void *w, int w_bits, l
                          const uint8_t *row_sel, const float *s_w, const float *bias, const void *rope_cos, const void *rope_sin,
                          long rope_cols, int head_dim, void *out, int out_dtype, long ldo, void *stream);
 
+/* Activation of the CONSUMER folded into the GEMM's store (round 6).  The reference wraps every Linear on its own
+ * (fake_quant/quant_utils.py:330-391); between two wrapped Linears the HF module applies its activation --
+ * Qwen2MLP: down_proj(act_fn(gate_proj(x)) * up_proj(x)), the vision MLP: fc2(quick_gelu(fc1(x))) -- and the down_proj / fc2 wrapper
+ * then reads that tensor (through the online Hadamard, fake_quant/hadamard_utils.py:115-128).  Here the producer GEMM stores the
+ * ACTIVATED tensor: the Linear's output y is formed and rounded to out_dtype exactly as mq_gemm_w4a8_ws stores it, then
+ *   act = MQ_ACT_SILU_MUL (1):   w is the image of a fused gate|up projection, gate = channels 0 .. N/2-1, up = N/2 .. N-1 (N / 2 a
+ *                                multiple of 32); out[m][c] = cast(cast(silu(y[m][c])) * y[m][N/2 + c]) -- [M, N/2], ldo >= N/2
+ *   act = MQ_ACT_QUICK_GELU (2): out[m][n] = cast(x * cast(sigmoid(cast(1.702 x)))), x = y[m][n] -- [M, N]
+ * every torch op rounding once to out_dtype, as F.silu(gate) * up / QuickGELUActivation evaluate on tensors of that dtype (the same
+ * device expf): bit-identical to mq_gemm_w4a8_ws followed by those torch ops.  Static scale set(s) (s_x0, s_x1, row_sel) or per-row
+ * scales (s_x_rows); bias optional; no rank-1 terms.  Needs tiled activations (lda = MQ_LD_TILED: MQ_EUNSUPPORTED otherwise),
+ * output columns and ldo multiples of 8, out 16-byte aligned. */
+int mq_gemm_w4a8_act_ws(const int8_t *a, long lda, const void *w, int w_bits, long M, long N, long K_pad, float s_x0, float s_x1,
+                        const uint8_t *row_sel, const float *s_x_rows, const float *s_w, const float *bias, int act,
+                        void *out, int out_dtype, long ldo, void *stream);
+
 /* out[m][n] = cast(y32[m][n] + x[m] * w[n]): a THIRD rank-1 term behind mq_gemm_w4a8_rank2_ws, for a layer that combines the split
  * column (--visual_split, quant_utils.py:367-376), asymmetric weights (--w_asym) and asymmetric dynamic activations (--a_asym): run
  * the two-slot GEMM with out_dtype = MQ_F32, then this pass -- the sum continues in fp32 and is rounded to the output dtype once,

@@ -46,6 +46,7 @@ SIGNATURES = {
     "mq_gemm_w4a8_groupscale_asym": (_i, [_vp, _l, _vp, _i, _l, _l, _l, _vp, _vp, _vp, _l, _i, _vp, _vp, _vp, _i, _l, _vp]),
     "mq_rank1_add_cast": (_i, [_vp, _l, _l, _l, _vp, _vp, _vp, _i, _l, _vp]),
     "mq_gemm_w4a8_rope_ws": (_i, [_vp, _l, _vp, _i, _l, _l, _l, _f, _f, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp, _i, _l, _vp]),
+    "mq_gemm_w4a8_act_ws": (_i, [_vp, _l, _vp, _i, _l, _l, _l, _f, _f, _vp, _vp, _vp, _vp, _i, _vp, _i, _l, _vp]),
     "mq_gemm_w4a8_wgroupscale": (_i, [_vp, _l, _vp, _i, _l, _l, _l, _vp, _l, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _l, _vp]),
     "mq_act_rowsum_scaled": (_i, [_vp, _l, _l, _l, _f, _f, _vp, _vp, _vp, _vp]),
     "mq_gemm_w4a8_residual_ws": (_i, [_vp, _l, _vp, _i, _l, _l, _l, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _l, _vp, C.c_size_t, _vp]),

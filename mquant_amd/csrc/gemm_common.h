@@ -62,6 +62,16 @@ struct GemmArgs {
     long n_groups = 0;
     int group_k = 0;
     int acc_float = 0;
+    // Activation of the CONSUMER folded into the store (round 6; the HF modules around quant_utils.py:330-391: Qwen2MLP's
+    // down_proj(act_fn(gate_proj(x)) * up_proj(x)), the vision MLP's fc2(quick_gelu(fc1(x)))), evaluated like the torch ops on
+    // tensors of the OUTPUT dtype -- every op rounds once (mq_common.h act_silu_mul / act_quick_gelu):
+    //   MQ_ACT_SILU_MUL:   the weight image holds gate (channels 0 .. N/2-1) and up (N/2 .. N-1) of a fused gate|up projection;
+    //                      out[m][c] = silu(y[m][c]) * y[m][N/2 + c], c < N/2 -- ONE tensor of M x N/2 instead of M x N.  The loaders
+    //                      pair the two halves inside a workgroup tile (a BN-wide tile = BN/2 gate + the same BN/2 up channels)
+    //   MQ_ACT_QUICK_GELU: out[m][n] = quick_gelu(y[m][n])
+    // Host-checked (gemm_common): tiled activations, floating-point output, no split-K / residual / rank-1 terms, N (N/2) a
+    // multiple of 8 (32), aligned operands -- the kernels' act paths rely on it.
+    int act = MQ_ACT_NONE;
     const void *residual = nullptr;  // [M, ldr] in the output dtype: out = cast(cast(y) + residual)
     long ldr = 0;
     const float *s_w, *bias, *x0, *w0;
@@ -250,7 +260,7 @@ __device__ __forceinline__ void store_quad(const GemmArgs &p, long m, long n, v4
 // kept SMALL: each wave parks its raw int32 accumulators in a private LDS slab with a handful of
 // unrolled ds_write_b128, then a ROLLED loop re-reads them row-contiguously, dequantises and
 // stores 16 B (fp16) / 32 B per lane: whole 128-byte row segments, edges in the same loop.
-template <int TM, int TN, int NWAVES, int RING_BYTES, int W_BITS, int EPI>
+template <int TM, int TN, int NWAVES, int RING_BYTES, int W_BITS, int EPI, bool ACT = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][TM], char *smem,
                                               int wave, int lane, int wm, int wn, long m0, long nt0,
                                               int split)
@@ -308,6 +318,112 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][
     // per-row parameters (activation scale set, split term) are fetched once per pass, one row
     // per lane, and parked behind the slab so the store loop never waits on global memory
     float *rowpar = reinterpret_cast<float *>(slab + PASS_ROWS * SLAB_LD);   // [PASS_ROWS][4]: s_x, x0, x1, unused
+
+    // Activation in the store (GemmArgs::act; host-checked preconditions, see there).  Same slab, same dequantisation arithmetic as
+    // the fast path below -- the Linear's output y is formed and rounded to the output dtype exactly as the plain launch stores
+    // it -- then the activation as the torch ops evaluate it on that tensor.  SILU_MUL: the wave's sub-tile holds [32 gate | 32 up]
+    // channel pairs (gemm_pp.hip's loader), a lane owns 8 OUTPUT channels: two 8-channel slab reads 128 bytes apart.
+    // Its own instantiation (ACT; gemm_pp.hip launches it when GemmArgs::act is set): inside the plain kernels this path's loop
+    // invariants, hoisted in front of the persistent kernels' k-loop, overflowed the register file of the 256 x 256 tile.
+    if constexpr (ACT) {
+        if constexpr (NWAVES <= 8 && EPI != EPI_I32) {
+            constexpr int DT = (EPI == EPI_F16) ? MQ_F16 : (EPI == EPI_BF16 ? MQ_BF16 : MQ_F32);
+            const bool silu = p.act == MQ_ACT_SILU_MUL;
+            const bool has_bias = p.bias != nullptr;
+            if (silu && (WN_COLS % 64 != 0)) return;                     // (host: only tiles whose waves hold whole pairs)
+            const long H = p.N >> 1;
+            constexpr int LPR_S = WN_COLS / 16 > 0 ? WN_COLS / 16 : 1;    // lanes per slab row: SILU_MUL (half as many outputs) / GELU
+            const int rpi = silu ? 64 / LPR_S : ROWS_PER_IT;              // rows per iteration
+            const int arow = silu ? lane / LPR_S : lane / LANES_PER_ROW;
+            const int ob = (silu ? lane % LPR_S : lane % LANES_PER_ROW) * 8;   // first of the lane's 8 outputs inside the wave's sub-tile
+            const int gc = silu ? (ob >> 5) * 64 + (ob & 31) : ob;        // slab column of the (gate) operand; up: + 32
+            const long no = silu ? nt0 * 8 + wn * (WN_COLS / 2) + ob : nt0 * 16 + wn * WN_COLS + ob;   // output column
+            const bool n_ok = silu ? (no + 8 <= H) : (no + 8 <= p.N);
+            // per-channel parameters of the lane's 8 outputs (and of the 8 up channels behind them): 16-byte loads -- the operands are
+            // 16-byte aligned and the columns multiples of 8 (host-checked); scalar loads with their 64-bit addresses, hoisted above the
+            // parking of the accumulators, overflowed the register file of the 256 x 256 tile
+            const long cb = n_ok ? no : 0;
+            const float *bias_or_sw = has_bias ? p.bias : p.s_w;
+            const v4f sg0 = *reinterpret_cast<const v4f *>(p.s_w + cb), sg1 = *reinterpret_cast<const v4f *>(p.s_w + cb + 4);
+            const v4f su0 = *reinterpret_cast<const v4f *>(p.s_w + (silu ? H : 0) + cb), su1 = *reinterpret_cast<const v4f *>(p.s_w + (silu ? H : 0) + cb + 4);
+            const v4f bg0 = *reinterpret_cast<const v4f *>(bias_or_sw + cb), bg1 = *reinterpret_cast<const v4f *>(bias_or_sw + cb + 4);
+            const v4f bu0 = *reinterpret_cast<const v4f *>(bias_or_sw + (silu ? H : 0) + cb), bu1 = *reinterpret_cast<const v4f *>(bias_or_sw + (silu ? H : 0) + cb + 4);
+            float sg[8], su[8], bg[8], bu[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sg[e] = sg0[e]; sg[4 + e] = sg1[e];
+                su[e] = su0[e]; su[4 + e] = su1[e];
+                bg[e] = bg0[e]; bg[4 + e] = bg1[e];
+                bu[e] = bu0[e]; bu[4 + e] = bu1[e];
+            }
+#pragma unroll
+            for (int pass = 0; pass < TM / PASS_MT; ++pass) {              // (unrolled: the accumulators are registers, no dynamic index)
+#pragma unroll
+                for (int jj = 0; jj < PASS_MT; ++jj)
+#pragma unroll
+                    for (int i = 0; i < TN; ++i)
+                        *reinterpret_cast<v4i *>(slab + (jj * 16 + ml) * SLAB_LD + (i * 16 + nq) * 4) = acc[i][pass * PASS_MT + jj];
+                if (lane < PASS_ROWS) {
+                    const long mr = m0 + (wm * TM + pass * PASS_MT) * 16 + lane;
+                    float sxl = p.sx0;
+                    if (mr < p.M) {
+                        if (p.sx_vec) sxl = p.sx_vec[mr];
+                        else if (p.row_sel && p.row_sel[mr]) sxl = p.sx1;
+                    }
+                    rowpar[lane * 4] = sxl;
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll 1
+                for (int r0 = 0; r0 < PASS_ROWS; r0 += rpi) {
+                    const int row = r0 + arow;
+                    const long m = m0 + (wm * TM + pass * PASS_MT) * 16 + row;
+                    const v4i g0 = *reinterpret_cast<const v4i *>(slab + row * SLAB_LD + gc * 4);
+                    const v4i g1 = *reinterpret_cast<const v4i *>(slab + row * SLAB_LD + gc * 4 + 16);
+                    v4i u0 = g0, u1 = g1;
+                    if (silu) {
+                        u0 = *reinterpret_cast<const v4i *>(slab + row * SLAB_LD + gc * 4 + 128);
+                        u1 = *reinterpret_cast<const v4i *>(slab + row * SLAB_LD + gc * 4 + 144);
+                    }
+                    const float sxe = (W_BITS == 4) ? rowpar[row * 4] * 0.0625f : rowpar[row * 4];
+                    const int ag[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+                    const int au[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
+                    float h[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float g = (float)ag[e] * sxe;
+                        g = g * sg[e];
+                        if (has_bias) g = g + bg[e];
+                        g = Elem<DT>::rnd(g);                            // the Linear's output, in the model's dtype
+                        if (silu) {
+                            float u = (float)au[e] * sxe;
+                            u = u * su[e];
+                            if (has_bias) u = u + bu[e];
+                            u = Elem<DT>::rnd(u);
+                            h[e] = act_silu_mul<DT>(g, u);
+                        } else {
+                            h[e] = act_quick_gelu<DT>(g);
+                        }
+                        // one element's exp / division chain at a time: interleaved, the eight chains plus the accumulators of the
+                        // passes still to come do not fit the register file of a 512-thread workgroup
+                        if (e & 1) __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (m >= p.M || !n_ok) continue;
+                    if (EPI == EPI_F32) {
+                        float *o = reinterpret_cast<float *>(p.out) + m * p.ldo + no;
+                        store_out(reinterpret_cast<v4f *>(o), v4f{h[0], h[1], h[2], h[3]});
+                        store_out(reinterpret_cast<v4f *>(o + 4), v4f{h[4], h[5], h[6], h[7]});
+                    } else {
+                        v4i hw;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            hw[e] = (int)((unsigned)Elem<DT>::st(h[2 * e]) | ((unsigned)Elem<DT>::st(h[2 * e + 1]) << 16));
+                        store_out(reinterpret_cast<v4i *>(reinterpret_cast<unsigned short *>(p.out) + m * p.ldo + no), hw);
+                    }
+                }
+            }
+        }
+        return;
+    }
 
     // Fast path (what every Linear of the prefill takes: whole 8-channel groups, fp16 / bf16 / fp32 output, no residual,
     // no split-K, integer accumulators).  Straight-line code per half pass: the slab reads and row parameters of four row

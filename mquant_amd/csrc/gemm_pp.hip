@@ -40,7 +40,7 @@ namespace mq {
 #define MQ_PP_ABL 0   // timing-only ablations (wrong results): 1 no DMA in the loop, 2 no fragment reads, 4 no unpack, 8 no MFMA
 #endif
 
-template <int BM, int BN, int KT, int RING, int EPI>
+template <int BM, int BN, int KT, int RING, int EPI, bool ACT = false>
 __global__ __launch_bounds__(512) void gemm_w4a8_pp_kernel(GemmArgs p)
 {
     kernarg_warm<sizeof(GemmArgs), true>();        // one scalar-load round trip instead of six (mq_common.h)
@@ -88,6 +88,16 @@ __global__ __launch_bounds__(512) void gemm_w4a8_pp_kernel(GemmArgs p)
         } else {
             long ntp = nt0 / 2 + (r - XP);
             if (ntp >= p.n_pairs) ntp = p.n_pairs - 1;
+            if (ACT && p.act == MQ_ACT_SILU_MUL) {
+                // silu(gate) * up in the store (GemmArgs::act): LDS pair slot 2 i = gate pair i, slot 2 i + 1 = up pair i of this
+                // n-block's BN / 2 output channels -- wave wn (slots 2 wn, 2 wn + 1 for BN = 256) then holds 32 gate channels and
+                // the SAME 32 up channels, and its private epilogue slab has both operands of an output
+                const int g = r - XP;
+                const long hp = p.n_pairs >> 1;                  // pairs per half (N / 2 is a multiple of 32: host-checked)
+                long pi = (long)bn * (WP / 2) + (g >> 1);
+                if (pi >= hp) pi = hp - 1;
+                ntp = (g & 1) ? hp + pi : pi;
+            }
             src[i] = reinterpret_cast<const char *>(p.w) + (ntp * kts + (long)sb * KT + kt) * 1024;
         }
     }
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(512) void gemm_w4a8_pp_kernel(GemmArgs p)
 #endif
     // (Requesting one dword per 128-byte line of the NEXT tile's first RING - 1 weight steps here, in front of the epilogue, so that
     //  its prologue's LDS-DMAs hit the L2, was measured in round 5: 0.4 % SLOWER over the bench, profiles/r5_bench_ab_pp_next_tile_prefetch.txt)
-    gemm_epilogue<TM, TN, NWAVES, RING * SLOT, 4, EPI>(p, acc, smem, wave, lane, grp, wn, m0, nt0, split);
+    gemm_epilogue<TM, TN, NWAVES, RING * SLOT, 4, EPI, ACT>(p, acc, smem, wave, lane, grp, wn, m0, nt0, split);
 #ifdef MQ_PP_STAMP
     if (tid == 0 && p.partial && p.splits == 1) p.partial[(long)wid * 8 + 4] = (int)__builtin_amdgcn_s_memrealtime();
 #endif
@@ -242,12 +252,12 @@ __global__ __launch_bounds__(512) void gemm_w4a8_pp_kernel(GemmArgs p)
 #undef MQ_PP_VM
 }
 
-template <int BM, int BN, int KT, int RING, int EPI>
+template <int BM, int BN, int KT, int RING, int EPI, bool ACT = false>
 static int launch_pp(const GemmArgs &p, hipStream_t st)
 {
     constexpr int SMEM = RING * KT * (BM / 16 + BN / 32) * 1024;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
-    auto kern = gemm_w4a8_pp_kernel<BM, BN, KT, RING, EPI>;
+    auto kern = gemm_w4a8_pp_kernel<BM, BN, KT, RING, EPI, ACT>;
     const int rc = ensure_dynamic_lds((const void *)kern, SMEM);
     if (rc != MQ_OK) return rc;
     GemmArgs g = p;
@@ -266,6 +276,15 @@ static int launch_pp(const GemmArgs &p, hipStream_t st)
 template <int EPI>
 int launch_gemm_pp(const GemmArgs &p, int tile, hipStream_t st)
 {
+    if (p.act != MQ_ACT_NONE) {
+        // activation in the store (GemmArgs::act): the 256-wide tiles only -- a wave then holds four 16-channel fragments, i.e. a
+        // gate pair AND its up pair (the plan sends every other shape to the wave-specialised kernels)
+        if constexpr (EPI != EPI_I32) {
+            if (tile == 14) return launch_pp<256, 256, 1, 6, EPI, true>(p, st);
+            if (tile == 19) return launch_pp<128, 256, 1, 8, EPI, true>(p, st);
+        }
+        return fail(MQ_EINVAL, "gemm_pp: tile %d has no activation epilogue", tile);
+    }
     switch (tile) {
     case 14: return launch_pp<256, 256, 1, 6, EPI>(p, st);
     case 15: return launch_pp<128, 128, 2, 6, EPI>(p, st);

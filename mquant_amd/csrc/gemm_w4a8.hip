@@ -524,9 +524,12 @@ struct Plan {
     int splits;
 };
 
+// epi_only: 0 = any kernel; 1 = an epilogue that exists in the wave-specialised kernels only (RoPE in the store); 2 = an activation in
+// the store (GemmArgs::act): the wave-specialised tiles or the wide ping-pong tile, no split-K, no weight-streaming kernels
 static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes, int force_tile,
-                      int force_splits, bool w4 = true, bool a_tiled = false, bool ws_only = false)
+                      int force_splits, bool w4 = true, bool a_tiled = false, int epi_only = 0)
 {
+    const bool ws_only = epi_only == 1, act_mode = epi_only == 2;
     const long kps = K_pad / 128;
     const long t256 = ceil_div(M, 256) * ceil_div(N, 256);
     Plan pl = {10, 1};
@@ -563,7 +566,7 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
     }
     if (ws_only) {
         // (an epilogue that exists in the wave-specialised kernels only -- RoPE in the store: the best of the tiles above, no split-K)
-    } else if (a_tiled && w4 && ceil_div(N, 128) <= 65535 &&
+    } else if (!act_mode && a_tiled && w4 && ceil_div(N, 128) <= 65535 &&
                (M <= 16 || (M <= 32 && K_pad >= 512 && K_pad <= 4096 && N >= 2048) || (M <= 64 && kps >= 64 && ceil_div(N, 128) < 128))) {
         // A few rows (generation steps of the exam scripts): the weight stream is the work -- gemm_skinny.hip, id 60; `splits` = its
         // K slices, added up by splitk_reduce_kernel.  One row tile: every decoder shape gains (48 against 80 us per layer at M = 1);
@@ -578,6 +581,8 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
             pl.tile = 61;
             pl.splits = skinny_wg_slices(M, N, K_pad, ws_bytes);
         }
+    } else if (act_mode && !(w4 && a_tiled)) {
+        // (int8 weights with an activation in the store: the wave-specialised tile chosen above; the 16-wave kernel has no act path)
     } else if (t256 >= 192) {
         // gate|up: with tiled activations the 8-wave ping-pong kernel (gemm_pp.hip, round 4: 93-101 us against 108-116
         // for the software-pipelined tile 13 and 110-112 for the 16-wave tile 3, profiles/r4_pp_ab.txt); with row-major
@@ -615,11 +620,12 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
         while (s > 1 && ((size_t)(s * M * N * 4) > ws_bytes || kps / s < 8)) --s;
         if (s > 1) { pl.tile = 3; pl.splits = (int)s; }
     }
-    if (force_tile >= 0 && (!ws_only || (force_tile >= 40 && force_tile < 60))) {
+    if (force_tile >= 0 && (!ws_only || (force_tile >= 40 && force_tile < 60))
+        && (!act_mode || (force_tile >= 40 && force_tile < 60) || force_tile == 14 || force_tile == 19)) {
         if ((pl.tile == 60 || pl.tile == 61) && force_tile != pl.tile) pl.splits = 1;   // (the slices were the skinny kernel's)
         pl.tile = force_tile;
     }
-    if (force_splits > 0 && !ws_only) pl.splits = force_splits;
+    if (force_splits > 0 && !ws_only && !act_mode) pl.splits = force_splits;
     if (pl.splits > kps) pl.splits = (int)kps;
     if (pl.splits < 1) pl.splits = 1;
     return pl;
@@ -702,7 +708,7 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
                        long ldr = 0, const float *sx_groups = nullptr, long n_groups = 0, int group_k = 0,
                        const float *x1 = nullptr, const float *w1 = nullptr, const float *shift_groups = nullptr,
                        const float *wsum_groups = nullptr, const float *sw_groups = nullptr,
-                       const void *rope_cos = nullptr, const void *rope_sin = nullptr, long rope_cols = 0)
+                       const void *rope_cos = nullptr, const void *rope_sin = nullptr, long rope_cols = 0, int act = MQ_ACT_NONE)
 {
     MQ_REQUIRE(M >= 0 && N >= 0 && K_pad >= 0, "mq_gemm_w4a8: negative shape");
     if (M == 0 || N == 0) return MQ_OK;
@@ -713,7 +719,7 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
                "mq_gemm_w4a8: activations must be 16-byte aligned with lda %% 16 == 0 and lda >= K_pad (or lda = MQ_LD_TILED)");
     MQ_REQUIRE(((uintptr_t)w) % 16 == 0, "mq_gemm_w4a8: weight image must be 16-byte aligned");
     MQ_REQUIRE(w_bits == 4 || w_bits == 8, "mq_gemm_w4a8: w_bits must be 4 or 8");
-    MQ_REQUIRE(ldo >= N, "mq_gemm_w4a8: ldo < N");
+    MQ_REQUIRE(ldo >= (act == MQ_ACT_SILU_MUL ? N / 2 : N), "mq_gemm_w4a8: ldo < N");
     MQ_REQUIRE(epi == EPI_I32 || s_w || sw_groups, "mq_gemm_w4a8: s_w is required");
     MQ_REQUIRE((x0 == nullptr) == (w0 == nullptr), "mq_gemm_w4a8: x0 and w0 go together");
     MQ_REQUIRE((x1 == nullptr) == (w1 == nullptr) && (x1 == nullptr || epi != EPI_I32), "mq_gemm_w4a8: x1 and w1 go together (floating-point outputs)");
@@ -775,6 +781,16 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
         default: return launch_gemm<128, 128, 2, 4, 3, 8, EPI_F32, 1, true>(p, gst);
         }
     }
+    if (act != MQ_ACT_NONE) {
+        // the activation lives in the act paths of the wave-specialised / ping-pong epilogues: everything they rely on is checked HERE
+        MQ_REQUIRE(act == MQ_ACT_SILU_MUL || act == MQ_ACT_QUICK_GELU, "mq_gemm_w4a8_act_ws: unknown activation %d", act);
+        MQ_REQUIRE(a_tiled && epi != EPI_I32 && !residual && !x0 && !x1 && !sx_groups && !sw_groups && !rope_cos,
+                   "mq_gemm_w4a8_act_ws: needs tiled activations (lda = MQ_LD_TILED), a floating-point output and no residual / rank-1 / group / RoPE terms");
+        const long n_out = act == MQ_ACT_SILU_MUL ? N / 2 : N;
+        MQ_REQUIRE(act != MQ_ACT_SILU_MUL || N % 64 == 0, "mq_gemm_w4a8_act_ws: silu(gate)*up needs N = 2 x (a multiple of 32) channels, gate then up (N = %ld)", N);
+        MQ_REQUIRE(n_out % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)out) % 16 == 0, "mq_gemm_w4a8_act_ws: output columns and ldo must be multiples of 8, out 16-byte aligned");
+        p.act = act;
+    }
     const bool rope = rope_cos != nullptr;
     if (rope) {
         // RoPE in the store lives in the fast path of the wave-specialised epilogue: everything that path needs is checked HERE
@@ -784,8 +800,13 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
                    "mq_gemm_w4a8_rope_ws: needs tiled activations, a 16-bit 16-byte aligned output with N and ldo multiples of 8, heads of 128 (rope_cols a multiple of 128, at most N) and 16-byte aligned tables");
         p.rope_cos = rope_cos; p.rope_sin = rope_sin; p.rope_cols = rope_cols;
     }
-    const Plan pl = make_plan(M, N, K_pad, workspace != nullptr && !rope, workspace_bytes, g_force_tile,
-                              workspace ? g_force_splits : 0, w_bits == 4, a_tiled, rope);
+    Plan pl = make_plan(M, N, K_pad, workspace != nullptr && !rope && act == MQ_ACT_NONE, workspace_bytes, g_force_tile,
+                        workspace ? g_force_splits : 0, w_bits == 4, a_tiled, rope ? 1 : (act != MQ_ACT_NONE ? 2 : 0));
+    if (act != MQ_ACT_NONE && !(pl.tile >= 40 && pl.tile < 60) && pl.tile != 14 && pl.tile != 19) {
+        // the activation epilogue exists in the 256-wide ping-pong tiles (a wave holds a gate pair AND its up pair) and in the
+        // wave-specialised kernels: anything else the plan came up with takes the best wave-specialised tile
+        pl.tile = make_plan(M, N, K_pad, false, 0, -1, 0, w_bits == 4, a_tiled, 1).tile;
+    }
     p.splits = pl.splits;
     p.partial = (int32_t *)workspace;
     auto al16 = [](const void *q) { return q == nullptr || ((uintptr_t)q) % 16 == 0; };
@@ -875,6 +896,19 @@ extern "C" int mq_gemm_w4a8_rope_ws(const int8_t *a, long lda, const void *w, in
     return mq::gemm_common(a, lda, w, w_bits, M, N, K_pad, s_x0, s_x1, row_sel, s_w, bias, nullptr, nullptr, out, out_dtype, ldo,
                            nullptr, 0, stream, nullptr, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
                            rope_cos, rope_sin, rope_cols);
+}
+
+extern "C" int mq_gemm_w4a8_act_ws(const int8_t *a, long lda, const void *w, int w_bits, long M, long N, long K_pad, float s_x0, float s_x1,
+                                   const uint8_t *row_sel, const float *s_x_rows, const float *s_w, const float *bias, int act,
+                                   void *out, int out_dtype, long ldo, void *stream)
+{
+    if (out_dtype != MQ_F16 && out_dtype != MQ_BF16 && out_dtype != MQ_F32)
+        return mq::fail(MQ_EINVAL, "mq_gemm_w4a8_act_ws: unknown output dtype %d", out_dtype);
+    if (M == 0 || N == 0) return MQ_OK;
+    if (lda != MQ_LD_TILED) return mq::fail(MQ_EUNSUPPORTED, "mq_gemm_w4a8_act_ws: needs activations in the tiled layout (lda = MQ_LD_TILED)");
+    return mq::gemm_common(a, lda, w, w_bits, M, N, K_pad, s_x_rows ? 1.0f : s_x0, s_x_rows ? 1.0f : s_x1, s_x_rows ? nullptr : row_sel, s_w, bias,
+                           nullptr, nullptr, out, out_dtype, ldo, nullptr, 0, stream, s_x_rows, nullptr, 0, nullptr, 0, 0, nullptr, nullptr,
+                           nullptr, nullptr, nullptr, nullptr, nullptr, 0, act);
 }
 
 extern "C" int mq_gemm_w4a8_rowscale_ws(const int8_t *a, long lda, const void *w, int w_bits, long M, long N,

@@ -42,9 +42,10 @@ namespace mq {
 #define MQ_WS_WG_ABL 0   // timing-only ablations of the group fold (wrong results): 4 no fold intervals (every interval plain), 8 no scale DMAs
 #endif
 
-template <int BM, int BN, int MW_M, int MW_N, int NL, int S, int W_BITS, int EPI, int MF = 0, int WG = 0>
+template <int BM, int BN, int MW_M, int MW_N, int NL, int S, int W_BITS, int EPI, int MF = 0, int WG = 0, bool ACT = false>
 __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmArgs p)
 {
+    // ACT: the instantiation with the consumer's activation in the store (GemmArgs::act; dispatch_ws_act)
     static_assert(WG == 0 || MF == 1, "the weight-group fold lives in the 16x16x64 math loop");
     // Math waves: MW_M x MW_N wave tiles of (BM / MW_M) x (BN / MW_N), one or two per SIMD.  (A second group of
     // math waves working the K = 32 sub-steps of the other parity, and wide 96 x 64 / 64 x 64 wave tiles, were
@@ -160,11 +161,29 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
                 const int g = f - A_PIECES;
                 long ntp = nt0 / 2 + (g >> 1);
                 if (ntp >= p.n_pairs) ntp = p.n_pairs - 1;
+                if (ACT && p.act == MQ_ACT_SILU_MUL) {
+                    // silu(gate) * up in the store (GemmArgs::act): slab columns [0, BN/2) = this n-block's BN / 2 gate channels,
+                    // [BN/2, BN) = the same up channels (second half of the image)
+                    constexpr int HS = BN / 64;                  // pair slots per half
+                    const int sl = g >> 1;
+                    const long hp = p.n_pairs >> 1;
+                    long pi = (long)bn * HS + (sl % HS);
+                    if (pi >= hp) pi = hp - 1;
+                    ntp = sl >= HS ? hp + pi : pi;
+                }
                 src[i] = reinterpret_cast<const char *>(p.w) + ((ntp * kps + k_begin) * 2 + (g & 1)) * 1024;
             } else {
                 const int g = f - A_PIECES;
                 long nt = nt0 + (g >> 1);
                 if (nt >= p.n_tiles) nt = p.n_tiles - 1;
+                if (ACT && p.act == MQ_ACT_SILU_MUL) {
+                    constexpr int HT = BN / 32;                  // 16-channel tile slots per half
+                    const int sl = g >> 1;
+                    const long ht = p.n_tiles >> 1;
+                    long ti = (long)bn * HT + (sl % HT);
+                    if (ti >= ht) ti = ht - 1;
+                    nt = sl >= HT ? ht + ti : ti;
+                }
                 src[i] = reinterpret_cast<const char *>(p.w) + ((nt * kps + k_begin) * 2 + (g & 1)) * 1024;
             }
         }
@@ -296,7 +315,11 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
         unsigned pr_rs = 0;
         if (EPI != EPI_I32) {
             const int tn = tid < BN ? tid : BN - 1, tm = tid < BM ? tid : BM - 1;
-            const long nc = n0 + tn < p.N ? n0 + tn : p.N - 1;
+            long nc = n0 + tn < p.N ? n0 + tn : p.N - 1;
+            if (ACT && p.act == MQ_ACT_SILU_MUL) {              // slab column tn: gate channel (first half) or the same up channel (second half)
+                const long H = p.N >> 1, c = (long)bn * (BN / 2) + (tn & (BN / 2 - 1));
+                nc = (c < H ? c : H - 1) + (tn >= BN / 2 ? H : 0);
+            }
             const long mc = m0 + tm < p.M ? m0 + tm : p.M - 1;
             // (dummy: any readable fp32 array for the parameters that are absent -- with weight groups s_w itself is absent)
             const float *dm = (WG & 1) ? p.sw_groups : p.s_w;
@@ -728,7 +751,7 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
         }
         if (EPI != EPI_I32) {                        // the parameter block sits behind the ring
             if (tid < BN) {
-                const bool ok = n0 + tid < p.N;
+                const bool ok = (ACT && p.act == MQ_ACT_SILU_MUL) ? ((long)bn * (BN / 2) + (tid & (BN / 2 - 1)) < (p.N >> 1)) : (n0 + tid < p.N);
                 par_sw[tid] = ok ? pr_sw : 0.0f;
                 par_bs[tid] = (ok && p.bias) ? pr_bs : 0.0f;
                 par_wz[tid] = (ok && p.w0) ? pr_wz : 0.0f;
@@ -793,6 +816,76 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
             wzv[e] = par_wz[c8 + e];
             w1v[e] = par_w1[c8 + e];
         }
+    }
+    // Activation in the store (GemmArgs::act; preconditions host-checked in gemm_common): the Linear's output is formed and rounded
+    // to the output dtype exactly as the fast path below stores it, then the activation like the torch ops on that tensor.
+    // SILU_MUL: slab columns [0, BN/2) hold gate, [BN/2, BN) the same up channels (the loaders' pairing); a lane owns 8 OUTPUT channels.
+    if constexpr (ACT) {
+        if constexpr (EPI != EPI_I32 && WG == 0) {
+            constexpr int DT = (EPI == EPI_F16) ? MQ_F16 : (EPI == EPI_BF16 ? MQ_BF16 : MQ_F32);
+            const bool silu = p.act == MQ_ACT_SILU_MUL;
+            const bool has_bias = p.bias != nullptr;
+            constexpr int LPR_S = BN / 16;                                // lanes per row with half as many outputs
+            const int rpi = silu ? NT / LPR_S : RPI;
+            const int arow = silu ? tid / LPR_S : tid / LPR;
+            const int ob = (silu ? tid % LPR_S : tid % LPR) * 8;          // slab column of the (gate) operand; up: + BN / 2
+            const long H = p.N >> 1;
+            const long no = silu ? (long)bn * (BN / 2) + ob : n0 + ob;    // output column
+            const bool n_ok = silu ? (no + 8 <= H) : (no + 8 <= p.N);
+            float sg[8], su[8], bg[8], bu[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sg[e] = par_sw[ob + e];
+                bg[e] = par_bs[ob + e];
+                su[e] = silu ? par_sw[BN / 2 + ob + e] : 0.0f;
+                bu[e] = silu ? par_bs[BN / 2 + ob + e] : 0.0f;
+            }
+#pragma unroll 1
+            for (int r0 = 0; r0 < BM; r0 += rpi) {
+                const int row = r0 + arow;
+                const long m = m0 + row;
+                if (row >= BM || m >= p.M || !n_ok) continue;
+                const v4i g0 = *reinterpret_cast<const v4i *>(smem + row * PITCH + ob * 4);
+                const v4i g1 = *reinterpret_cast<const v4i *>(smem + row * PITCH + ob * 4 + 16);
+                v4i u0 = g0, u1 = g1;
+                if (silu) {
+                    u0 = *reinterpret_cast<const v4i *>(smem + row * PITCH + (BN / 2 + ob) * 4);
+                    u1 = *reinterpret_cast<const v4i *>(smem + row * PITCH + (BN / 2 + ob) * 4 + 16);
+                }
+                const float sxe = (W_BITS == 4) ? par_sx[row] * 0.0625f : par_sx[row];
+                const int ag[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+                const int au[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
+                float h[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float g = (float)ag[e] * sxe;
+                    g = g * sg[e];
+                    if (has_bias) g = g + bg[e];
+                    g = Elem<DT>::rnd(g);                                 // the Linear's output, in the model's dtype
+                    if (silu) {
+                        float u = (float)au[e] * sxe;
+                        u = u * su[e];
+                        if (has_bias) u = u + bu[e];
+                        u = Elem<DT>::rnd(u);
+                        h[e] = act_silu_mul<DT>(g, u);
+                    } else {
+                        h[e] = act_quick_gelu<DT>(g);
+                    }
+                }
+                if (EPI == EPI_F32) {
+                    float *o = reinterpret_cast<float *>(p.out) + m * p.ldo + no;
+                    store_out(reinterpret_cast<v4f *>(o), v4f{h[0], h[1], h[2], h[3]});
+                    store_out(reinterpret_cast<v4f *>(o + 4), v4f{h[4], h[5], h[6], h[7]});
+                } else {
+                    v4i hw;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        hw[e] = (int)((unsigned)Elem<DT>::st(h[2 * e]) | ((unsigned)Elem<DT>::st(h[2 * e + 1]) << 16));
+                    store_out(reinterpret_cast<v4i *>(reinterpret_cast<unsigned short *>(p.out) + m * p.ldo + no), hw);
+                }
+            }
+        }
+        return;
     }
     // Fast path (what every Linear of the prefill takes): whole 8-channel groups, fp16 / bf16 / fp32
     // output, no residual, no split-K.  Straight-line code: all slab reads first, then the arithmetic,
@@ -1032,14 +1125,14 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
     }
 }
 
-template <int BM, int BN, int MW_M, int MW_N, int NL, int S, int W_BITS, int EPI, int MF = 0, int WG = 0>
+template <int BM, int BN, int MW_M, int MW_N, int NL, int S, int W_BITS, int EPI, int MF = 0, int WG = 0, bool ACT = false>
 static int launch_ws(const GemmArgs &p, hipStream_t st)
 {
     constexpr int PIECES = (BM / 16) * 2 + ((W_BITS == 4) ? (BN / 32) * 2 : (BN / 16) * 2);
     constexpr int RING = S * (PIECES + ((WG && !(MQ_WS_WG_ABL & 8)) ? 3 : 0)) * 1024, SLAB = BM * (BN * 4 + 16);   // (WG: three 1 KiB scale blocks per stage)
     constexpr int SMEM = (RING > SLAB ? RING : SLAB) + (4 * BN + 3 * BM) * 4;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
-    auto kern = gemm_ws_kernel<BM, BN, MW_M, MW_N, NL, S, W_BITS, EPI, MF, WG>;
+    auto kern = gemm_ws_kernel<BM, BN, MW_M, MW_N, NL, S, W_BITS, EPI, MF, WG, ACT>;
     int rc = ensure_dynamic_lds((const void *)kern, SMEM);
     if (rc != MQ_OK) return rc;
     GemmArgs g = p;
@@ -1049,9 +1142,31 @@ static int launch_ws(const GemmArgs &p, hipStream_t st)
     return check_launch("gemm_ws");
 }
 
+// Activation in the store (GemmArgs::act): the 16x16x64 tiles (ids 44-48; the 32x32x32 ids 40-43 map onto their twins).
+template <int W_BITS, int EPI>
+static int dispatch_ws_act(const GemmArgs &p, int tile, hipStream_t st)
+{
+    if constexpr (EPI == EPI_I32) {
+        return fail(MQ_EINVAL, "gemm_ws: an activation needs a floating-point output");
+    } else {
+        switch (tile) {
+        case 40: case 44: return launch_ws<96, 128, 1, 4, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI, 1, 0, true>(p, st);
+        case 41: case 45: return launch_ws<128, 128, 2, 4, 4, (W_BITS == 4 ? 6 : 4), W_BITS, EPI, 1, 0, true>(p, st);
+        case 42: case 46:
+            if constexpr (W_BITS == 4) return launch_ws<192, 128, 2, 4, 4, 4, W_BITS, EPI, 1, 0, true>(p, st);
+            else break;
+        case 43: case 47: return launch_ws<64, 128, 1, 4, 4, (W_BITS == 4 ? 8 : 6), W_BITS, EPI, 1, 0, true>(p, st);
+        case 48: return launch_ws<96, 128, 2, 4, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI, 1, 0, true>(p, st);
+        default: break;
+        }
+        return fail(MQ_EINVAL, "gemm_ws: tile %d has no activation epilogue", tile);
+    }
+}
+
 template <int W_BITS, int EPI>
 int dispatch_ws(const GemmArgs &p, int tile, hipStream_t st)
 {
+    if (p.act != MQ_ACT_NONE) return dispatch_ws_act<W_BITS, EPI>(p, tile, st);
     switch (tile) {
     // one math wave per SIMD (1 x 4 wave tiles) or two (2 x 4), four loader waves
     case 40: return launch_ws<96, 128, 1, 4, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI>(p, st);

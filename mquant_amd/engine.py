@@ -297,6 +297,26 @@ class W4A8Linear:
                              s_x1=self.s_x1, row_sel=row_sel, bias=self.bias, x0=x0, w0=w0,
                              out_dtype=out_dtype, out=out)
 
+    def act_in_store_ok(self, act: int) -> bool:
+        """Whether ``gemm_act`` can run this layer: a plain static layer (no split column, rank-1 terms, groups or --act_order), tiled
+        activations, and for silu(gate) * up a fused gate|up image of 2 x (a multiple of 32) channels."""
+        plain = (not self.split and self.w_shift is None and self.w_groups is None and self.dynamic is None and self.col_perm is None
+                 and ACT_LAYOUT == "tiled")
+        if act == ops.ACT_SILU_MUL:
+            return plain and self.N % 64 == 0
+        return plain and act == ops.ACT_QUICK_GELU and self.N % 8 == 0
+
+    def gemm_act(self, a, act: int, out_dtype: torch.dtype, row_sel: Optional[torch.Tensor] = None,
+                 out: Optional[torch.Tensor] = None):
+        """The Linear with the activation of its CONSUMER folded into the GEMM's store (``mq_gemm_w4a8_act_ws``): for a fused
+        gate|up engine ``silu(gate) * up`` -- ONE [M, N/2] tensor instead of [M, N] -- and ``quick_gelu`` behind the vision tower's
+        fc1; the rotated Linear behind it (down_proj / fc2) then runs its plain Hadamard + quantize launch."""
+        assert self.act_in_store_ok(act), "gemm_act: plain static layers only (see act_in_store_ok)"
+        if DEBUG_WORKSPACE:
+            WORKSPACE.check_fresh(a)
+        return ops.gemm_w4a8_act(a, self.w_img, self.w_bits, self.N, self.s_x0, self.s_w, act, s_x1=self.s_x1, row_sel=row_sel,
+                                 bias=self.bias, out_dtype=out_dtype, out=out)
+
     def gemm_rope(self, a, cos: torch.Tensor, sin: torch.Tensor, rope_cols: int, out_dtype: torch.dtype,
                   row_sel: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
         """The Linear with the rotary embedding of its first ``rope_cols`` output columns (heads of 128: the q | k part of a

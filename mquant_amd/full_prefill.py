@@ -81,6 +81,10 @@ class FullPrefill:
         self.vis_attn_kernel = own and self.g.vis_dim // self.g.vis_heads in (80, 128)      # the vision tower's (non-causal) attention
         #: the decoder's RoPE rides in the q|k|v GEMM's store (mq_gemm_w4a8_rope_ws) instead of its own launch (round 5)
         self.rope_fused = fused_glue
+        #: silu(gate) * up and the vision tower's QuickGELU ride in the store of the PRODUCING GEMM (mq_gemm_w4a8_act_ws, round 6):
+        #: one [T, 18944] tensor leaves gate|up instead of [T, 37888], and down_proj / fc2 run their plain Hadamard + quantize
+        #: launch; False = round 5's form, the activation in the Hadamard kernel's prologue (mq_act_hadamard_quant_i8)
+        self.act_in_gemm = fused_glue
         self.kv_cache: List[torch.Tensor] = []
         self.kv_scales: List[torch.Tensor] = []
         assert pf.share_groups, "the chained prefill uses the fused q/k/v and gate/up GEMMs"
@@ -138,6 +142,14 @@ class FullPrefill:
         a, _ = L.lin.quantize_rmsn(x, dim, 1e-6, L.row_sel)
         return L.lin.gemm(a, None, self.dtype, L.row_sel)
 
+    def _norm_lin_act(self, L: Layer, x: torch.Tensor, dim: int, act: int) -> Optional[torch.Tensor]:
+        """act(Linear(RMSN(x))) with the activation in the GEMM's store, or None when this layer / mode cannot take it."""
+        if (self.calibrating or not (self.fused_glue and self.act_in_gemm) or not L.lin.act_in_store_ok(act) or L.lin.had is not None
+                or x.shape[0] <= 64):                                      # (a few rows: the weight-streaming kernels have no act epilogue)
+            return None
+        a, _ = L.lin.quantize_rmsn(x, dim, 1e-6, L.row_sel)
+        return L.lin.gemm_act(a, act, self.dtype, L.row_sel)
+
     def _act_lin(self, L: Layer, x: torch.Tensor, x2, act: int, residual: torch.Tensor) -> torch.Tensor:
         """residual + Linear(act(x[, x2])) for a layer with an online Hadamard."""
         if self.calibrating or not self.fused_glue:
@@ -145,6 +157,15 @@ class FullPrefill:
             return self._lin(L, h, residual)
         a, x0 = L.lin.quantize_act(x, x2, act, L.row_sel)
         return L.lin.gemm_residual(a, x0, residual, L.row_sel)
+
+    def _vis_mlp(self, i: int, x: torch.Tensor) -> torch.Tensor:
+        """x + fc2(quick_gelu(fc1(RMSN(x)))) of vision block i (hidden_act = quick_gelu)."""
+        VD = self.g.vis_dim
+        f = self._norm_lin_act(self.by["vis.mlp.fc1"][i], x, VD, ops.ACT_QUICK_GELU)     # fc1 storing quick_gelu(fc1(.))
+        if f is not None:
+            return self._lin(self.by["vis.mlp.fc2"][i], f, residual=x)
+        f = self._norm_lin(self.by["vis.mlp.fc1"][i], x, VD)
+        return self._act_lin(self.by["vis.mlp.fc2"][i], f, None, ops.ACT_QUICK_GELU, residual=x)
 
     def calibrate(self):
         """One calibration pass over the CHAINED activations; the hot path's own scales (calibrated on its
@@ -191,8 +212,7 @@ class FullPrefill:
                 qa = Lp.lin.act_buffer(M_VIS)
                 ops.attn_prefill_quant_i8(q, Lp.lin.s_x0, Lp.lin.s_x1, k=k, v=v, causal=False, row_sel=Lp.row_sel, out=qa)
                 x = Lp.lin.gemm_residual(qa, None, x, Lp.row_sel)
-                f = self._norm_lin(by["vis.mlp.fc1"][i], x, VD)
-                x = self._act_lin(by["vis.mlp.fc2"][i], f, None, ops.ACT_QUICK_GELU, residual=x)
+                x = self._vis_mlp(i, x)
                 continue
             if self.vis_attn_kernel:
                 flat = ops.attn_prefill(q, k, v, causal=False)
@@ -203,8 +223,7 @@ class FullPrefill:
             if i == 0:
                 self.vis_attn_first = flat     # [patches, vis_dim] of the first vision block (tests)
             x = self._lin(by["vis.attn.proj"][i], flat, residual=x)
-            f = self._norm_lin(by["vis.mlp.fc1"][i], x, VD)
-            x = self._act_lin(by["vis.mlp.fc2"][i], f, None, ops.ACT_QUICK_GELU, residual=x)   # hidden_act = quick_gelu
+            x = self._vis_mlp(i, x)
         m = F.rms_norm(x, (VD,), eps=1e-6).view(M_MERGED, 4 * VD)
         m = self._lin(by["merger.mlp.2"][0], F.gelu(self._lin(by["merger.mlp.0"][0], m)))
         # language model: [vision tokens | text tokens]
@@ -281,9 +300,13 @@ class FullPrefill:
                 self.attn_first = a            # [heads, T, head_dim] of the first decoder layer (tests; layer 0 keeps the 16-bit output)
             if not quant_out:
                 hdn = self._lin(Lo, flat, residual=hdn)
-            gu = self._norm_lin(by["llm.gate_proj"][i], hdn, D)    # fused gate|up GEMM
-            half = gu.shape[1] // 2
-            hdn = self._act_lin(by["llm.down_proj"][i], gu[:, :half], gu[:, half:], ops.ACT_SILU_MUL, residual=hdn)
+            h = self._norm_lin_act(by["llm.gate_proj"][i], hdn, D, ops.ACT_SILU_MUL)     # fused gate|up GEMM storing silu(gate) * up
+            if h is not None:
+                hdn = self._lin(by["llm.down_proj"][i], h, residual=hdn)
+            else:
+                gu = self._norm_lin(by["llm.gate_proj"][i], hdn, D)    # fused gate|up GEMM
+                half = gu.shape[1] // 2
+                hdn = self._act_lin(by["llm.down_proj"][i], gu[:, :half], gu[:, half:], ops.ACT_SILU_MUL, residual=hdn)
         last = F.rms_norm(hdn[-1:], (D,), eps=1e-6)
         self.logits = last @ self.lm_head.t()
         return self.logits

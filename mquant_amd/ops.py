@@ -613,6 +613,26 @@ def gemm_w4a8(a: torch.Tensor, w_img: torch.Tensor, w_bits: int, N: int, s_x0: f
 
 
 @_on_device
+def gemm_w4a8_act(a, w_img: torch.Tensor, w_bits: int, N: int, s_x0: float, s_w: torch.Tensor, act: int, *,
+                  s_x1: Optional[float] = None, row_sel: Optional[torch.Tensor] = None,
+                  s_x_rows: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+                  out_dtype: torch.dtype = torch.float16, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The Linear with its CONSUMER's activation folded into the store (``mq_gemm_w4a8_act_ws``): ``ACT_SILU_MUL`` -- the image
+    holds gate (channels 0 .. N/2-1) then up, the result is silu(gate) * up, [M, N/2]; ``ACT_QUICK_GELU`` -- [M, N].  Bit-identical
+    to ``gemm_w4a8`` followed by the torch ops on the rounded output.  Tiled activations only."""
+    _need_cuda(a, w_img, s_w, row_sel, s_x_rows, bias, out)
+    aptr, lda, M, K_pad = _a_args(a)
+    n_out = N // 2 if act == ACT_SILU_MUL else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=out_dtype, device=w_img.device)
+    assert out.shape == (M, n_out)
+    call("mq_gemm_w4a8_act_ws", aptr, lda, w_img.data_ptr(), w_bits, M, N, K_pad, float(s_x0),
+         float(s_x0 if s_x1 is None else s_x1), _ptr(row_sel), _ptr(s_x_rows), s_w.data_ptr(), _ptr(bias), int(act),
+         out.data_ptr(), dtype_code(out.dtype), out.stride(0), _stream())
+    return out
+
+
+@_on_device
 def quantize_act_dyn_i8(x: torch.Tensor, bits: int = 8, clip_ratio: float = 1.0, *, skip_col0: bool = False,
                         out=None, tiled: bool = False):
     """Dynamic symmetric per-token quantizer (the reference's default activation mode).

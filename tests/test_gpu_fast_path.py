@@ -27,11 +27,16 @@ def _wrapped(K=512, N=256, had=False, msq=False, bias=True, seed=0):
     rtn_module(root, "m", 4, True, False, [], {})
     args = types.SimpleNamespace(skip_names=[], no_sibling_fusion=True)
     x = torch.randn((48, K), generator=g, device=dev).half()
-    qu.model_open_calibrate(root, args)
-    qu.model_open_last_calibrate(root, args)
-    wrap(x)
-    qu.model_close_calibrate(root, args)
-    qu.model_quant(root, args)
+    mask = None
+    if msq:                                            # rows 0..19 vision, 20.. text: both scale sets get calibrated
+        mask = torch.zeros(48, dtype=torch.uint8, device=dev)
+        mask[20:] = 1
+    with qu.token_type_mask(mask):
+        qu.model_open_calibrate(root, args)
+        qu.model_open_last_calibrate(root, args)
+        wrap(x)
+        qu.model_close_calibrate(root, args)
+        qu.model_quant(root, args)
     return qu, root, wrap, args, x
 
 
