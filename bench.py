@@ -172,9 +172,10 @@ def full_prefill_report(pf, dev, args, geometry=None, kv_fp8=False, attn_fp8=Fal
     from mquant_amd import workload
     from mquant_amd.full_prefill import FullPrefill
     try:
-        def measure(fused, rope_fused=True):
+        def measure(fused, rope_fused=True, act_in_gemm=True):
             fp = FullPrefill(pf, fused_glue=fused, geometry=geometry, kv_fp8=kv_fp8, attn_fp8=attn_fp8)
             fp.rope_fused = fused and rope_fused          # the decoder's RoPE in the q|k|v GEMM's store (round 5) or its own launch
+            fp.act_in_gemm = fused and act_in_gemm        # silu(gate)*up / QuickGELU in the producing GEMM's store (round 6) or in the Hadamard kernel's prologue
             fp.calibrate()
             if args.no_graph:
                 run = fp.step
@@ -209,6 +210,7 @@ def full_prefill_report(pf, dev, args, geometry=None, kv_fp8=False, attn_fp8=Fal
         med_u, p90_u, _, _ = measure(False)
         med, p90, iters, finite = measure(True)
         med_rope = measure(True, rope_fused=False)[0]     # same process, same box: what the separate RoPE launch costs
+        med_actp = measure(True, act_in_gemm=False)[0]    # same process, same box: round 5's form of the activations
         # informational: the same prefill with the NON-DEFAULT fast Hadamard stage (K x K stage on the half-precision matrix
         # core; ~1e-7 of the int8 levels differ from the exact kernel -- DESIGN 4.2).  The flag lives in the layer descriptors
         # of THIS model object (workload.set_had_fast); it is cleared again before returning, and nothing process-wide exists.
@@ -223,13 +225,16 @@ def full_prefill_report(pf, dev, args, geometry=None, kv_fp8=False, attn_fp8=Fal
             med_fast = None
         return {"what": "whole synthetic prefill: W4A8 Linears (this repo's kernels) + attention (mq_attn_prefill on the q|k|v GEMM "
                         "outputs in place: decoder head_dim 128 causal, vision tower head_dim 80) and fp16 lm_head on the last position; "
-                        "RMS norm -> quantize, SiLU*up / QuickGELU -> Hadamard -> quantize, residual adds (GEMM epilogue) and "
+                        "RMS norm -> quantize, residual adds (GEMM epilogue), SiLU*up / QuickGELU (in the store of the PRODUCING gate|up / fc1 "
+                        "GEMM, mq_gemm_w4a8_act_ws: down_proj / fc2 then run their plain Hadamard -> quantize launch) and "
                         "RoPE (the decoder's in the q|k|v GEMM's store, the vision tower's as one in-place launch) run fused; "
+                        "ttft_ms_median_act_in_hadamard_prologue = the same with the activations in the Hadamard kernel's prologue (round 5's form); "
                         "ttft_ms_median_unfused_glue = the same dataflow with those steps as separate torch ops and torch SDPA everywhere; "
                         "ttft_ms_median_rope_as_its_own_launch = fused glue with the decoder's RoPE launched separately (round 4's form)",
                 "ttft_ms_median": round(med, 4), "ttft_ms_p90": round(p90, 4), "iters": iters,
                 "ttft_ms_median_unfused_glue": round(med_u, 4), "ttft_ms_p90_unfused_glue": round(p90_u, 4),
                 "ttft_ms_median_rope_as_its_own_launch": round(med_rope, 4),
+                "ttft_ms_median_act_in_hadamard_prologue": round(med_actp, 4),
                 "ttft_ms_median_fast_hadamard_NON_DEFAULT": None if med_fast is None else round(med_fast, 4),
                 "llm_tokens_per_s": round(workload.M_LLM / (med * 1e-3), 1),
                 "all_tokens_per_s": round((workload.M_LLM + workload.M_VIS) / (med * 1e-3), 1),
@@ -665,6 +670,28 @@ def main():
                         "frac keeps the nominal peak as its denominator (profiles/r5_clock_reconciliation.txt)"}
         except Exception as exc:  # a report, never a reason to lose the line
             roofline["peak_sustained_measured"] = {"value": None, "how": f"failed: {exc!r}"}
+
+    if not args.tiny:
+        # per-shape launch times (each shape's GEMMs back to back from their own hipGraph, distinct weight images as in the step) and the
+        # floor model beside them: mquant_amd/floor_model.py
+        try:
+            from mquant_amd import floor_model
+            from mquant_amd.engine import WORKSPACE
+            groups = floor_model.shape_groups(pf.layers)
+            per_shape_us = {}
+            for gi, grp in enumerate(groups):
+                def run_group(grp=grp):
+                    for L in grp["layers"]:
+                        a = WORKSPACE.act(dev, L.spec.M, L.lin.K_pad)
+                        x0 = WORKSPACE.x0(dev, L.spec.M) if L.lin.split else None
+                        L.lin.gemm(a, x0, torch.float16, L.row_sel, L.out)
+                per_shape_us[gi] = timed(capture(run_group), batches=3) * 1e3 / len(grp["layers"])
+            sus_top = (roofline.get("peak_sustained_measured") or {}).get("value") or 0.0
+            fm = floor_model.summarize(groups, per_shape_us, sus_top, cus=torch.cuda.get_device_properties(dev).multi_processor_count)
+            roofline["frac_floor_model"] = fm["frac_floor_model"]
+            roofline["floor_model"] = fm
+        except Exception as exc:  # a report, never a reason to lose the line
+            roofline["floor_model"] = {"error": repr(exc)}
 
     n_lin = sum(sp.count for sp in specs)
     desc = workload_desc + f", M_llm={workload.M_LLM}"

@@ -521,6 +521,11 @@ int mq_act_rowsum_scaled(const int8_t *a, long lda, long M, long K_pad, float s_
  * force the number of m-groups of the XCD mapping, 0 = automatic) for the GEMM calls the CALLING THREAD
  * makes afterwards (thread-local state; other threads keep the heuristic). */
 int mq_gemm_debug_force(int tile, int splits);
+/* TEST-ONLY: the fused activations of the 16-bit dtypes (csrc/mq_common.h act_silu_16 / act_sigmoid_16 and the packed forms of the GEMM act
+ * epilogues) against the reference forms (device expf + IEEE division, what torch's silu / sigmoid kernels execute), element by element:
+ * which = 0 silu(x), 1 sigmoid(x), 2 silu(x) * u, 3 quick_gelu(x), 4 / 5 the packed two-at-a-time forms of 2 / 3.  in_bits / in2_bits /
+ * out_*: n 16-bit patterns of dtype (MQ_F16 or MQ_BF16); in2_bits may be NULL (u = 1).  tests/test_gpu_act_exhaustive.py runs all 2^16 inputs. */
+int mq_debug_act_table(int dtype, int which, const void *in_bits, const void *in2_bits, long n, void *out_fast, void *out_ref, void *stream);
 /* TEST-ONLY: the plan (tile id, split-K factor) the dispatcher takes for a shape; host arithmetic only. */
 int mq_gemm_debug_plan(long M, long N, long K_pad, int w_bits, int a_tiled, int have_workspace, int *tile, int *splits);
 

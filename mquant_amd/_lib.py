@@ -72,6 +72,7 @@ SIGNATURES = {
     "mq_gemm_w4a8_ws": (_i, [_vp, _l, _vp, _i, _l, _l, _l, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _l, _vp, C.c_size_t, _vp]),
     "mq_gemm_w4a8_i32_ws": (_i, [_vp, _l, _vp, _i, _l, _l, _l, _vp, _l, _vp, C.c_size_t, _vp]),
     "mq_gemm_debug_force": (_i, [_i, _i]),
+    "mq_debug_act_table": (_i, [_i, _i, _vp, _vp, _l, _vp, _vp, _vp]),
     "mq_gemm_debug_plan": (_i, [_l, _l, _l, _i, _i, _i, _vp, _vp]),
     "mq_minmax_channels": (_i, [_vp, _i, _l, _l, _l, _l, _vp, _vp, _vp]),
     "mq_minmax_tensor": (_i, [_vp, _i, _l, _l, _l, _l, _vp, _vp]),

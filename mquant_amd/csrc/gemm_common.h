@@ -1,6 +1,8 @@
 // gemm_common.h -- pieces shared by the W4A8 GEMM kernels (gemm_w4a8.hip, gemm_ws.hip):
 // argument block, LDS-DMA helper, dequantisation epilogue.
 #pragma once
+#include <type_traits>
+
 #include "mq_common.h"
 
 namespace mq {
@@ -328,26 +330,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][
     if constexpr (ACT) {
         if constexpr (NWAVES <= 8 && EPI != EPI_I32) {
             constexpr int DT = (EPI == EPI_F16) ? MQ_F16 : (EPI == EPI_BF16 ? MQ_BF16 : MQ_F32);
-            const bool silu = p.act == MQ_ACT_SILU_MUL;
-            const bool has_bias = p.bias != nullptr;
-            if (silu && (WN_COLS % 64 != 0)) return;                     // (host: only tiles whose waves hold whole pairs)
+            const bool silu_rt = p.act == MQ_ACT_SILU_MUL;
+            const bool bias_rt = p.bias != nullptr;
+            if (silu_rt && (WN_COLS % 64 != 0)) return;                     // (host: only tiles whose waves hold whole pairs)
             const long H = p.N >> 1;
             constexpr int LPR_S = WN_COLS / 16 > 0 ? WN_COLS / 16 : 1;    // lanes per slab row: SILU_MUL (half as many outputs) / GELU
-            const int rpi = silu ? 64 / LPR_S : ROWS_PER_IT;              // rows per iteration
-            const int arow = silu ? lane / LPR_S : lane / LANES_PER_ROW;
-            const int ob = (silu ? lane % LPR_S : lane % LANES_PER_ROW) * 8;   // first of the lane's 8 outputs inside the wave's sub-tile
-            const int gc = silu ? (ob >> 5) * 64 + (ob & 31) : ob;        // slab column of the (gate) operand; up: + 32
-            const long no = silu ? nt0 * 8 + wn * (WN_COLS / 2) + ob : nt0 * 16 + wn * WN_COLS + ob;   // output column
-            const bool n_ok = silu ? (no + 8 <= H) : (no + 8 <= p.N);
+            const int rpi = silu_rt ? 64 / LPR_S : ROWS_PER_IT;              // rows per iteration
+            const int arow = silu_rt ? lane / LPR_S : lane / LANES_PER_ROW;
+            const int ob = (silu_rt ? lane % LPR_S : lane % LANES_PER_ROW) * 8;   // first of the lane's 8 outputs inside the wave's sub-tile
+            const int gc = silu_rt ? (ob >> 5) * 64 + (ob & 31) : ob;        // slab column of the (gate) operand; up: + 32
+            const long no = silu_rt ? nt0 * 8 + wn * (WN_COLS / 2) + ob : nt0 * 16 + wn * WN_COLS + ob;   // output column
+            const bool n_ok = silu_rt ? (no + 8 <= H) : (no + 8 <= p.N);
             // per-channel parameters of the lane's 8 outputs (and of the 8 up channels behind them): 16-byte loads -- the operands are
             // 16-byte aligned and the columns multiples of 8 (host-checked); scalar loads with their 64-bit addresses, hoisted above the
             // parking of the accumulators, overflowed the register file of the 256 x 256 tile
             const long cb = n_ok ? no : 0;
-            const float *bias_or_sw = has_bias ? p.bias : p.s_w;
+            const float *bias_or_sw = bias_rt ? p.bias : p.s_w;
             const v4f sg0 = *reinterpret_cast<const v4f *>(p.s_w + cb), sg1 = *reinterpret_cast<const v4f *>(p.s_w + cb + 4);
-            const v4f su0 = *reinterpret_cast<const v4f *>(p.s_w + (silu ? H : 0) + cb), su1 = *reinterpret_cast<const v4f *>(p.s_w + (silu ? H : 0) + cb + 4);
+            const v4f su0 = *reinterpret_cast<const v4f *>(p.s_w + (silu_rt ? H : 0) + cb), su1 = *reinterpret_cast<const v4f *>(p.s_w + (silu_rt ? H : 0) + cb + 4);
             const v4f bg0 = *reinterpret_cast<const v4f *>(bias_or_sw + cb), bg1 = *reinterpret_cast<const v4f *>(bias_or_sw + cb + 4);
-            const v4f bu0 = *reinterpret_cast<const v4f *>(bias_or_sw + (silu ? H : 0) + cb), bu1 = *reinterpret_cast<const v4f *>(bias_or_sw + (silu ? H : 0) + cb + 4);
+            const v4f bu0 = *reinterpret_cast<const v4f *>(bias_or_sw + (silu_rt ? H : 0) + cb), bu1 = *reinterpret_cast<const v4f *>(bias_or_sw + (silu_rt ? H : 0) + cb + 4);
             float sg[8], su[8], bg[8], bu[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -356,71 +358,77 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, v4i (&acc)[TN][
                 bg[e] = bg0[e]; bg[4 + e] = bg1[e];
                 bu[e] = bu0[e]; bu[4 + e] = bu1[e];
             }
+            // the row loop once per (activation, bias) combination: no uniform branch left between two elements
+            auto rows = [&](auto silu_c, auto bias_c) {
+                constexpr bool silu = decltype(silu_c)::value, has_bias = decltype(bias_c)::value;
 #pragma unroll
-            for (int pass = 0; pass < TM / PASS_MT; ++pass) {              // (unrolled: the accumulators are registers, no dynamic index)
+                for (int pass = 0; pass < TM / PASS_MT; ++pass) {              // (unrolled: the accumulators are registers, no dynamic index)
 #pragma unroll
-                for (int jj = 0; jj < PASS_MT; ++jj)
+                    for (int jj = 0; jj < PASS_MT; ++jj)
 #pragma unroll
-                    for (int i = 0; i < TN; ++i)
-                        *reinterpret_cast<v4i *>(slab + (jj * 16 + ml) * SLAB_LD + (i * 16 + nq) * 4) = acc[i][pass * PASS_MT + jj];
-                if (lane < PASS_ROWS) {
-                    const long mr = m0 + (wm * TM + pass * PASS_MT) * 16 + lane;
-                    float sxl = p.sx0;
-                    if (mr < p.M) {
-                        if (p.sx_vec) sxl = p.sx_vec[mr];
-                        else if (p.row_sel && p.row_sel[mr]) sxl = p.sx1;
+                        for (int i = 0; i < TN; ++i)
+                            *reinterpret_cast<v4i *>(slab + (jj * 16 + ml) * SLAB_LD + (i * 16 + nq) * 4) = acc[i][pass * PASS_MT + jj];
+                    if (lane < PASS_ROWS) {
+                        const long mr = m0 + (wm * TM + pass * PASS_MT) * 16 + lane;
+                        float sxl = p.sx0;
+                        if (mr < p.M) {
+                            if (p.sx_vec) sxl = p.sx_vec[mr];
+                            else if (p.row_sel && p.row_sel[mr]) sxl = p.sx1;
+                        }
+                        rowpar[lane * 4] = sxl;
                     }
-                    rowpar[lane * 4] = sxl;
-                }
-                asm volatile("" ::: "memory");
+                    asm volatile("" ::: "memory");
 #pragma unroll 1
-                for (int r0 = 0; r0 < PASS_ROWS; r0 += rpi) {
-                    const int row = r0 + arow;
-                    const long m = m0 + (wm * TM + pass * PASS_MT) * 16 + row;
-                    const v4i g0 = *reinterpret_cast<const v4i *>(slab + row * SLAB_LD + gc * 4);
-                    const v4i g1 = *reinterpret_cast<const v4i *>(slab + row * SLAB_LD + gc * 4 + 16);
-                    v4i u0 = g0, u1 = g1;
-                    if (silu) {
-                        u0 = *reinterpret_cast<const v4i *>(slab + row * SLAB_LD + gc * 4 + 128);
-                        u1 = *reinterpret_cast<const v4i *>(slab + row * SLAB_LD + gc * 4 + 144);
-                    }
-                    const float sxe = (W_BITS == 4) ? rowpar[row * 4] * 0.0625f : rowpar[row * 4];
-                    const int ag[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-                    const int au[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
-                    float h[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float g = (float)ag[e] * sxe;
-                        g = g * sg[e];
-                        if (has_bias) g = g + bg[e];
-                        g = Elem<DT>::rnd(g);                            // the Linear's output, in the model's dtype
+                    for (int r0 = 0; r0 < PASS_ROWS; r0 += rpi) {
+                        const int row = r0 + arow;
+                        const long m = m0 + (wm * TM + pass * PASS_MT) * 16 + row;
+                        const v4i g0 = *reinterpret_cast<const v4i *>(slab + row * SLAB_LD + gc * 4);
+                        const v4i g1 = *reinterpret_cast<const v4i *>(slab + row * SLAB_LD + gc * 4 + 16);
+                        v4i u0 = g0, u1 = g1;
                         if (silu) {
+                            u0 = *reinterpret_cast<const v4i *>(slab + row * SLAB_LD + gc * 4 + 128);
+                            u1 = *reinterpret_cast<const v4i *>(slab + row * SLAB_LD + gc * 4 + 144);
+                        }
+                        const float sxe = (W_BITS == 4) ? rowpar[row * 4] * 0.0625f : rowpar[row * 4];
+                        const int ag[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+                        const int au[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
+                        // the two Linear outputs in fp32 -- the plain launch's arithmetic, one rounding per operation -- then the activation
+                        float gf[8], uf[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            float g = (float)ag[e] * sxe;
+                            g = g * sg[e];
+                            if (has_bias) g = g + bg[e];
+                            gf[e] = g;
                             float u = (float)au[e] * sxe;
                             u = u * su[e];
                             if (has_bias) u = u + bu[e];
-                            u = Elem<DT>::rnd(u);
-                            h[e] = act_silu_mul<DT>(g, u);
-                        } else {
-                            h[e] = act_quick_gelu<DT>(g);
+                            uf[e] = u;
                         }
-                        // one element's exp / division chain at a time: interleaved, the eight chains plus the accumulators of the
-                        // passes still to come do not fit the register file of a 512-thread workgroup
-                        if (e & 1) __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (m >= p.M || !n_ok) continue;
-                    if (EPI == EPI_F32) {
-                        float *o = reinterpret_cast<float *>(p.out) + m * p.ldo + no;
-                        store_out(reinterpret_cast<v4f *>(o), v4f{h[0], h[1], h[2], h[3]});
-                        store_out(reinterpret_cast<v4f *>(o + 4), v4f{h[4], h[5], h[6], h[7]});
-                    } else {
-                        v4i hw;
+                        if (m >= p.M || !n_ok) continue;
+                        if constexpr (EPI == EPI_F32) {
+                            float h[8];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            hw[e] = (int)((unsigned)Elem<DT>::st(h[2 * e]) | ((unsigned)Elem<DT>::st(h[2 * e + 1]) << 16));
-                        store_out(reinterpret_cast<v4i *>(reinterpret_cast<unsigned short *>(p.out) + m * p.ldo + no), hw);
+                            for (int e = 0; e < 8; ++e) h[e] = silu ? act_silu_mul<DT>(gf[e], uf[e]) : act_quick_gelu<DT>(gf[e]);
+                            float *o = reinterpret_cast<float *>(p.out) + m * p.ldo + no;
+                            store_out(reinterpret_cast<v4f *>(o), v4f{h[0], h[1], h[2], h[3]});
+                            store_out(reinterpret_cast<v4f *>(o + 4), v4f{h[4], h[5], h[6], h[7]});
+                        } else {
+                            v4i hw;
+                            if (silu) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) hw[e] = (int)act_silu_mul_pk<DT>(gf[2 * e], gf[2 * e + 1], uf[2 * e], uf[2 * e + 1]);
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) hw[e] = (int)act_quick_gelu_pk<DT>(gf[2 * e], gf[2 * e + 1]);
+                            }
+                            store_out(reinterpret_cast<v4i *>(reinterpret_cast<unsigned short *>(p.out) + m * p.ldo + no), hw);
+                        }
                     }
                 }
-            }
+            };
+            if (silu_rt) { if (bias_rt) rows(std::true_type{}, std::true_type{}); else rows(std::true_type{}, std::false_type{}); }
+            else { if (bias_rt) rows(std::false_type{}, std::true_type{}); else rows(std::false_type{}, std::false_type{}); }
         }
         return;
     }

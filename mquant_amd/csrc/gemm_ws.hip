@@ -823,67 +823,76 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
     if constexpr (ACT) {
         if constexpr (EPI != EPI_I32 && WG == 0) {
             constexpr int DT = (EPI == EPI_F16) ? MQ_F16 : (EPI == EPI_BF16 ? MQ_BF16 : MQ_F32);
-            const bool silu = p.act == MQ_ACT_SILU_MUL;
-            const bool has_bias = p.bias != nullptr;
+            const bool silu_rt = p.act == MQ_ACT_SILU_MUL;
+            const bool bias_rt = p.bias != nullptr;
             constexpr int LPR_S = BN / 16;                                // lanes per row with half as many outputs
-            const int rpi = silu ? NT / LPR_S : RPI;
-            const int arow = silu ? tid / LPR_S : tid / LPR;
-            const int ob = (silu ? tid % LPR_S : tid % LPR) * 8;          // slab column of the (gate) operand; up: + BN / 2
+            const int rpi = silu_rt ? NT / LPR_S : RPI;
+            const int arow = silu_rt ? tid / LPR_S : tid / LPR;
+            const int ob = (silu_rt ? tid % LPR_S : tid % LPR) * 8;          // slab column of the (gate) operand; up: + BN / 2
             const long H = p.N >> 1;
-            const long no = silu ? (long)bn * (BN / 2) + ob : n0 + ob;    // output column
-            const bool n_ok = silu ? (no + 8 <= H) : (no + 8 <= p.N);
+            const long no = silu_rt ? (long)bn * (BN / 2) + ob : n0 + ob;    // output column
+            const bool n_ok = silu_rt ? (no + 8 <= H) : (no + 8 <= p.N);
             float sg[8], su[8], bg[8], bu[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 sg[e] = par_sw[ob + e];
                 bg[e] = par_bs[ob + e];
-                su[e] = silu ? par_sw[BN / 2 + ob + e] : 0.0f;
-                bu[e] = silu ? par_bs[BN / 2 + ob + e] : 0.0f;
+                su[e] = silu_rt ? par_sw[BN / 2 + ob + e] : 0.0f;
+                bu[e] = silu_rt ? par_bs[BN / 2 + ob + e] : 0.0f;
             }
+            auto rows = [&](auto silu_c, auto bias_c) {      // once per (activation, bias) combination: no uniform branch between two elements
+                constexpr bool silu = decltype(silu_c)::value, has_bias = decltype(bias_c)::value;
 #pragma unroll 1
-            for (int r0 = 0; r0 < BM; r0 += rpi) {
-                const int row = r0 + arow;
-                const long m = m0 + row;
-                if (row >= BM || m >= p.M || !n_ok) continue;
-                const v4i g0 = *reinterpret_cast<const v4i *>(smem + row * PITCH + ob * 4);
-                const v4i g1 = *reinterpret_cast<const v4i *>(smem + row * PITCH + ob * 4 + 16);
-                v4i u0 = g0, u1 = g1;
-                if (silu) {
-                    u0 = *reinterpret_cast<const v4i *>(smem + row * PITCH + (BN / 2 + ob) * 4);
-                    u1 = *reinterpret_cast<const v4i *>(smem + row * PITCH + (BN / 2 + ob) * 4 + 16);
-                }
-                const float sxe = (W_BITS == 4) ? par_sx[row] * 0.0625f : par_sx[row];
-                const int ag[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-                const int au[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
-                float h[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float g = (float)ag[e] * sxe;
-                    g = g * sg[e];
-                    if (has_bias) g = g + bg[e];
-                    g = Elem<DT>::rnd(g);                                 // the Linear's output, in the model's dtype
+                for (int r0 = 0; r0 < BM; r0 += rpi) {
+                    const int row = r0 + arow;
+                    const long m = m0 + row;
+                    if (row >= BM || m >= p.M || !n_ok) continue;
+                    const v4i g0 = *reinterpret_cast<const v4i *>(smem + row * PITCH + ob * 4);
+                    const v4i g1 = *reinterpret_cast<const v4i *>(smem + row * PITCH + ob * 4 + 16);
+                    v4i u0 = g0, u1 = g1;
                     if (silu) {
+                        u0 = *reinterpret_cast<const v4i *>(smem + row * PITCH + (BN / 2 + ob) * 4);
+                        u1 = *reinterpret_cast<const v4i *>(smem + row * PITCH + (BN / 2 + ob) * 4 + 16);
+                    }
+                    const float sxe = (W_BITS == 4) ? par_sx[row] * 0.0625f : par_sx[row];
+                    const int ag[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+                    const int au[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
+                    // the two Linear outputs in fp32 -- the plain launch's arithmetic, one rounding per operation -- then the activation
+                    float gf[8], uf[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float g = (float)ag[e] * sxe;
+                        g = g * sg[e];
+                        if (has_bias) g = g + bg[e];
+                        gf[e] = g;
                         float u = (float)au[e] * sxe;
                         u = u * su[e];
                         if (has_bias) u = u + bu[e];
-                        u = Elem<DT>::rnd(u);
-                        h[e] = act_silu_mul<DT>(g, u);
+                        uf[e] = u;
+                    }
+                
+                    if constexpr (EPI == EPI_F32) {
+                        float h[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) h[e] = silu ? act_silu_mul<DT>(gf[e], uf[e]) : act_quick_gelu<DT>(gf[e]);
+                        float *o = reinterpret_cast<float *>(p.out) + m * p.ldo + no;
+                        store_out(reinterpret_cast<v4f *>(o), v4f{h[0], h[1], h[2], h[3]});
+                        store_out(reinterpret_cast<v4f *>(o + 4), v4f{h[4], h[5], h[6], h[7]});
                     } else {
-                        h[e] = act_quick_gelu<DT>(g);
+                        v4i hw;
+                        if (silu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) hw[e] = (int)act_silu_mul_pk<DT>(gf[2 * e], gf[2 * e + 1], uf[2 * e], uf[2 * e + 1]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) hw[e] = (int)act_quick_gelu_pk<DT>(gf[2 * e], gf[2 * e + 1]);
+                        }
+                        store_out(reinterpret_cast<v4i *>(reinterpret_cast<unsigned short *>(p.out) + m * p.ldo + no), hw);
                     }
                 }
-                if (EPI == EPI_F32) {
-                    float *o = reinterpret_cast<float *>(p.out) + m * p.ldo + no;
-                    store_out(reinterpret_cast<v4f *>(o), v4f{h[0], h[1], h[2], h[3]});
-                    store_out(reinterpret_cast<v4f *>(o + 4), v4f{h[4], h[5], h[6], h[7]});
-                } else {
-                    v4i hw;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        hw[e] = (int)((unsigned)Elem<DT>::st(h[2 * e]) | ((unsigned)Elem<DT>::st(h[2 * e + 1]) << 16));
-                    store_out(reinterpret_cast<v4i *>(reinterpret_cast<unsigned short *>(p.out) + m * p.ldo + no), hw);
-                }
-            }
+            };
+            if (silu_rt) { if (bias_rt) rows(std::true_type{}, std::true_type{}); else rows(std::true_type{}, std::false_type{}); }
+            else { if (bias_rt) rows(std::false_type{}, std::true_type{}); else rows(std::false_type{}, std::false_type{}); }
         }
         return;
     }

@@ -300,19 +300,131 @@ __device__ __forceinline__ float exp_neg(float z)
 // DT tensors: fp32 arithmetic inside one op, one rounding to DT per op.
 enum { MQ_ACT_NONE = 0, MQ_ACT_SILU_MUL = 1, MQ_ACT_QUICK_GELU = 2 };
 
-template <int DT> __device__ __forceinline__ float act_silu_mul(float g, float u)
+// ---- the reference forms: the device library's expf and IEEE divisions (what torch's kernels execute) ----
+template <int DT> __device__ __forceinline__ float act_silu_ref(float g)
 {
     const float den = 1.0f + exp_neg(g);              // F.silu: x / (1 + exp(-x))
-    const float sl = Elem<DT>::rnd(g / den);
-    return Elem<DT>::rnd(sl * u);                      // silu(gate) * up
+    return Elem<DT>::rnd(g / den);
+}
+template <int DT> __device__ __forceinline__ float act_sigmoid_ref(float z)
+{
+    const float den = 1.0f + exp_neg(z);
+    return Elem<DT>::rnd(1.0f / den);
+}
+
+// ---- 16-bit dtypes: the same VALUES in half the instructions (round 6) ----
+// silu and sigmoid of a half-precision tensor are functions of 65 536 inputs, so ANY arithmetic that returns the reference's
+// rounded result on every one of them IS the reference: tests/test_gpu_act_exhaustive.py runs both forms over all 2^16 bit
+// patterns of fp16 and bf16 (mq_debug_act_table) and requires identical bits (NaNs: NaN for NaN).  What is cheaper here:
+//  * exp(-x): the library's own reduction (x log2(e) as a 49-bit product, 2^fraction by V_EXP_F32, V_LDEXP_F32) without its
+//    range selects -- the sum 1 + exp(-x) and the quotients below come out the same where it would have returned 0 or inf
+//    (bf16 reaches beyond fp32's exponent range: its argument is clamped to +-128 first);
+//  * x / den and 1 / den: V_RCP_F32 and one Newton step (the quotient's error stays far inside the half-precision rounding
+//    interval it lands in, on every input), V_DIV_FIXUP_F32 for den = inf -- 5 instructions for the 10 of the IEEE sequence.
+// ~14 vector-ALU instructions per element instead of ~25; fp32 tensors keep the reference forms.
+template <int DT> __device__ __forceinline__ float exp_neg_16(float v)
+{
+    float x = -v;
+    if (DT == MQ_BF16) x = __builtin_amdgcn_fmed3f(x, -128.0f, 128.0f);
+    const float c = 0x1.715476p+0f, cc = 0x1.4ae0bep-26f;
+    const float ph = x * c;
+    const float pl = __builtin_fmaf(x, cc, __builtin_fmaf(x, c, -ph));
+    const float e = __builtin_rintf(ph);
+    const float a = (ph - e) + pl;
+    return __builtin_ldexpf(__builtin_amdgcn_exp2f(a), (int)e);
+}
+template <int DT> __device__ __forceinline__ float silu_raw_16(float g)        // g: a DT value; the fp32 quotient BEFORE its rounding to DT
+{
+    const float den = 1.0f + exp_neg_16<DT>(g);
+    const float r = __builtin_amdgcn_rcpf(den);
+    float q = g * r;
+    q = __builtin_fmaf(__builtin_fmaf(-q, den, g), r, q);
+    return __builtin_amdgcn_div_fixupf(q, den, g);
+}
+template <int DT> __device__ __forceinline__ float sigmoid_raw_16(float z)
+{
+    const float den = 1.0f + exp_neg_16<DT>(z);
+    float r = __builtin_amdgcn_rcpf(den);
+    r = __builtin_fmaf(__builtin_fmaf(-den, r, 1.0f), r, r);
+    return __builtin_amdgcn_div_fixupf(r, den, 1.0f);
+}
+template <int DT> __device__ __forceinline__ float act_silu_16(float g) { return Elem<DT>::rnd(silu_raw_16<DT>(g)); }
+template <int DT> __device__ __forceinline__ float act_sigmoid_16(float z) { return Elem<DT>::rnd(sigmoid_raw_16<DT>(z)); }
+template <int DT> __device__ __forceinline__ float act_silu(float g)
+{
+    if constexpr (DT == MQ_F32) return act_silu_ref<DT>(g);
+    else return act_silu_16<DT>(g);
+}
+template <int DT> __device__ __forceinline__ float act_sigmoid(float z)
+{
+    if constexpr (DT == MQ_F32) return act_sigmoid_ref<DT>(z);
+    else return act_sigmoid_16<DT>(z);
+}
+
+template <int DT> __device__ __forceinline__ float act_silu_mul(float g, float u)
+{
+    return Elem<DT>::rnd(act_silu<DT>(g) * u);          // silu(gate) * up
 }
 
 template <int DT> __device__ __forceinline__ float act_quick_gelu(float x)
 {
     const float z = Elem<DT>::rnd(1.702f * x);         // QuickGELUActivation: x * sigmoid(1.702 x)
-    const float den = 1.0f + exp_neg(z);
-    const float sg = Elem<DT>::rnd(1.0f / den);
-    return Elem<DT>::rnd(x * sg);
+    return Elem<DT>::rnd(x * act_sigmoid<DT>(z));
+}
+
+// Two outputs at once from the fp32 values of two Linear outputs each (the producer GEMM's act epilogues): the roundings of the
+// scalar forms above with the packed converts (V_CVT_PK_F16_F32 / V_CVT_PK_BF16_F32) and, for fp16, V_PK_MUL_F16 for the last product
+// -- a product of two halves is exact in fp32, so its rounding to half IS the correctly rounded half product.  Returns the two
+// results packed in one dword (low half = first); fp32: two floats through `out`.
+template <int DT> __device__ __forceinline__ unsigned act_silu_mul_pk(float g0, float g1, float u0, float u1)
+{
+    static_assert(DT == MQ_F16 || DT == MQ_BF16, "packed forms are for the 16-bit dtypes");
+    if constexpr (DT == MQ_F16) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const unsigned gp = pack2_f16(g0, g1), up = pack2_f16(u0, u1);        // the two Linear outputs, rounded to the model's dtype
+        h2 gh, uh;
+        __builtin_memcpy(&gh, &gp, 4);
+        __builtin_memcpy(&uh, &up, 4);
+        const unsigned sp = pack2_f16(silu_raw_16<DT>((float)gh[0]), silu_raw_16<DT>((float)gh[1]));
+        h2 sh;
+        __builtin_memcpy(&sh, &sp, 4);
+        const h2 r = sh * uh;
+        unsigned out;
+        __builtin_memcpy(&out, &r, 4);
+        return out;
+    } else {
+        const unsigned gp = pack2_bf16(g0, g1), up = pack2_bf16(u0, u1);
+        const float ga = __uint_as_float(gp << 16), gb = __uint_as_float(gp & 0xffff0000u);
+        const float ua = __uint_as_float(up << 16), ub = __uint_as_float(up & 0xffff0000u);
+        return pack2_bf16(act_silu_16<DT>(ga) * ua, act_silu_16<DT>(gb) * ub);
+    }
+}
+template <int DT> __device__ __forceinline__ unsigned act_quick_gelu_pk(float x0, float x1)
+{
+    static_assert(DT == MQ_F16 || DT == MQ_BF16, "packed forms are for the 16-bit dtypes");
+    if constexpr (DT == MQ_F16) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const unsigned xp = pack2_f16(x0, x1);
+        h2 xh;
+        __builtin_memcpy(&xh, &xp, 4);
+        const float xa = (float)xh[0], xb = (float)xh[1];
+        const unsigned zp = pack2_f16(1.702f * xa, 1.702f * xb);
+        h2 zh;
+        __builtin_memcpy(&zh, &zp, 4);
+        const unsigned sp = pack2_f16(sigmoid_raw_16<DT>((float)zh[0]), sigmoid_raw_16<DT>((float)zh[1]));
+        h2 sh;
+        __builtin_memcpy(&sh, &sp, 4);
+        const h2 r = xh * sh;
+        unsigned out;
+        __builtin_memcpy(&out, &r, 4);
+        return out;
+    } else {
+        const unsigned xp = pack2_bf16(x0, x1);
+        const float xa = __uint_as_float(xp << 16), xb = __uint_as_float(xp & 0xffff0000u);
+        const unsigned zp = pack2_bf16(1.702f * xa, 1.702f * xb);
+        const float za = __uint_as_float(zp << 16), zb = __uint_as_float(zp & 0xffff0000u);
+        return pack2_bf16(xa * act_sigmoid_16<DT>(za), xb * act_sigmoid_16<DT>(zb));
+    }
 }
 
 __host__ __device__ inline long ceil_div(long a, long b) { return (a + b - 1) / b; }
