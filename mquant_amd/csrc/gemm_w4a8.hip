@@ -544,8 +544,16 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
         static const int cand[][3] = {{43, 64, 128}, {40, 96, 128}, {41, 128, 128}, {42, 192, 128}};
         constexpr int WS192 = 42;
 #else
+        // round 6: ids 53 / 54 / 51 / 52 = the same kernels with the slab-free epilogue (gemm_ws.hip DIRECT: -0.6 ... -1.5 us per launch,
+        // profiles/r6_ws_direct_epilogue_ab.txt); launches it does not cover (split-K, RoPE, int32 / fp32 outputs ...) fall back to the
+        // slab twin inside dispatch_ws.  -DMQ_PLAN_WS_SLAB restores ids 47 / 48 / 45 / 46
+#ifdef MQ_PLAN_WS_SLAB
         static const int cand[][3] = {{47, 64, 128}, {48, 96, 128}, {45, 128, 128}, {46, 192, 128}};
         constexpr int WS192 = 46;
+#else
+        static const int cand[][3] = {{53, 64, 128}, {54, 96, 128}, {51, 128, 128}, {52, 192, 128}};
+        constexpr int WS192 = 52;
+#endif
 #endif
         for (const auto &c : cand) {
             if (c[0] == WS192 && !w4) continue;
@@ -599,8 +607,10 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
             const float t_192 = rounds(ceil_div(M, 192) * ceil_div(N, 128)) * (7.8f + 0.55f * (float)kps);
 #ifdef MQ_PLAN_WS_32X32
             if (t_192 < t_pipe) pl.tile = 42;
-#else
+#elif defined(MQ_PLAN_WS_SLAB)
             if (t_192 < t_pipe) pl.tile = 46;
+#else
+            if (t_192 < t_pipe) pl.tile = 52;
 #endif
         }
     } else if (a_tiled && best >= 0 && ceil_div(M, 96) * ceil_div(N, 128) >= 128) {

@@ -42,10 +42,16 @@ namespace mq {
 #define MQ_WS_WG_ABL 0   // timing-only ablations of the group fold (wrong results): 4 no fold intervals (every interval plain), 8 no scale DMAs
 #endif
 
-template <int BM, int BN, int MW_M, int MW_N, int NL, int S, int W_BITS, int EPI, int MF = 0, int WG = 0, bool ACT = false>
+template <int BM, int BN, int MW_M, int MW_N, int NL, int S, int W_BITS, int EPI, int MF = 0, int WG = 0, bool ACT = false, bool DIRECT = false>
 __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmArgs p)
 {
     // ACT: the instantiation with the consumer's activation in the store (GemmArgs::act; dispatch_ws_act)
+    // DIRECT (round 6, ids 50-54): the plain 16-bit epilogue WITHOUT the LDS slab -- every math wave dequantises its own accumulators in
+    // the MFMA D layout (a lane holds 4 consecutive channels of one row per 16 x 16 tile), packs them to 16 bits, V_PERMLANE16_SWAP
+    // pairs the quads of two adjacent channel tiles so that a lane owns 8 consecutive channels, and stores 16 bytes: no barrier and no
+    // LDS round trip behind the k-loop (the slab path: two barriers, park, re-read -- 1.6-4 us of every launch,
+    // profiles/r5_ws_fixed_cost_timeline.txt).  Per-channel / per-row parameters wait in registers from before the k-loop.
+    static_assert(!DIRECT || (MF == 1 && WG == 0 && !ACT && (EPI == EPI_F16 || EPI == EPI_BF16) && (BN / MW_N / 16) % 2 == 0), "direct epilogue: 16x16x64 tiles, 16-bit output, channel-tile pairs");
     static_assert(WG == 0 || MF == 1, "the weight-group fold lives in the 16x16x64 math loop");
     // Math waves: MW_M x MW_N wave tiles of (BM / MW_M) x (BN / MW_N), one or two per SIMD.  (A second group of
     // math waves working the K = 32 sub-steps of the other parity, and wide 96 x 64 / 64 x 64 wave tiles, were
@@ -297,6 +303,7 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
             }
         }
         __builtin_amdgcn_s_setprio(0);
+        if constexpr (DIRECT) return;                // (no slab epilogue to take part in)
 #ifdef MQ_WS_TL
         if (tl && tid == NM * 64) {
             tl[4] = tl_req;
@@ -313,7 +320,7 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
         // so B(0) does not wait for these cold misses), selected and parked in LDS after the loop.
         float pr_sw = 0.0f, pr_bs = 0.0f, pr_wz = 0.0f, pr_sx = 0.0f, pr_xz = 0.0f, pr_w1 = 0.0f, pr_x1 = 0.0f;
         unsigned pr_rs = 0;
-        if (EPI != EPI_I32) {
+        if (EPI != EPI_I32 && !DIRECT) {
             const int tn = tid < BN ? tid : BN - 1, tm = tid < BM ? tid : BM - 1;
             long nc = n0 + tn < p.N ? n0 + tn : p.N - 1;
             if (ACT && p.act == MQ_ACT_SILU_MUL) {              // slab column tn: gate channel (first half) or the same up channel (second half)
@@ -332,6 +339,39 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
             pr_x1 = (p.x1 ? p.x1 : dm)[p.x1 ? mc : 0];
             pr_rs = (p.row_sel ? p.row_sel : reinterpret_cast<const uint8_t *>(dm))[p.row_sel ? mc : 0];
         }
+        // DIRECT: this lane's parameters in the D layout -- 4 consecutive channels per 16-channel tile (weight scale, bias, split-column
+        // factor), one row per 16-row tile (activation scale, split-column value) -- requested here, consumed behind the k-loop
+        constexpr int DN = DIRECT ? BN / MW_N / 16 : 1, DM = DIRECT ? BM / MW_M / 16 : 1;
+        // (the 192 x 128 tile has no registers to spare for bias / split-column parameters during the k-loop: it fetches those behind it)
+        constexpr bool D_EARLY = BM * BN < 192 * 128;
+        v4f d_sw[DN], d_bs[DN], d_wz[DN];
+        float d_sx[DM], d_xz[DM];
+        auto direct_params = [&](bool scales, bool terms) {
+            const float *bsp = p.bias ? p.bias : p.s_w, *wzp = p.w0 ? p.w0 : p.s_w;
+#pragma unroll
+            for (int i = 0; i < DN; ++i) {
+                long nq = n0 + (wn * DN + i) * 16 + (lane >> 4) * 4;
+                if (nq + 4 > p.N) nq = 0;                    // (N % 8 == 0, host-checked: a quad is inside or outside)
+                if (scales) d_sw[i] = *reinterpret_cast<const v4f *>(p.s_w + nq);
+                if (terms) {
+                    d_bs[i] = *reinterpret_cast<const v4f *>(bsp + nq);
+                    d_wz[i] = *reinterpret_cast<const v4f *>(wzp + nq);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < DM; ++j) {
+                long mr = m0 + (wm * DM + j) * 16 + (lane & 15);
+                if (mr >= p.M) mr = p.M - 1;
+                if (scales) {
+                    float sx = p.sx0;
+                    if (p.sx_vec) sx = p.sx_vec[mr];
+                    else if (p.row_sel && p.row_sel[mr]) sx = p.sx1;
+                    d_sx[j] = (W_BITS == 4) ? sx * 0.0625f : sx;       // (int4 levels sit in the high nibble: exact power-of-two rescale)
+                }
+                if (terms) d_xz[j] = p.x0 ? p.x0[mr] : 0.0f;
+            }
+        };
+        if constexpr (DIRECT) direct_params(true, D_EARLY);
         if constexpr (MF == 1) {
             // ---- V_MFMA_I32_16X16X64_I8: one interval per 64-wide k-tile t (two per stage, so every register-set index below
             // is a compile-time parity):   X[(t+1)&1] <- activations (t+1)   |  F[t&1] <- packed weights (t+2)
@@ -622,6 +662,89 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
                     }
             }
             MQ_TL(0, 7);                             // k-loop done
+            if constexpr (DIRECT) {
+                const bool has_bias = p.bias != nullptr, has_x0 = p.x0 != nullptr, has_res = p.residual != nullptr;
+                if constexpr (!D_EARLY) direct_params(false, true);
+                const int g = lane >> 4;
+                unsigned short *outp = reinterpret_cast<unsigned short *>(p.out);
+                // residual (hidden + linear(x), torch rounds the Linear's output first): the 16 bytes this lane will store over, all
+                // requested up front
+                v4i res[TM16][TN16 / 2];
+                if (has_res) {
+                    const unsigned short *rp = reinterpret_cast<const unsigned short *>(p.residual);
+#pragma unroll
+                    for (int j = 0; j < TM16; ++j)
+#pragma unroll
+                        for (int ip = 0; ip < TN16 / 2; ++ip) {
+                            long m = m0 + (wm * TM16 + j) * 16 + (lane & 15);
+                            long n = n0 + (wn * TN16 + 2 * ip + (g & 1)) * 16 + (g >> 1) * 8;
+                            if (m >= p.M) m = p.M - 1;
+                            if (n + 8 > p.N) n = 0;
+                            res[j][ip] = *reinterpret_cast<const v4i *>(rp + m * p.ldr + n);
+                        }
+                }
+#pragma unroll
+                for (int j = 0; j < TM16; ++j) {
+                    const long m = m0 + (wm * TM16 + j) * 16 + (lane & 15);
+                    const v2f_t sx2 = v2f_t{d_sx[j], d_sx[j]}, xz2 = v2f_t{d_xz[j], d_xz[j]};
+#pragma unroll
+                    for (int ip = 0; ip < TN16 / 2; ++ip) {
+                        unsigned pk[2][2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int i = 2 * ip + h;
+                            const v4i a = acc16[i][j];
+                            v2f_t v0 = v2f_t{(float)a[0], (float)a[1]}, v1 = v2f_t{(float)a[2], (float)a[3]};
+                            v0 = v0 * sx2;
+                            v1 = v1 * sx2;
+                            v0 = v0 * v2f_t{d_sw[i][0], d_sw[i][1]};
+                            v1 = v1 * v2f_t{d_sw[i][2], d_sw[i][3]};
+                            if (has_bias) {
+                                v0 = v0 + v2f_t{d_bs[i][0], d_bs[i][1]};
+                                v1 = v1 + v2f_t{d_bs[i][2], d_bs[i][3]};
+                            }
+                            if (has_x0) {
+                                const v2f_t p0 = xz2 * v2f_t{d_wz[i][0], d_wz[i][1]}, p1 = xz2 * v2f_t{d_wz[i][2], d_wz[i][3]};
+                                v0 = v0 + p0;
+                                v1 = v1 + p1;
+                            }
+                            pk[h][0] = (EPI == EPI_F16) ? pack2_f16(v0[0], v0[1]) : pack2_bf16(v0[0], v0[1]);
+                            pk[h][1] = (EPI == EPI_F16) ? pack2_f16(v1[0], v1[1]) : pack2_bf16(v1[0], v1[1]);
+                        }
+                        // odd rows of 16 lanes of tile i0's words <-> even rows of tile i1's: afterwards a lane holds 8 consecutive
+                        // channels -- lane rows 0 / 2: channels 0..7 / 8..15 of tile i0, rows 1 / 3: the same of tile i1
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                        v4i y = v4i{(int)s0[0], (int)s1[0], (int)s0[1], (int)s1[1]};
+                        if (has_res) {
+                            // cast(cast(y) + residual): the fp32 sum of two halves is exact unless one is below 2^-13 of the other, and then
+                            // both forms return the larger one -- V_PK_ADD_F16 gives the same bits (as in the RoPE store); bf16 adds in fp32
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if constexpr (EPI == EPI_F16) {
+                                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                                    h2 ya, rb;
+                                    const int yi = y[e], ri = res[j][ip][e];
+                                    __builtin_memcpy(&ya, &yi, 4);
+                                    __builtin_memcpy(&rb, &ri, 4);
+                                    const h2 sum = ya + rb;
+                                    int si;
+                                    __builtin_memcpy(&si, &sum, 4);
+                                    y[e] = si;
+                                } else {
+                                    const unsigned yu = (unsigned)y[e], ru = (unsigned)res[j][ip][e];
+                                    const float lo = __uint_as_float(yu << 16) + __uint_as_float(ru << 16);
+                                    const float hi = __uint_as_float(yu & 0xffff0000u) + __uint_as_float(ru & 0xffff0000u);
+                                    y[e] = (int)pack2_bf16(lo, hi);
+                                }
+                            }
+                        }
+                        const long n = n0 + (wn * TN16 + 2 * ip + (g & 1)) * 16 + (g >> 1) * 8;
+                        if (m < p.M && n + 8 <= p.N) store_out(reinterpret_cast<v4i *>(outp + m * p.ldo + n), y);
+                    }
+                }
+                return;
+            }
         } else {
 #pragma unroll
         for (int a = 0; a < NACC; ++a)
@@ -1134,14 +1257,14 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
     }
 }
 
-template <int BM, int BN, int MW_M, int MW_N, int NL, int S, int W_BITS, int EPI, int MF = 0, int WG = 0, bool ACT = false>
+template <int BM, int BN, int MW_M, int MW_N, int NL, int S, int W_BITS, int EPI, int MF = 0, int WG = 0, bool ACT = false, bool DIRECT = false>
 static int launch_ws(const GemmArgs &p, hipStream_t st)
 {
     constexpr int PIECES = (BM / 16) * 2 + ((W_BITS == 4) ? (BN / 32) * 2 : (BN / 16) * 2);
     constexpr int RING = S * (PIECES + ((WG && !(MQ_WS_WG_ABL & 8)) ? 3 : 0)) * 1024, SLAB = BM * (BN * 4 + 16);   // (WG: three 1 KiB scale blocks per stage)
     constexpr int SMEM = (RING > SLAB ? RING : SLAB) + (4 * BN + 3 * BM) * 4;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
-    auto kern = gemm_ws_kernel<BM, BN, MW_M, MW_N, NL, S, W_BITS, EPI, MF, WG, ACT>;
+    auto kern = gemm_ws_kernel<BM, BN, MW_M, MW_N, NL, S, W_BITS, EPI, MF, WG, ACT, DIRECT>;
     int rc = ensure_dynamic_lds((const void *)kern, SMEM);
     if (rc != MQ_OK) return rc;
     GemmArgs g = p;
@@ -1159,13 +1282,13 @@ static int dispatch_ws_act(const GemmArgs &p, int tile, hipStream_t st)
         return fail(MQ_EINVAL, "gemm_ws: an activation needs a floating-point output");
     } else {
         switch (tile) {
-        case 40: case 44: return launch_ws<96, 128, 1, 4, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI, 1, 0, true>(p, st);
-        case 41: case 45: return launch_ws<128, 128, 2, 4, 4, (W_BITS == 4 ? 6 : 4), W_BITS, EPI, 1, 0, true>(p, st);
-        case 42: case 46:
+        case 40: case 44: case 50: return launch_ws<96, 128, 1, 4, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI, 1, 0, true>(p, st);
+        case 41: case 45: case 51: return launch_ws<128, 128, 2, 4, 4, (W_BITS == 4 ? 6 : 4), W_BITS, EPI, 1, 0, true>(p, st);
+        case 42: case 46: case 52:
             if constexpr (W_BITS == 4) return launch_ws<192, 128, 2, 4, 4, 4, W_BITS, EPI, 1, 0, true>(p, st);
             else break;
-        case 43: case 47: return launch_ws<64, 128, 1, 4, 4, (W_BITS == 4 ? 8 : 6), W_BITS, EPI, 1, 0, true>(p, st);
-        case 48: return launch_ws<96, 128, 2, 4, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI, 1, 0, true>(p, st);
+        case 43: case 47: case 53: return launch_ws<64, 128, 1, 4, 4, (W_BITS == 4 ? 8 : 6), W_BITS, EPI, 1, 0, true>(p, st);
+        case 48: case 54: return launch_ws<96, 128, 2, 4, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI, 1, 0, true>(p, st);
         default: break;
         }
         return fail(MQ_EINVAL, "gemm_ws: tile %d has no activation epilogue", tile);
@@ -1193,6 +1316,25 @@ int dispatch_ws(const GemmArgs &p, int tile, hipStream_t st)
     case 47: return launch_ws<64, 128, 1, 4, 4, (W_BITS == 4 ? 8 : 6), W_BITS, EPI, 1>(p, st);
     // 96 x 128 with TWO math waves per SIMD (48 x 32 per wave): the 16x16x64 form issues at full rate from two waves
     case 48: return launch_ws<96, 128, 2, 4, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI, 1>(p, st);
+    // ids 50-54: the 16x16x64 tiles 44-48 with the DIRECT epilogue (no LDS slab; see the kernel's head).  Plain 16-bit launches only
+    // (no split-K, residual, second rank-1 term, RoPE; aligned parameters, N % 8 == 0): anything else takes the slab twin.
+    case 50: case 51: case 52: case 53: case 54: {
+        const bool direct_ok = (EPI == EPI_F16 || EPI == EPI_BF16) && p.splits == 1 && (!p.residual || p.res_vec) && !p.x1 && !p.rope_cos && p.vec_ok
+                               && p.par_ok && ((uintptr_t)p.s_w) % 16 == 0;
+        if (!direct_ok) return dispatch_ws<W_BITS, EPI>(p, tile - 6, st);
+        if constexpr (EPI == EPI_F16 || EPI == EPI_BF16) {
+            switch (tile) {
+            case 50: return launch_ws<96, 128, 1, 4, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI, 1, 0, false, true>(p, st);
+            case 51: return launch_ws<128, 128, 2, 4, 4, (W_BITS == 4 ? 6 : 4), W_BITS, EPI, 1, 0, false, true>(p, st);
+            case 52:
+                if constexpr (W_BITS == 4) return launch_ws<192, 128, 2, 4, 4, 4, W_BITS, EPI, 1, 0, false, true>(p, st);
+                else return dispatch_ws<W_BITS, EPI>(p, 45, st);
+            case 53: return launch_ws<64, 128, 1, 4, 4, (W_BITS == 4 ? 8 : 6), W_BITS, EPI, 1, 0, false, true>(p, st);
+            default: return launch_ws<96, 128, 2, 4, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI, 1, 0, false, true>(p, st);
+            }
+        }
+        break;
+    }
     // (a 32 x 128 tile -- 320 workgroups for the ViT's 1024 x 1280 outputs instead of 160, two per CU -- was measured in round 5
     //  and is not faster: proj 9.68 against 9.73 us, fc2 14.8 against 13.4, profiles/r5_ws_tile_32x128.txt; not instantiated)
     default: break;
@@ -1205,6 +1347,7 @@ int dispatch_ws(const GemmArgs &p, int tile, hipStream_t st)
 template <int W_BITS, int EPI, int WGM>
 static int dispatch_ws_group_mode(const GemmArgs &p, int tile, hipStream_t st)
 {
+    if (tile >= 50 && tile <= 54) tile -= 6;          // (the slab-free ids: their 16x16x64 twins carry the group fold)
     if (tile == 46) {
         // 192 x 128: twelve waves at <= 168 registers each cannot hold the extra fp32 accumulators (136 bytes of scratch).  Its shapes take
         // 128 x 128 or 96 x 128, whichever needs fewer row-rounds (gate|up: 7 x 128 against 10 x 96, measured 14-20 % ahead; ViT fc1:

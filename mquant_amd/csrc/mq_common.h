@@ -317,15 +317,16 @@ template <int DT> __device__ __forceinline__ float act_sigmoid_ref(float z)
 // rounded result on every one of them IS the reference: tests/test_gpu_act_exhaustive.py runs both forms over all 2^16 bit
 // patterns of fp16 and bf16 (mq_debug_act_table) and requires identical bits (NaNs: NaN for NaN).  What is cheaper here:
 //  * exp(-x): the library's own reduction (x log2(e) as a 49-bit product, 2^fraction by V_EXP_F32, V_LDEXP_F32) without its
-//    range selects -- the sum 1 + exp(-x) and the quotients below come out the same where it would have returned 0 or inf
-//    (bf16 reaches beyond fp32's exponent range: its argument is clamped to +-128 first);
+//    range selects -- the argument is clamped to +-128 instead (one V_MED3_F32): the sum 1 + exp(-x) and the quotients below come
+//    out the same where the library would have returned 0 or inf;
 //  * x / den and 1 / den: V_RCP_F32 and one Newton step (the quotient's error stays far inside the half-precision rounding
 //    interval it lands in, on every input), V_DIV_FIXUP_F32 for den = inf -- 5 instructions for the 10 of the IEEE sequence.
 // ~14 vector-ALU instructions per element instead of ~25; fp32 tensors keep the reference forms.
 template <int DT> __device__ __forceinline__ float exp_neg_16(float v)
 {
-    float x = -v;
-    if (DT == MQ_BF16) x = __builtin_amdgcn_fmed3f(x, -128.0f, 128.0f);
+    // (+-inf and bf16's values beyond fp32's exponent range: the reduction below would form inf - inf; 2^-128 and 2^128 give the same
+    //  sums 1 + exp(-x) and quotients as the library's 0 and inf)
+    const float x = __builtin_amdgcn_fmed3f(-v, -128.0f, 128.0f);
     const float c = 0x1.715476p+0f, cc = 0x1.4ae0bep-26f;
     const float ph = x * c;
     const float pl = __builtin_fmaf(x, cc, __builtin_fmaf(x, c, -ph));
@@ -339,14 +340,20 @@ template <int DT> __device__ __forceinline__ float silu_raw_16(float g)        /
     const float r = __builtin_amdgcn_rcpf(den);
     float q = g * r;
     q = __builtin_fmaf(__builtin_fmaf(-q, den, g), r, q);
-    return __builtin_amdgcn_div_fixupf(q, den, g);
+    q = __builtin_amdgcn_div_fixupf(q, den, g);      // den = inf, g = +-inf, NaN: the division's own special cases
+    // V_RCP_F32 flushes a denormal reciprocal to 0 (den > 2^126, g below -87): fp16 rounds those quotients to -0 anyway, bf16 has the
+    // exponent range to represent them -- there (never, on real activations) the IEEE sequence runs
+    if (DT == MQ_BF16 && __builtin_expect(den > 0x1p+125f, 0)) q = g / den;
+    return q;
 }
 template <int DT> __device__ __forceinline__ float sigmoid_raw_16(float z)
 {
     const float den = 1.0f + exp_neg_16<DT>(z);
     float r = __builtin_amdgcn_rcpf(den);
     r = __builtin_fmaf(__builtin_fmaf(-den, r, 1.0f), r, r);
-    return __builtin_amdgcn_div_fixupf(r, den, 1.0f);
+    r = __builtin_amdgcn_div_fixupf(r, den, 1.0f);
+    if (DT == MQ_BF16 && __builtin_expect(den > 0x1p+125f, 0)) r = 1.0f / den;
+    return (z != z) ? z : r;                          // (the clamp in exp_neg_16 swallows a NaN argument; silu's numerator carries it)
 }
 template <int DT> __device__ __forceinline__ float act_silu_16(float g) { return Elem<DT>::rnd(silu_raw_16<DT>(g)); }
 template <int DT> __device__ __forceinline__ float act_sigmoid_16(float z) { return Elem<DT>::rnd(sigmoid_raw_16<DT>(z)); }

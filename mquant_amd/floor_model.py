@@ -35,6 +35,7 @@ TILE_SHAPES: Dict[int, Tuple[int, int]] = {
     13: (256, 256), 14: (256, 256), 15: (128, 128), 16: (96, 128), 17: (192, 128), 18: (64, 128), 19: (128, 256),
     26: (128, 128), 31: (96, 128), 35: (192, 128),
     40: (96, 128), 41: (128, 128), 42: (192, 128), 43: (64, 128), 44: (96, 128), 45: (128, 128), 46: (192, 128), 47: (64, 128), 48: (96, 128),
+    50: (96, 128), 51: (128, 128), 52: (192, 128), 53: (64, 128), 54: (96, 128),
 }
 
 GAP_US = 1.23

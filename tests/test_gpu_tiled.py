@@ -15,8 +15,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 DTYPES = [torch.float16, torch.bfloat16, torch.float32]
 MODE = {torch.float16: 1, torch.bfloat16: 2, torch.float32: 0}
-WS_TILES = (40, 41, 42, 43, 44, 45, 46, 47, 48)     # 44-47: the same tiles with V_MFMA_I32_16X16X64_I8 in the math waves (round 5)
-W4_ONLY = (42, 46)
+WS_TILES = (40, 41, 42, 43, 44, 45, 46, 47, 48, 50, 51, 52, 53, 54)     # 44-48: V_MFMA_I32_16X16X64_I8 in the math waves (round 5); 50-54: those with the slab-free epilogue (round 6)
+W4_ONLY = (42, 46, 52)
 
 
 def ops():
@@ -373,7 +373,7 @@ def test_every_m_grouping_of_the_xcd_mapping_is_a_bijection(M, N, K):
     img = o.prepack(to_dev(w), 4)
     o.splitk_workspace(torch.device(DEV), 64 << 20)
     try:
-        for tile in (40, 41, 42, 43, 44, 45, 46, 47, 48, 3, 1, 14, 15, 16, 17, 18, 19):
+        for tile in (40, 41, 42, 43, 44, 45, 46, 47, 48, 50, 51, 52, 53, 54, 3, 1, 14, 15, 16, 17, 18, 19):
             for xm in (1, 2, 3, 4, 6, 8):
                 for splits in (1, 2):
                     o.gemm_debug_force(tile, splits | (xm << 8))
@@ -459,7 +459,7 @@ def test_persistent_ping_pong_tiles_walk_past_the_cu_count_into_ragged_tail_tile
 
 
 @pytest.mark.parametrize("out_dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("tile", [14, 13, 3, 26, 40, 44, 45, 46, 47, 48])
+@pytest.mark.parametrize("tile", [14, 13, 3, 26, 40, 44, 45, 46, 47, 48, 51, 52, 53, 54])
 def test_epilogue_overflow_infinity_and_nan_equal_the_oracles_rounding(out_dtype, tile):
     """The straight-line epilogues convert with V_CVT_PK_F16_F32 / V_CVT_PK_BF16_F32 (pack2_f16 / pack2_bf16) where the
     general loop uses the bit-trick conversions: both must agree with the oracle's round-to-nearest-even on results beyond the
