@@ -112,6 +112,7 @@ inline unsigned pick_m_groups(unsigned m_blocks, double w_bytes, double a_bytes)
 }
 
 extern thread_local int g_gemm_force_xm;   // test hook (mq_gemm_debug_force, bits 8.. of `splits`); 0 = automatic
+extern thread_local int g_pp_act_slab;     // test hook (bit 16 of `splits`): the slab form of the ping-pong activation epilogue
 
 inline void set_geometry(GemmArgs &p, int BM, int BN, int k_unit, int w_bits)
 {

@@ -517,7 +517,9 @@ static int launch_gemm(const GemmArgs &p, hipStream_t st)
 //   * everything else is latency bound (~8 us floor per launch + ~0.3 us per k-step): 64x128
 //     tiles put two or three workgroups on every CU and measured 10-30 % faster than 128x128.
 #ifndef MQ_PLAN_WIDE_TILE
-#define MQ_PLAN_WIDE_TILE 14   // A/B builds: -DMQ_PLAN_WIDE_TILE=13 (the software-pipelined kernel of rounds 1-3)
+#define MQ_PLAN_WIDE_TILE 20   // the ping-pong 256 x 256 tile with the slab-free epilogue and the next tile's stages requested ahead (round 6: -2.4 % on
+                               // gate|up, profiles/r6_pp_direct_epilogue_ab.txt; launches it does not cover take tile 14 inside launch_gemm_pp).
+                               // A/B builds: -DMQ_PLAN_WIDE_TILE=14 (round 4/5), =13 (the software-pipelined kernel of rounds 1-3)
 #endif
 struct Plan {
     int tile;    // index into dispatch_tile
@@ -631,7 +633,7 @@ static Plan make_plan(long M, long N, long K_pad, bool have_ws, size_t ws_bytes,
         if (s > 1) { pl.tile = 3; pl.splits = (int)s; }
     }
     if (force_tile >= 0 && (!ws_only || (force_tile >= 40 && force_tile < 60))
-        && (!act_mode || (force_tile >= 40 && force_tile < 60) || force_tile == 14 || force_tile == 19)) {
+        && (!act_mode || (force_tile >= 40 && force_tile < 60) || force_tile == 14 || force_tile == 19 || force_tile == 20)) {
         if ((pl.tile == 60 || pl.tile == 61) && force_tile != pl.tile) pl.splits = 1;   // (the slices were the skinny kernel's)
         pl.tile = force_tile;
     }
@@ -666,7 +668,7 @@ static int dispatch_tile(const GemmArgs &p, int tile, hipStream_t st)
     case 4: return launch_gemm<128, 256, 2, 4, 3, W_BITS, EPI>(p, st);
     case 5: return launch_gemm<256, 128, 2, 4, 3, W_BITS, EPI>(p, st);
     case 13: if constexpr (W_BITS == 4) return launch_gemm_pipe<EPI>(p, st); else break;
-    case 14: case 15: case 16: case 17: case 18: case 19:
+    case 14: case 15: case 16: case 17: case 18: case 19: case 20:
         if constexpr (W_BITS == 4) {
             if (!p.a_tiled) return fail(MQ_EINVAL, "mq_gemm_w4a8: tile %d needs activations in the tiled layout (lda = MQ_LD_TILED)", tile);
             const int rc = launch_gemm_pp<EPI>(p, tile, st);
@@ -812,7 +814,7 @@ static int gemm_common(const int8_t *a, long lda, const void *w, int w_bits, lon
     }
     Plan pl = make_plan(M, N, K_pad, workspace != nullptr && !rope && act == MQ_ACT_NONE, workspace_bytes, g_force_tile,
                         workspace ? g_force_splits : 0, w_bits == 4, a_tiled, rope ? 1 : (act != MQ_ACT_NONE ? 2 : 0));
-    if (act != MQ_ACT_NONE && !(pl.tile >= 40 && pl.tile < 60) && pl.tile != 14 && pl.tile != 19) {
+    if (act != MQ_ACT_NONE && !(pl.tile >= 40 && pl.tile < 60) && pl.tile != 14 && pl.tile != 19 && pl.tile != 20) {
         // the activation epilogue exists in the 256-wide ping-pong tiles (a wave holds a gate pair AND its up pair) and in the
         // wave-specialised kernels: anything else the plan came up with takes the best wave-specialised tile
         pl.tile = make_plan(M, N, K_pad, false, 0, -1, 0, w_bits == 4, a_tiled, 1).tile;
@@ -1023,5 +1025,6 @@ extern "C" int mq_gemm_debug_force(int tile, int splits)
     mq::g_force_tile = tile;
     mq::g_force_splits = splits > 0 ? (splits & 0xff) : 0;
     mq::g_gemm_force_xm = splits > 0 ? (splits >> 8) & 0xff : 0;
+    mq::g_pp_act_slab = splits > 0 ? (splits >> 16) & 1 : 0;
     return MQ_OK;
 }

@@ -664,6 +664,7 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
             MQ_TL(0, 7);                             // k-loop done
             if constexpr (DIRECT) {
                 const bool has_bias = p.bias != nullptr, has_x0 = p.x0 != nullptr, has_res = p.residual != nullptr;
+                const bool gelu = p.act == MQ_ACT_QUICK_GELU;
                 if constexpr (!D_EARLY) direct_params(false, true);
                 const int g = lane >> 4;
                 unsigned short *outp = reinterpret_cast<unsigned short *>(p.out);
@@ -708,8 +709,14 @@ __global__ __launch_bounds__((MW_M * MW_N + NL) * 64) void gemm_ws_kernel(GemmAr
                                 v0 = v0 + p0;
                                 v1 = v1 + p1;
                             }
-                            pk[h][0] = (EPI == EPI_F16) ? pack2_f16(v0[0], v0[1]) : pack2_bf16(v0[0], v0[1]);
-                            pk[h][1] = (EPI == EPI_F16) ? pack2_f16(v1[0], v1[1]) : pack2_bf16(v1[0], v1[1]);
+                            if (gelu) {                  // GemmArgs::act == MQ_ACT_QUICK_GELU: the vision MLP's activation in fc1's store
+                                constexpr int DT = (EPI == EPI_F16) ? MQ_F16 : MQ_BF16;
+                                pk[h][0] = act_quick_gelu_pk<DT>(v0[0], v0[1]);
+                                pk[h][1] = act_quick_gelu_pk<DT>(v1[0], v1[1]);
+                            } else {
+                                pk[h][0] = (EPI == EPI_F16) ? pack2_f16(v0[0], v0[1]) : pack2_bf16(v0[0], v0[1]);
+                                pk[h][1] = (EPI == EPI_F16) ? pack2_f16(v1[0], v1[1]) : pack2_bf16(v1[0], v1[1]);
+                            }
                         }
                         // odd rows of 16 lanes of tile i0's words <-> even rows of tile i1's: afterwards a lane holds 8 consecutive
                         // channels -- lane rows 0 / 2: channels 0..7 / 8..15 of tile i0, rows 1 / 3: the same of tile i1
@@ -1298,7 +1305,10 @@ static int dispatch_ws_act(const GemmArgs &p, int tile, hipStream_t st)
 template <int W_BITS, int EPI>
 int dispatch_ws(const GemmArgs &p, int tile, hipStream_t st)
 {
-    if (p.act != MQ_ACT_NONE) return dispatch_ws_act<W_BITS, EPI>(p, tile, st);
+    // (QuickGELU is elementwise: the slab-free ids carry it themselves; silu(gate) * up needs the slab to bring the two halves together)
+    const bool direct_gelu = p.act == MQ_ACT_QUICK_GELU && tile >= 50 && tile <= 54 && (EPI == EPI_F16 || EPI == EPI_BF16) && p.vec_ok && p.par_ok
+                             && ((uintptr_t)p.s_w) % 16 == 0 && g_pp_act_slab == 0;
+    if (p.act != MQ_ACT_NONE && !direct_gelu) return dispatch_ws_act<W_BITS, EPI>(p, tile, st);
     switch (tile) {
     // one math wave per SIMD (1 x 4 wave tiles) or two (2 x 4), four loader waves
     case 40: return launch_ws<96, 128, 1, 4, 4, (W_BITS == 4 ? 7 : 5), W_BITS, EPI>(p, st);

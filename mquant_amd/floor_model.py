@@ -32,7 +32,7 @@ from typing import Dict, Iterable, List, Tuple
 #: tile id (csrc/gemm_w4a8.hip dispatch_tile / gemm_ws.hip dispatch_ws) -> (BM, BN)
 TILE_SHAPES: Dict[int, Tuple[int, int]] = {
     1: (256, 256), 2: (256, 128), 3: (256, 256), 4: (128, 256), 5: (256, 128), 10: (64, 128), 11: (128, 64), 12: (128, 128),
-    13: (256, 256), 14: (256, 256), 15: (128, 128), 16: (96, 128), 17: (192, 128), 18: (64, 128), 19: (128, 256),
+    13: (256, 256), 14: (256, 256), 15: (128, 128), 16: (96, 128), 17: (192, 128), 18: (64, 128), 19: (128, 256), 20: (256, 256),
     26: (128, 128), 31: (96, 128), 35: (192, 128),
     40: (96, 128), 41: (128, 128), 42: (192, 128), 43: (64, 128), 44: (96, 128), 45: (128, 128), 46: (192, 128), 47: (64, 128), 48: (96, 128),
     50: (96, 128), 51: (128, 128), 52: (192, 128), 53: (64, 128), 54: (96, 128),

@@ -5,7 +5,7 @@ import ctypes as C
 
 import pytest
 
-PIPE, WS64, WS96, WS128, WS192 = 14, 53, 54, 51, 52   # PIPE: the 256 x 256 tile (ping-pong kernel since round 4); WS*: the
+PIPE, WS64, WS96, WS128, WS192 = 20, 53, 54, 51, 52   # PIPE: the 256 x 256 tile (ping-pong kernel since round 4); WS*: the
 #                                                       wave-specialised tiles with V_MFMA_I32_16X16X64_I8 math waves (round 5) and the
 #                                                       slab-free epilogue (round 6; ids 47 / 48 / 45 / 46 are their slab twins)
 

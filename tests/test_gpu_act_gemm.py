@@ -58,13 +58,16 @@ def _torch_act_native(y, act, ops):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("act", [1, 2])
-@pytest.mark.parametrize("tile", [-1, 14, 19, 44, 45, 46, 47, 48, 41])
+@pytest.mark.parametrize("tile", [-1, 14, 20, 19, 44, 45, 46, 47, 48, 41, 51, 52, 53, 54, (20, "slab"), (53, "slab"), (52, "slab")])
 def test_act_store_equals_gemm_plus_torch_ops(dtype, act, tile):
+    # (tile, "slab"): the slab form of the activation epilogue where a slab-free one exists (ping-pong silu, wave-specialised gelu)
+    slab = isinstance(tile, tuple)
+    tile = tile[0] if slab else tile
     M, N, K = 300, 448, 384            # N / 2 = 224 = 7 x 32: ragged against every tile width; M ragged against every tile height
     ops, levels, s_w, b, a, img, sel, s0, s1 = _case(M, N, K, seed=tile + 3 * act)
     y = ops.gemm_w4a8(a, img, 4, N, s0, s_w, s_x1=s1, row_sel=sel, bias=b, out_dtype=dtype)
     want = _torch_act(y, act, ops)
-    ops.gemm_debug_force(tile, 0)
+    ops.gemm_debug_force(tile, (1 << 16) if slab else 0)
     try:
         got = ops.gemm_w4a8_act(a, img, 4, N, s0, s_w, act, s_x1=s1, row_sel=sel, bias=b, out_dtype=dtype)
     finally:

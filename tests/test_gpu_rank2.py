@@ -24,7 +24,7 @@ def dev(a, dtype=None):
     return t if dtype is None else t.to(dtype)
 
 
-@pytest.mark.parametrize("tile", [-1, 40, 41, 42, 43, 44, 45, 46, 47, 51, 53, 54, 14, 15, 3, 26, 10])
+@pytest.mark.parametrize("tile", [-1, 40, 41, 42, 43, 44, 45, 46, 47, 51, 53, 54, 14, 20, 15, 3, 26, 10])
 @pytest.mark.parametrize("rowscale", [False, True])
 def test_rank2_epilogue_equals_the_oracle_on_every_kernel_family(tile, rowscale):
     from mquant_amd import ops

@@ -254,7 +254,7 @@ def test_symmetric_kernels_accept_the_tiled_layout():
     img = o.prepack(to_dev(w), 4)
     o.splitk_workspace(torch.device(DEV), 64 << 20)
     try:
-        for tile in (1, 3, 13, 14, 15, 16, 17, 18, 19, 10, 26, 31, 35, 2):
+        for tile in (1, 3, 13, 14, 20, 15, 16, 17, 18, 19, 10, 26, 31, 35, 2):
             for splits in (1, 3):
                 o.gemm_debug_force(tile, splits)
                 np.testing.assert_array_equal(o.gemm_w4a8_i32(at, img, 4, N).cpu().numpy(), acc_ref,
@@ -337,7 +337,7 @@ def test_row_loop_of_the_resident_hadamard_workgroups(had_table, n_in, n, K, M):
         assert torch.equal(part, full[r0:r0 + 64]) and torch.equal(x0p, x0[r0:r0 + 64]), r0
 
 
-@pytest.mark.parametrize("M,N,K,tile", [(768, 24576, 256, 14), (700, 33000, 384, 14), (512, 40960, 128, 19)])
+@pytest.mark.parametrize("M,N,K,tile", [(768, 24576, 256, 14), (700, 33000, 384, 14), (700, 33000, 384, 20), (512, 40960, 128, 19)])
 def test_persistent_ping_pong_launch_with_more_tiles_than_cus(M, N, K, tile):
     """More work ids than CUs: the ping-pong kernel starts 256 workgroups that walk ids b, b + 256, ... (gemm_pp.hip); every
     accumulator and the dequantised output must equal the wave-specialised kernel's (one workgroup per tile)."""
@@ -373,7 +373,7 @@ def test_every_m_grouping_of_the_xcd_mapping_is_a_bijection(M, N, K):
     img = o.prepack(to_dev(w), 4)
     o.splitk_workspace(torch.device(DEV), 64 << 20)
     try:
-        for tile in (40, 41, 42, 43, 44, 45, 46, 47, 48, 50, 51, 52, 53, 54, 3, 1, 14, 15, 16, 17, 18, 19):
+        for tile in (40, 41, 42, 43, 44, 45, 46, 47, 48, 50, 51, 52, 53, 54, 3, 1, 14, 15, 16, 17, 18, 19, 20):
             for xm in (1, 2, 3, 4, 6, 8):
                 for splits in (1, 2):
                     o.gemm_debug_force(tile, splits | (xm << 8))
@@ -388,7 +388,7 @@ def test_random_shapes_tiles_and_epilogues_against_the_oracle():
     epilogue terms: int32 accumulators and the dequantised output bit for bit against the oracle."""
     o = ops()
     rng = np.random.default_rng(20261002)
-    tiles_w4 = list(WS_TILES) + [1, 3, 13, 14, 15, 16, 17, 18, 19, 2, 10, 26, 31, 35]
+    tiles_w4 = list(WS_TILES) + [1, 3, 13, 14, 15, 16, 17, 18, 19, 20, 2, 10, 26, 31, 35]
     tiles_w8 = [t for t in WS_TILES if t not in W4_ONLY] + [3, 2, 10, 26, 31]
     o.splitk_workspace(torch.device(DEV), 64 << 20)
     try:
@@ -459,7 +459,7 @@ def test_persistent_ping_pong_tiles_walk_past_the_cu_count_into_ragged_tail_tile
 
 
 @pytest.mark.parametrize("out_dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("tile", [14, 13, 3, 26, 40, 44, 45, 46, 47, 48, 51, 52, 53, 54])
+@pytest.mark.parametrize("tile", [14, 20, 13, 3, 26, 40, 44, 45, 46, 47, 48, 51, 52, 53, 54])
 def test_epilogue_overflow_infinity_and_nan_equal_the_oracles_rounding(out_dtype, tile):
     """The straight-line epilogues convert with V_CVT_PK_F16_F32 / V_CVT_PK_BF16_F32 (pack2_f16 / pack2_bf16) where the
     general loop uses the bit-trick conversions: both must agree with the oracle's round-to-nearest-even on results beyond the

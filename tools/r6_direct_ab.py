@@ -16,7 +16,7 @@ from mquant_amd.engine import WORKSPACE  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--pairs", default="47:53,48:54,45:51,46:52")
+    ap.add_argument("--pairs", default="53:47,54:48,51:45,52:46", help="plan tile : the tile to compare it with")
     ap.add_argument("--rounds", type=int, default=5)
     args = ap.parse_args()
     pairs = dict(tuple(int(v) for v in p.split(":")) for p in args.pairs.split(","))
