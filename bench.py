@@ -360,6 +360,8 @@ def main():
     ap.add_argument("--ttft-kv-fp8", action="store_true",
                     help="secondary lines: also report the whole-prefill TTFT with the fp8 (e4m3) KV cache read by the prefill attention "
                          "(Qwen2-VL geometries only)")
+    ap.add_argument("--no-floor-model", action="store_true",
+                    help="skip the per-shape launch timings and the floor model (profiling runs: keeps the kernel trace to the step's own launches)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the bounded secondary block (the other BASELINE configurations + the W8A8-vision line as child processes)")
     ap.add_argument("--secondary-budget", type=float, default=420.0,
@@ -671,7 +673,7 @@ def main():
         except Exception as exc:  # a report, never a reason to lose the line
             roofline["peak_sustained_measured"] = {"value": None, "how": f"failed: {exc!r}"}
 
-    if not args.tiny:
+    if not args.tiny and not args.no_floor_model:
         # per-shape launch times (each shape's GEMMs back to back from their own hipGraph, distinct weight images as in the step) and the
         # floor model beside them: mquant_amd/floor_model.py
         try:

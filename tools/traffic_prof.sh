@@ -5,7 +5,7 @@ set -euo pipefail
 GRAFT_REPO_ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"; export GRAFT_REPO_ROOT
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=$1; COMMIT=$2
-CMD="python3 bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-full-prefill"
+CMD="python3 bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-full-prefill --no-secondary --no-floor-model"
 rm -rf gpurun_out/tr; mkdir -p gpurun_out/tr $(dirname $OUT)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/tr -o f -- $CMD > gpurun_out/tr/f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/tr -o w -- $CMD > gpurun_out/tr/w.log 2>&1
