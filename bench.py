@@ -618,7 +618,7 @@ def main():
         lm_ms = timed(lm_only)
     launches = pf.gemm_launches()
     traffic, traffic_note, traffic_source, traffic_stale = None, "no PMC traffic file for this workload", None, None
-    tpath = next((pth for pth in (os.path.join(ROOT, "profiles", nm) for nm in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json"))
+    tpath = next((pth for pth in (os.path.join(ROOT, "profiles", nm) for nm in ("r6_traffic.json", "r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json"))
                   if os.path.exists(pth)), None)
     if tpath and headline and args.batch == 1 and not args.no_fuse:
         # HBM bytes per GEMM launch from the PMC passes (tools/pmc_traffic.py); counters cannot be
