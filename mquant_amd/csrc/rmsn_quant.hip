@@ -33,6 +33,7 @@ struct RqArgs {
 template <int DT>
 __global__ __launch_bounds__(RQ_THREADS) void rmsn_quant_kernel(RqArgs p)
 {
+    kernarg_warm<sizeof(RqArgs)>();                 // one scalar-load round trip for the argument block (mq_common.h)
     typedef typename Elem<DT>::T T;
     __shared__ float wsum[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
