@@ -130,14 +130,14 @@ class FullPrefill:
                 L.lin.s_x1 = s1
         if residual is None:
             return L.lin.forward(x, L.row_sel)
-        if self.calibrating or not self.fused_glue:
+        if self.calibrating or not self.fused_glue or L.lin.col_perm is not None or L.lin.w_groups is not None:
             return residual + L.lin.forward(x, L.row_sel)
         a, x0 = L.lin.quantize(x, L.row_sel)
         return L.lin.gemm_residual(a, x0, residual, L.row_sel)
 
     def _norm_lin(self, L: Layer, x: torch.Tensor, dim: int) -> torch.Tensor:
         """Linear(RMSN(x))."""
-        if self.calibrating or not self.fused_glue:
+        if self.calibrating or not self.fused_glue or L.lin.col_perm is not None:      # (--act_order engines gather their columns: quantize() only)
             return self._lin(L, F.rms_norm(x, (dim,), eps=1e-6))
         a, _ = L.lin.quantize_rmsn(x, dim, 1e-6, L.row_sel)
         return L.lin.gemm(a, None, self.dtype, L.row_sel)
@@ -152,7 +152,7 @@ class FullPrefill:
 
     def _act_lin(self, L: Layer, x: torch.Tensor, x2, act: int, residual: torch.Tensor) -> torch.Tensor:
         """residual + Linear(act(x[, x2])) for a layer with an online Hadamard."""
-        if self.calibrating or not self.fused_glue:
+        if self.calibrating or not self.fused_glue or L.lin.col_perm is not None:
             h = F.silu(x) * x2 if act == ops.ACT_SILU_MUL else x * torch.sigmoid(1.702 * x)
             return self._lin(L, h, residual)
         a, x0 = L.lin.quantize_act(x, x2, act, L.row_sel)
@@ -208,7 +208,7 @@ class FullPrefill:
                 q, k = _rope(q, self.vcos, self.vsin), _rope(k, self.vcos, self.vsin)
             Lp = by["vis.attn.proj"][i]
             if (self.vis_attn_kernel and self.fused_glue and self.attn_quant and not self.calibrating and i > 0
-                    and Lp.lin.had is None and not Lp.lin.split):
+                    and Lp.lin.had is None and not Lp.lin.split and Lp.lin.col_perm is None):
                 qa = Lp.lin.act_buffer(M_VIS)
                 ops.attn_prefill_quant_i8(q, Lp.lin.s_x0, Lp.lin.s_x1, k=k, v=v, causal=False, row_sel=Lp.row_sel, out=qa)
                 x = Lp.lin.gemm_residual(qa, None, x, Lp.row_sel)
@@ -233,7 +233,7 @@ class FullPrefill:
         for i in range(len(by["llm.q_proj"])):
             Lq = by["llm.q_proj"][i]
             rope_in_gemm = (self.fused_glue and self.rope_fused and not self.calibrating and HD == 128 and Lq.lin.had is None
-                            and not Lq.lin.split and Lq.lin.dynamic is None and Lq.lin.w_shift is None and Lq.lin.w_groups is None
+                            and not Lq.lin.split and Lq.lin.dynamic is None and Lq.lin.w_shift is None and Lq.lin.w_groups is None and Lq.lin.col_perm is None
                             and self.dtype in (torch.float16, torch.bfloat16))
             if rope_in_gemm:
                 # RMS norm -> quantize (one launch), then the fused q|k|v GEMM whose q | k heads leave the store rotated
@@ -264,7 +264,7 @@ class FullPrefill:
             # attention -> o_proj's static quantizer in ONE launch (the int8 levels of the attention output, tiled): fused
             # glue, outside calibration, o_proj without an online Hadamard / split
             quant_out = (self.fused_glue and self.attn_quant and not self.calibrating and i > 0
-                         and Lo.lin.had is None and not Lo.lin.split)
+                         and Lo.lin.had is None and not Lo.lin.split and Lo.lin.col_perm is None)
             if self.kv_fp8 and self.attn_fp8 and not self.calibrating:
                 # write the cache (e4m3, static per-head scales); the attention kernel reads those bytes
                 ops.kv_quant_fp8(kv_cols, self.kv_scales[i], out=self.kv_cache[i])
