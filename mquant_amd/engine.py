@@ -427,7 +427,10 @@ class W4A8Linear:
                 gemm=lib.mq_gemm_w4a8_ws, err=lib.mq_last_error,
                 had=None if had is None else (had.n, had.K, ops._ptr(had.bits), had.fp32_had, had.fast),
                 had_obj=had, w=self.w_img.data_ptr(), s_w=self.s_w.data_ptr(), bias=ops._ptr(self.bias), w0=ops._ptr(self.w0),
-                skip=int(self.split))
+                skip=int(self.split),
+                # the tensors whose addresses are bound: held here (their storage cannot be recycled) and compared by identity
+                # on every call, so re-assigning one of the engine's tensors re-binds instead of launching on a stale pointer
+                refs=(self.w_img, self.s_w, self.bias, self.w0, had))
         return self._fast
 
     def _forward_fast(self, f, x2: torch.Tensor, row_sel, out):
@@ -469,6 +472,10 @@ class W4A8Linear:
         f = self.__dict__.get("_fast", False)
         if f is False:
             f = self._bind_fast()
+        if f is not None:
+            r = f["refs"]
+            if not (r[0] is self.w_img and r[1] is self.s_w and r[2] is self.bias and r[3] is self.w0 and r[4] is self.had):
+                f = self._bind_fast()
         if (f is not None and f["scales"] == (self.s_x0, self.s_x1) and x2.is_cuda and x2.stride(1) == 1 and x2.dtype in ops._DT
                 and x2.device == f["dev"] and f["idx"] == torch.cuda.current_device()
                 and (row_sel is None or row_sel.is_cuda) and (out is None or out.is_cuda)):

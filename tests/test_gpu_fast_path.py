@@ -138,3 +138,15 @@ def test_act_order_engines_refuse_producer_side_entry_points():
     for fn in (lambda: eng.act_buffer(16), lambda: eng.quantize_rmsn(torch.zeros(16, 256, device=dev, dtype=torch.float16), 256, 1e-6)):
         with pytest.raises(AssertionError):
             fn()
+
+
+def test_engine_rebinds_when_one_of_its_tensors_is_replaced():
+    qu, root, wrap, args, x = _wrapped(bias=True)
+    y = wrap(x)
+    eng = wrap._real
+    eng.forward(x)                                     # bound
+    new_bias = (eng.bias + 1.0).contiguous()
+    eng.bias = new_bias                                # a different tensor object: the bound address is stale
+    y2 = eng.forward(x)
+    a, x0 = eng.quantize(x)
+    assert torch.equal(y2, eng.gemm(a, x0, x.dtype)) and not torch.equal(y2, y)
