@@ -179,3 +179,47 @@ def test_chained_prefill_logits_do_not_depend_on_where_the_activation_runs():
         fp.restore_hot_path_scales()
     assert torch.isfinite(outs[0]).all() and float(outs[0].abs().max()) > 0
     assert torch.equal(outs[0], outs[1])
+
+
+def test_random_shapes_of_the_act_store():
+    """Seeded sweep: ragged M, N / 2 any multiple of 32 (silu) or N any multiple of 8 (gelu), K any multiple of 128, W4 / W8, with and without
+    bias, token-type scales or per-row scales, every kernel family the plan can send an activation to -- against GEMM + torch ops."""
+    from mquant_amd import ops
+    rng = np.random.default_rng(20261003)
+    tiles = [-1, 14, 20, 19, 44, 45, 46, 47, 48, 51, 52, 53, 54]
+    try:
+        for case in range(60):
+            act = 1 + case % 2
+            w_bits = 8 if case % 5 == 0 else 4
+            M = int(rng.integers(65, 600))
+            N = int(rng.integers(1, 24)) * 64 if act == 1 else int(rng.integers(2, 160)) * 8
+            K = int(rng.integers(1, 6)) * 128
+            tile = int(rng.choice(tiles))
+            if w_bits == 8 and tile in (14, 20, 19, 46, 52):
+                tile = -1
+            dtype = [torch.float16, torch.bfloat16, torch.float32][case % 3]
+            g = torch.Generator(device=DEV).manual_seed(case)
+            lim = 1 << (w_bits - 1)
+            levels = torch.randint(-lim, lim, (N, K), generator=g, device=DEV, dtype=torch.int8)
+            s_w = (torch.rand((N,), generator=g, device=DEV) * (0.004 if w_bits == 4 else 0.0003) + 0.0002).float()
+            b = (torch.randn((N,), generator=g, device=DEV) * 0.3).float() if case % 3 else None
+            x = torch.from_numpy(make_x(case, (M, K))).to(DEV).half()
+            img = ops.prepack(levels, w_bits)
+            if case % 4 == 0:
+                a, s_rows, _ = ops.quantize_act_dyn_i8(x, tiled=True)
+                y = ops.gemm_w4a8_rowscale(a, img, w_bits, N, s_rows, s_w, bias=b, out_dtype=dtype)
+                kw = dict(s_x_rows=s_rows)
+                s0 = 1.0
+            else:
+                sel = (torch.arange(M, device=DEV) % 3 == 0).to(torch.uint8)
+                s0, s1 = 0.03, 0.05
+                a, _ = ops.quantize_act_i8(x, s0, s1, row_sel=sel, tiled=True)
+                y = ops.gemm_w4a8(a, img, w_bits, N, s0, s_w, s_x1=s1, row_sel=sel, bias=b, out_dtype=dtype)
+                kw = dict(s_x1=s1, row_sel=sel)
+            want = _torch_act(y, act, ops)
+            ops.gemm_debug_force(tile, 0)
+            got = ops.gemm_w4a8_act(a, img, w_bits, N, s0, s_w, act, bias=b, out_dtype=dtype, **kw)
+            ops.gemm_debug_force(-1, 0)
+            assert torch.equal(got, want), (case, act, w_bits, M, N, K, tile, dtype)
+    finally:
+        ops.gemm_debug_force(-1, 0)
