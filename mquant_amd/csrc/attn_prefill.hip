@@ -161,27 +161,26 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_prefill_kernel(AttnArgs p)
     // would touch 64 cache lines per instruction (measured: 55 us against 25 us for the e4m3 cache at the 7B shape), so
     // both tiles are loaded COALESCED -- instruction j = rows 4 j .. 4 j + 3, lane = (row, 16-byte piece) -- and K takes
     // the detour through a padded LDS tile as well.
+    // Round 6: the loads go through buffer descriptors of this KV head's column slice ([0, (T - 1) ldkv + row bytes)): one
+    // 32-bit offset per lane and block, rows past T come back as zeros from the hardware's range check -- no per-load
+    // compare / branch and no sixteen 64-bit row pointers (the first form held 32 registers of addresses and the compiler,
+    // out of registers, waited for every LDS operand right before its MFMA).
     const int v_key = KV8 ? lane >> 1 : lane >> 4, v_d = (lane & 1) * 64, pc16 = (lane & 15) * 16;
     char *kt = vt + G::VBYTES;
+    constexpr unsigned ESZ = KV8 ? 1 : 2;
+    const unsigned ldkv = (unsigned)p.ldkv, kv_bytes = (unsigned)(p.T - 1) * ldkv + HD * ESZ;   // host: (T + 32) ldkv < 2^32
+    const __amdgpu_buffer_rsrc_t k_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.k) + (long)kvh * (AT_D * ESZ), 0, kv_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.v) + (long)kvh * (AT_D * ESZ), 0, kv_bytes, 0x00020000);
+    // HD = 80: ten 16-byte pieces per row, lanes 10..15 of a row re-read piece 9 (never stored)
+    const unsigned off_k = KV8 ? (unsigned)(lane & 31) * ldkv + 64 * ko : (unsigned)v_key * ldkv + (pc16 < 2 * HD ? pc16 : 2 * HD - 16);
+    const unsigned off_v = KV8 ? (unsigned)v_key * ldkv + v_d : off_k;
     auto load_block = [&](int kb, v4i (&kraw)[NR], v4i (&vraw)[NR]) {
-        if (KV8) {
-            const long kkey = (long)kb * AT_KB + (lane & 31), vkey = (long)kb * AT_KB + v_key;
-            const uint8_t *kp = p.k + kkey * p.ldkv + (long)kvh * AT_D + 64 * ko;
-            const uint8_t *vp = p.v + vkey * p.ldkv + (long)kvh * AT_D + v_d;
+        const unsigned blk = (unsigned)kb * (AT_KB * ldkv);
 #pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                kraw[j] = kkey < p.T ? *reinterpret_cast<const v4i *>(kp + 16 * j) : v4i{0, 0, 0, 0};
-                vraw[j] = vkey < p.T ? *reinterpret_cast<const v4i *>(vp + 16 * j) : v4i{0, 0, 0, 0};
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                const long key = (long)kb * AT_KB + 4 * j + v_key;
-                const long off = key * p.ldkv + (long)kvh * AT_D * 2 + pc16;
-                const bool ok = key < p.T && pc16 < 2 * HD;               // HD = 80: ten 16-byte pieces per row, lanes 10..15 of a row idle
-                kraw[j] = ok ? *reinterpret_cast<const v4i *>(p.k + off) : v4i{0, 0, 0, 0};
-                vraw[j] = ok ? *reinterpret_cast<const v4i *>(p.v + off) : v4i{0, 0, 0, 0};
-            }
+        for (int j = 0; j < NR; ++j) {
+            const unsigned step = KV8 ? 16 * j : 4 * j * ldkv;
+            kraw[j] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(k_rs, blk + off_k + step, 0, 0));
+            vraw[j] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(v_rs, blk + off_v + step, 0, 0));
         }
     };
 
@@ -190,7 +189,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_prefill_kernel(AttnArgs p)
     const int t16 = lane & 15, g16 = (lane >> 4) & 1;
     for (int kb = wave; kb < n_blocks; kb += NW) {
         // ---- K into MFMA operands, V into this wave's LDS tile (e4m3: widened on the way) ------------------------
-        v4i Kf[KV8 ? 8 : 1];
+        v4i Kf[8];
         if (KV8) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) widen16<DT>(kraw[j], Kf[2 * j], Kf[2 * j + 1]);
@@ -221,11 +220,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_prefill_kernel(AttnArgs p)
         at_v16f S;
 #pragma unroll
         for (int e = 0; e < 16; ++e) S[e] = 0.0f;
+        if (!KV8) {                                                   // all operand reads first, then the MFMAs wait for them one by one
 #pragma unroll
-        for (int ds = 0; ds < NKS; ++ds) {
-            if (KV8) S = MM::mma(Kf[KV8 ? ds : 0], Qf[ds], S);
-            else S = MM::mma(*reinterpret_cast<const v4i *>(kt + (lane & 31) * AT_KROW + (G::HALF * ko + 8 * ds) * 2), Qf[ds], S);
+            for (int ds = 0; ds < NKS; ++ds)
+                Kf[ds] = *reinterpret_cast<const v4i *>(kt + (lane & 31) * AT_KROW + (G::HALF * ko + 8 * ds) * 2);
         }
+#pragma unroll
+        for (int ds = 0; ds < NKS; ++ds) S = MM::mma(Kf[ds], Qf[ds], S);
 
         // ---- online softmax (log2 domain); register r <-> key key0 + (r & 3) + 8 (r >> 2) + 4 ko.  The maximum is taken
         // over the raw scores (sc > 0) and the scale rides in the exponent's fma; a masked score is -1e30 BEFORE scaling,
@@ -241,7 +242,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_prefill_kernel(AttnArgs p)
         float m_raw = fmaxf(S[0], S[1]);
 #pragma unroll
         for (int r = 2; r < 16; ++r) m_raw = fmaxf(m_raw, S[r]);
-        m_raw = fmaxf(m_raw, __shfl_xor(m_raw, 32, 64));              // lane + 32 holds the other 16 keys of this query
+        {                                                             // lane + 32 holds the other 16 keys of this query: (lo, lo) and (hi, hi)
+            const auto mx = __builtin_amdgcn_permlane32_swap(__float_as_uint(m_raw), __float_as_uint(m_raw), false, false);
+            m_raw = fmaxf(__uint_as_float(mx[0]), __uint_as_float(mx[1]));
+        }
         const float m_new = fmaxf(m_run, m_raw * sc);
         float psum = 0.0f;
         unsigned pk[8];                                               // P as 16-bit pairs: pk[2 g + e2] = keys 8 g + 4 ko + 2 e2, + 1
@@ -273,6 +277,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_prefill_kernel(AttnArgs p)
             const auto x0 = __builtin_amdgcn_permlane32_swap(pk[4 * ks + 0], pk[4 * ks + 2], false, false);
             const auto x1 = __builtin_amdgcn_permlane32_swap(pk[4 * ks + 1], pk[4 * ks + 3], false, false);
             const v4i pf = v4i{(int)x0[0], (int)x1[0], (int)x0[1], (int)x1[1]};
+            v4i Af[NDT];
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
                 // A operand: row d = 32 dt + (lane & 31), keys 16 ks + 8 ko + 0..7, two transpose reads of [4 k][16 d]
@@ -285,8 +290,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_prefill_kernel(AttnArgs p)
                 const at_v4s r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                     (at_lds_v4s *)(vt + (kA + 4) * AT_VROW + ((d_lane * 2) ^ G::vswz(kA + 4))));
                 const v2i lo = __builtin_bit_cast(v2i, r0), hi = __builtin_bit_cast(v2i, r1);
-                O[dt] = MM::mma(v4i{lo[0], lo[1], hi[0], hi[1]}, pf, O[dt]);
+                Af[dt] = v4i{lo[0], lo[1], hi[0], hi[1]};
             }
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) O[dt] = MM::mma(Af[dt], pf, O[dt]);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");        // ... and the reads before the next block's stores
         __builtin_amdgcn_wave_barrier();
@@ -393,6 +400,8 @@ extern "C" int mq_attn_debug_waves(int waves)
 
 static int attn_launch(const mq::AttnArgs &a, int dtype, bool kv8, int head_dim, void *stream)
 {
+    // K / V are addressed through 32-bit buffer offsets (one block past the last row included)
+    MQ_REQUIRE((a.T + mq::AT_KB) * a.ldkv < (1L << 32), "attention: (T + 32) x the K / V row stride in bytes must stay below 4 GiB (T %ld, stride %ld bytes)", a.T, a.ldkv);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (kv8) attn_launch_t<128, true>(a, dtype, st);
     else if (head_dim == 128) attn_launch_t<128, false>(a, dtype, st);
