@@ -131,9 +131,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_prefill_kernel(AttnArgs p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // grid = (heads, query tiles): workgroups are handed out x first, so the deepest (last) query tiles of EVERY head start
     // before any shallow one (causal: a tile's work grows with its index; with the tiles in x the late heads' deep tiles
-    // waited for a second round of slots and set the launch time -- 23.2 -> 18.x us at the 7B shape)
+    // waited for a second round of slots and set the launch time -- 23.2 -> 20.3 us at the 7B shape)
     const int head = blockIdx.x, kvh = head / (p.heads / p.kv_heads);
-    const long qt = (long)gridDim.y - 1 - blockIdx.y;
+    long qt = (long)gridDim.y - 1 - blockIdx.y;
+    if (p.causal) {
+        // The first 256 workgroups take the first slot of the 256 CUs, the next 256 the second: run that second round shallow -> deep,
+        // so that the CU holding the deepest tile gets the shallowest of the middle ones (23 + 6, 22 + 7, ... instead of 23 + 14,
+        // 22 + 13, ...: every CU then carries the same number of key blocks).  Measured 20.4 -> 19.6 us (7B), 19.1 -> 17.5 us (e4m3).
+        const long rows_a = 256 / gridDim.x, r = blockIdx.y, n = gridDim.y;
+        if (rows_a > 0 && 2 * rows_a <= n && r >= rows_a && r < 2 * rows_a) qt = n - 3 * rows_a + r;
+    }
     const long q_row = qt * 32 + (lane & 31);                         // the query this lane owns (D layout: lane = column)
     const int ko = lane >> 5;                                         // lane half: d 64 ko.. of K / Q, keys + 4 ko of S, octet ko of P
     const float sc = (KV8 ? p.kv_scale[kvh] : 1.0f) * p.softmax_scale * 1.4426950408889634f;   // K scale and log2(e) folded into the score scale
@@ -379,12 +386,12 @@ static void attn_launch_t(const mq::AttnArgs &a, int dtype, hipStream_t st)
     using namespace mq;
     const dim3 grid((unsigned)a.heads, (unsigned)((a.T + 31) / 32));
     // 4-wave workgroups: two per CU (LDS, registers).  When their grid needs more than one round on those 512 slots, 2-wave
-    // workgroups (four per CU) keep more of a short prefill resident: measured on the e4m3 variant 23.3 -> 20.9 us at the 7B
-    // shape (672 workgroups) and 38.8 -> 36.6 us at the 72B shape (1536); level from ~1300 workgroups of 48 blocks on, behind
-    // at 4096 tokens; no difference on the 16-bit variant, and worse when the 4-wave grid fits one round (vision tower: 22.6 ->
-    // 32.1 us) -- tools/debug/attn_waves.py.
+    // workgroups (four per CU) keep more of a prefill resident.  Round 6 (after the grid order and the buffer loads), 4 -> 2 waves:
+    // 7B shape (672 workgroups) 18.4 -> 17.6 us on 16-bit K / V and 18.5 -> 16.0 on the e4m3 cache, 72B (1536) 31.9 -> 29.8 and
+    // 31.3 -> 26.8, 4096 tokens 230 -> 217 and 200 -> 192; worse when the 4-wave grid fits one round (512 tokens: 11.4 -> 12.7;
+    // vision tower, 512 workgroups: 18.7 -> 21.7 us) -- tools/debug/attn_waves.py.
     const long wgs = (long)grid.x * grid.y;
-    int nw = (KV8 && wgs > 512 && wgs <= 2048) ? 2 : 4;
+    int nw = (HD == 128 && wgs > 512) ? 2 : 4;
     if (g_attn_waves == 2 || g_attn_waves == 4) nw = g_attn_waves;
     if (nw == 2) {
         if (dtype == MQ_F16) hipLaunchKernelGGL((attn_prefill_kernel<MQ_F16, KV8, HD, 2>), grid, dim3(128), 0, st, a);
