@@ -31,6 +31,7 @@
 //   * the next block's K and V bytes are in flight (registers) while the current block is multiplied; the running
 //     output is rescaled only when some query's maximum actually moved.
 #include "mq_common.h"
+#include <type_traits>
 
 namespace mq {
 
@@ -56,6 +57,7 @@ struct AttnArgs {
     long q_kpad, q_ld;
     float qs0, qs1;
     const uint8_t *row_sel;
+    int deep_rows;           // grid rows that are ONE query tile (the deepest ones); the rows after them carry two (see the kernel)
 };
 
 template <int DT> struct AttnMma;
@@ -129,17 +131,33 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_prefill_kernel(AttnArgs p)
     __shared__ __attribute__((aligned(16))) char smem[NW * AT_WAVE_LDS + AT_STATS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // grid = (heads, query tiles): workgroups are handed out x first, so the deepest (last) query tiles of EVERY head start
-    // before any shallow one (causal: a tile's work grows with its index; with the tiles in x the late heads' deep tiles
-    // waited for a second round of slots and set the launch time -- 23.2 -> 20.3 us at the 7B shape)
+    // grid = (heads, rows of query tiles): workgroups are handed out x first, so the deepest (last) query tiles of EVERY head
+    // start before any shallow one (causal: a tile's work grows with its index; with the tiles in x the late heads' deep tiles
+    // waited for a second round of slots and set the launch time -- 23.2 -> 20.3 us at the 7B shape).
+    // Causal launches of 4-wave workgroups PAIR the shallow half of the tiles: rows [0, deep_rows) are the deepest tiles, keys
+    // split four ways; each row after them carries two tiles of the shallow half -- the deepest with the shallowest left, keys
+    // split two ways by a pair of waves each -- so no wave walks more than a quarter of the deepest tile's blocks and 0.75 n rows
+    // do the work of n (7B: 504 workgroups, all resident at once, instead of 672 on 512 slots).
     const int head = blockIdx.x, kvh = head / (p.heads / p.kv_heads);
-    long qt = (long)gridDim.y - 1 - blockIdx.y;
+    const long n_all = (p.T + AT_KB - 1) / AT_KB;
+    long r = blockIdx.y;
     if (p.causal) {
-        // The first 256 workgroups take the first slot of the 256 CUs, the next 256 the second: run that second round shallow -> deep,
-        // so that the CU holding the deepest tile gets the shallowest of the middle ones (23 + 6, 22 + 7, ... instead of 23 + 14,
-        // 22 + 13, ...: every CU then carries the same number of key blocks).  Measured 20.4 -> 19.6 us (7B), 19.1 -> 17.5 us (e4m3).
-        const long rows_a = 256 / gridDim.x, r = blockIdx.y, n = gridDim.y;
-        if (rows_a > 0 && 2 * rows_a <= n && r >= rows_a && r < 2 * rows_a) qt = n - 3 * rows_a + r;
+        // The first 256 workgroups take the first slot of the 256 CUs, the next 256 the second: run that second round in reverse,
+        // so that the CU holding the deepest tile gets the lightest row of the second round (every CU then carries about the same
+        // number of key blocks).  Measured 20.4 -> 19.6 us (7B), 19.1 -> 17.5 us (e4m3) before the pairing.
+        const long rows_a = 256 / gridDim.x;
+        if (rows_a > 0 && 2 * rows_a <= (long)gridDim.y && r >= rows_a && r < 2 * rows_a) r = 3 * rows_a - 1 - r;
+    }
+    int nwe = NW, wig = wave;                                         // waves that share this wave's tile, and its index among them
+    long qt = n_all - 1 - r;
+    if (r >= p.deep_rows) {
+        const long j = r - p.deep_rows, hi = n_all - p.deep_rows - 1 - j;
+        qt = hi;
+        if (hi != j) {                                                // (an odd shallow half leaves its middle tile alone)
+            nwe = NW / 2;
+            wig = wave & (NW / 2 - 1);
+            if (wave >= NW / 2) qt = j;
+        }
     }
     const long q_row = qt * 32 + (lane & 31);                         // the query this lane owns (D layout: lane = column)
     const int ko = lane >> 5;                                         // lane half: d 64 ko.. of K / Q, keys + 4 ko of S, octet ko of P
@@ -163,7 +181,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_prefill_kernel(AttnArgs p)
         for (int e = 0; e < 16; ++e) O[dt][e] = 0.0f;
     float m_run = -1.0e30f, l_run = 0.0f;                              // log2 domain
 
-    long n_all = (p.T + AT_KB - 1) / AT_KB;
     const int n_blocks = (int)((p.causal && qt + 1 < n_all) ? qt + 1 : n_all);
 
     // A lane's loads for one block.  e4m3: K -- the 64 bytes d 64 ko.. of key (lane & 31), straight into its MFMA operands;
@@ -195,9 +212,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_prefill_kernel(AttnArgs p)
     };
 
     v4i kraw[NR], vraw[NR];
-    if (wave < n_blocks) load_block(wave, kraw, vraw);
+    if (wig < n_blocks) load_block(wig, kraw, vraw);
     const int t16 = lane & 15, g16 = (lane >> 4) & 1;
-    for (int kb = wave; kb < n_blocks; kb += NW) {
+    for (int kb = wig; kb < n_blocks; kb += nwe) {
         // ---- K into MFMA operands, V into this wave's LDS tile (e4m3: widened on the way) ------------------------
         v4i Kf[8];
         if (KV8) {
@@ -223,7 +240,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_prefill_kernel(AttnArgs p)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-        if (kb + NW < n_blocks) load_block(kb + NW, kraw, vraw);      // in flight during this block's arithmetic
+        if (kb + nwe < n_blocks) load_block(kb + nwe, kraw, vraw);      // in flight during this block's arithmetic
         const long key0 = (long)kb * AT_KB;
 
         // ---- S^T = K Q^T : [32 keys][32 queries] ----------------------------------------------------------------
@@ -322,29 +339,32 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_prefill_kernel(AttnArgs p)
         stats[(wave * 32 + lane) * 2 + 1] = l_run;
     }
     __syncthreads();
+    auto finish = [&](auto nwe_c) {
+    constexpr int NWE = decltype(nwe_c)::value;
+    const int g0 = wave - wig;                                        // first wave of this tile
     float M = -1.0e30f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) M = fmaxf(M, stats[(w * 32 + (lane & 31)) * 2]);
-    float L = 0.0f, fw[NW];
+    for (int w = 0; w < NWE; ++w) M = fmaxf(M, stats[((g0 + w) * 32 + (lane & 31)) * 2]);
+    float L = 0.0f, fw[NWE];
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-        fw[w] = __builtin_amdgcn_exp2f(stats[(w * 32 + (lane & 31)) * 2] - M);
-        L += stats[(w * 32 + (lane & 31)) * 2 + 1] * fw[w];
+    for (int w = 0; w < NWE; ++w) {
+        fw[w] = __builtin_amdgcn_exp2f(stats[((g0 + w) * 32 + (lane & 31)) * 2] - M);
+        L += stats[((g0 + w) * 32 + (lane & 31)) * 2 + 1] * fw[w];
     }
     const float f = L > 0.0f ? s_v / L : 0.0f;
     const float qs = (p.qout && p.row_sel && q_row < p.T && p.row_sel[q_row]) ? p.qs1 : p.qs0;
     const float qinv = 1.0f / qs;
     const bool qrcp = quant_rcp_ok(qs);
 #pragma unroll
-    for (int dt0 = 0; dt0 < NDT; dt0 += NW) {
-        const int dt = dt0 + wave;                                    // wave-uniform
+    for (int dt0 = 0; dt0 < NDT; dt0 += NWE) {
+        const int dt = dt0 + wig;                                    // wave-uniform
         if (dt >= NDT) break;                                         // HD = 80: three d-tiles
         float acc[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const float *src = reinterpret_cast<const float *>(smem + w * AT_WAVE_LDS) + dt * 16 * 64 + lane;
+        for (int w = 0; w < NWE; ++w) {
+            const float *src = reinterpret_cast<const float *>(smem + (g0 + w) * AT_WAVE_LDS) + dt * 16 * 64 + lane;
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] += src[e * 64] * fw[w];
         }
@@ -374,25 +394,39 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_prefill_kernel(AttnArgs p)
             }
         }
     }
+    };
+    if (nwe == NW) finish(std::integral_constant<int, NW>());
+    else finish(std::integral_constant<int, NW / 2>());
 }
 
 }  // namespace mq
 
-static thread_local int g_attn_waves = 0;      // TEST-ONLY (mq_attn_debug_waves): 0 = by shape, 2 / 4 = forced
+static thread_local int g_attn_waves = 0;      // TEST-ONLY (mq_attn_debug_waves): 0 = by shape, 2 / 4 = forced, 5 = 4 waves without the tile pairing
 
 template <int HD, bool KV8>
-static void attn_launch_t(const mq::AttnArgs &a, int dtype, hipStream_t st)
+static void attn_launch_t(mq::AttnArgs a, int dtype, hipStream_t st)
 {
     using namespace mq;
-    const dim3 grid((unsigned)a.heads, (unsigned)((a.T + 31) / 32));
+    const long n = (a.T + AT_KB - 1) / AT_KB;
     // 4-wave workgroups: two per CU (LDS, registers).  When their grid needs more than one round on those 512 slots, 2-wave
     // workgroups (four per CU) keep more of a prefill resident.  Round 6 (after the grid order and the buffer loads), 4 -> 2 waves:
     // 7B shape (672 workgroups) 18.4 -> 17.6 us on 16-bit K / V and 18.5 -> 16.0 on the e4m3 cache, 72B (1536) 31.9 -> 29.8 and
     // 31.3 -> 26.8, 4096 tokens 230 -> 217 and 200 -> 192; worse when the 4-wave grid fits one round (512 tokens: 11.4 -> 12.7;
     // vision tower, 512 workgroups: 18.7 -> 21.7 us) -- tools/debug/attn_waves.py.
-    const long wgs = (long)grid.x * grid.y;
-    int nw = (HD == 128 && wgs > 512) ? 2 : 4;
-    if (g_attn_waves == 2 || g_attn_waves == 4) nw = g_attn_waves;
+    // Causal launches whose 4-wave grid misses one round but fits it with the shallow half of the tiles PAIRED (see the kernel:
+    // 0.75 n rows) take that form: 7B shape 672 -> 504 workgroups, 18.2 (unpaired) / 17.3 (2 waves) -> 16.2 us, e4m3 18.6 / 16.1 ->
+    // 15.6; a grid that fits anyway is better left alone (512 tokens: 11.6 -> 13.5 paired), a larger one goes to 2 waves (72B: 28.8
+    // against 32.3 paired).
+    const long rows_paired = n / 2 + (n - n / 2 + 1) / 2;
+    const bool fits = a.heads * n <= 512, fits_paired = a.causal && n >= 2 && a.heads * rows_paired <= 512;
+    int nw = (HD == 128 && !fits && !fits_paired) ? 2 : 4;
+    bool pair = !fits && fits_paired;
+    if (g_attn_waves == 2 || g_attn_waves == 4 || g_attn_waves == 5) {
+        nw = g_attn_waves == 2 ? 2 : 4;
+        pair = g_attn_waves == 4 && a.causal && n >= 2;
+    }
+    a.deep_rows = (int)(pair ? n / 2 : n);
+    const dim3 grid((unsigned)a.heads, (unsigned)(pair ? rows_paired : n));
     if (nw == 2) {
         if (dtype == MQ_F16) hipLaunchKernelGGL((attn_prefill_kernel<MQ_F16, KV8, HD, 2>), grid, dim3(128), 0, st, a);
         else hipLaunchKernelGGL((attn_prefill_kernel<MQ_BF16, KV8, HD, 2>), grid, dim3(128), 0, st, a);
