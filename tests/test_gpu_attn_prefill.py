@@ -218,6 +218,55 @@ def test_both_workgroup_widths_give_the_same_attention(waves, variant, T, H, HKV
     assert float((got.double() - want).abs().max() / want.abs().max()) < 2.5e-3
 
 
+@pytest.mark.parametrize("variant", ["fp16", "bf16", "fp8"])
+@pytest.mark.parametrize("T", [33, 64, 65, 97, 160, 161, 352, 1000])
+def test_paired_shallow_tiles_cover_every_tile_count(variant, T):
+    """Causal launches may give a workgroup TWO query tiles of the shallow half (round 6; taken by shape at the 7B prefill, forced
+    here through the test hook: 4 = paired, 5 = one tile per workgroup).  Tile counts 2, 3, 5, 6, 11 and 32 walk every branch of
+    the row map -- an odd shallow half leaves its middle tile alone --; ragged last tiles; each form against the float64 checker,
+    and the fused int8 store against attention-then-quantize under the pairing."""
+    from mquant_amd import ops
+    from mquant_amd._lib import call
+    H, HKV, D = 6, 2, 128
+    dtype = torch.bfloat16 if variant == "bf16" else torch.float16
+    g = torch.Generator(device=DEV).manual_seed(T)
+    qkv = (torch.randn(T, (H + 2 * HKV) * D, generator=g, device=DEV) * 0.9).to(dtype)
+    q = qkv[:, :H * D].view(T, H, D)
+    k = qkv[:, H * D:(H + HKV) * D].view(T, HKV, D)
+    v = qkv[:, (H + HKV) * D:].view(T, HKV, D)
+    out = {}
+    try:
+        for hook in (4, 5):
+            call("mq_attn_debug_waves", hook)
+            if variant == "fp8":
+                kv = qkv[:, H * D:].view(T, 2 * HKV, D)
+                scale = ops.kv_scale_from_absmax(kv)
+                cache = ops.kv_quant_fp8(kv, scale)
+                out[hook] = ops.attn_prefill_fp8kv(q, cache, scale, causal=True)
+                want = _ref(q, cache, scale, True)
+                kw = dict(kv_cache=cache, kv_scale=scale)
+            else:
+                out[hook] = ops.attn_prefill(q, k, v, causal=True)
+                s = torch.einsum("thd,hkd->htk", q.double(), k.double().repeat_interleave(H // HKV, 1).permute(1, 0, 2)) * D ** -0.5
+                s = s.masked_fill(torch.ones(T, T, device=DEV, dtype=torch.bool).triu(1), float("-inf"))
+                want = (torch.softmax(s, dim=-1) @ v.double().repeat_interleave(H // HKV, 1).permute(1, 0, 2)).permute(1, 0, 2).reshape(T, H * D)
+                kw = dict(k=k, v=v)
+            tol = 1.6e-2 if variant == "bf16" else 2.5e-3
+            assert float((out[hook].double() - want).abs().max() / want.abs().max()) < tol, hook
+            if hook == 4:
+                s0 = float(out[4].float().abs().max()) / 127.0 * 0.8
+                sel = (torch.arange(T, device=DEV) % 2).to(torch.uint8)
+                lv, _ = ops.quantize_act_i8(out[4], s0, 0.5 * s0, row_sel=sel, tiled=True)
+                fused = ops.attn_prefill_quant_i8(q, s0, 0.5 * s0, causal=True, row_sel=sel, tiled=True, **kw)
+                assert torch.equal(fused.to_rows(), lv.to_rows())
+    finally:
+        call("mq_attn_debug_waves", 0)
+    # the deepest half of the tiles takes the same path in both forms: identical bits there
+    n = (T + 31) // 32
+    deep_from = (n - n // 2) * 32
+    assert torch.equal(out[4][deep_from:], out[5][deep_from:])
+
+
 def test_size_independent_properties_at_full_size():
     """Properties that need no checker: (i) scaling V by a power of two scales the output exactly (the V scale rides in the
     output scale / the values themselves, the softmax does not see it); (ii) a query whose keys all carry the same V row
