@@ -126,7 +126,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_prefill_kernel(AttnArgs p)
     typedef AttnGeo<HD> G;
     static_assert(HD == 128 || (HD == 80 && !KV8), "head dimensions built: 128, and 80 for 16-bit K / V");
     constexpr int NKS = G::NKS, NDT = G::NDT, AT_D = HD, AT_VROW = G::VROW, AT_KROW = G::KROW, AT_WAVE_LDS = G::WAVE_LDS;
-    constexpr int NR = KV8 ? 4 : 8;                                   // 16-byte loads per lane and operand and block
+    constexpr int NR = KV8 ? 4 : (HD == 80 ? 5 : 8);                  // 16-byte loads per lane and operand and block
     typedef AttnMma<DT> MM;
     __shared__ __attribute__((aligned(16))) char smem[NW * AT_WAVE_LDS + AT_STATS];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -198,16 +198,28 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_prefill_kernel(AttnArgs p)
     const unsigned ldkv = (unsigned)p.ldkv, kv_bytes = (unsigned)(p.T - 1) * ldkv + HD * ESZ;   // host: (T + 32) ldkv < 2^32
     const __amdgpu_buffer_rsrc_t k_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.k) + (long)kvh * (AT_D * ESZ), 0, kv_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t v_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.v) + (long)kvh * (AT_D * ESZ), 0, kv_bytes, 0x00020000);
-    // HD = 80: ten 16-byte pieces per row, lanes 10..15 of a row re-read piece 9 (never stored)
-    const unsigned off_k = KV8 ? (unsigned)(lane & 31) * ldkv + 64 * ko : (unsigned)v_key * ldkv + (pc16 < 2 * HD ? pc16 : 2 * HD - 16);
+    // HD = 80: a row is ten 16-byte pieces, a block 320 of them -- five instructions with every lane busy (instruction j, lane l:
+    // piece 64 j + l = row (64 j + l) / 10, piece (64 j + l) % 10) instead of eight with ten lanes in sixteen
+    const unsigned off_k = KV8 ? (unsigned)(lane & 31) * ldkv + 64 * ko : (unsigned)v_key * ldkv + pc16;
     const unsigned off_v = KV8 ? (unsigned)v_key * ldkv + v_d : off_k;
+    unsigned off80[HD == 80 ? 5 : 1];
+    int lds80[HD == 80 ? 5 : 1];                                      // row * 16 + piece of the same five pieces
+    if (HD == 80) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int idx = 64 * j + lane, row = idx / 10, piece = idx - 10 * row;
+            off80[j] = (unsigned)row * ldkv + 16 * piece;
+            lds80[j] = row * 16 + piece;
+        }
+    }
     auto load_block = [&](int kb, v4i (&kraw)[NR], v4i (&vraw)[NR]) {
         const unsigned blk = (unsigned)kb * (AT_KB * ldkv);
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             const unsigned step = KV8 ? 16 * j : 4 * j * ldkv;
-            kraw[j] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(k_rs, blk + off_k + step, 0, 0));
-            vraw[j] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(v_rs, blk + off_v + step, 0, 0));
+            const unsigned ok = HD == 80 ? blk + off80[HD == 80 ? j : 0] : blk + off_k + step, ov = HD == 80 ? ok : blk + off_v + step;
+            kraw[j] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(k_rs, ok, 0, 0));
+            vraw[j] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(v_rs, ov, 0, 0));
         }
     };
 
@@ -228,14 +240,21 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_prefill_kernel(AttnArgs p)
                 *reinterpret_cast<v4i *>(vt + v_key * AT_VROW + col) = a;
                 *reinterpret_cast<v4i *>(vt + v_key * AT_VROW + col + 16) = b;
             }
+        } else if (HD == 80) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int r = lds80[HD == 80 ? j : 0] >> 4, pc = (lds80[HD == 80 ? j : 0] & 15) * 16;
+                *reinterpret_cast<v4i *>(kt + r * AT_KROW + pc) = kraw[j % NR];
+                *reinterpret_cast<v4i *>(vt + r * AT_VROW + pc) = vraw[j % NR];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int r = 4 * j + v_key;
-                if (pc16 < 2 * HD) {
-                    *reinterpret_cast<v4i *>(kt + r * AT_KROW + pc16) = kraw[j & (NR - 1)];
-                    *reinterpret_cast<v4i *>(vt + r * AT_VROW + (pc16 ^ G::vswz(r))) = vraw[j & (NR - 1)];
-                }
+                *reinterpret_cast<v4i *>(kt + r * AT_KROW + pc16) = kraw[j % NR];
+                *reinterpret_cast<v4i *>(vt + r * AT_VROW + (pc16 ^ G::vswz(r))) = vraw[j % NR];
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
