@@ -498,11 +498,19 @@ def main():
         per = specs[-1].M // B_local
         last_rows = torch.arange(1, B_local + 1, device=dev) * per - 1
 
+    def lm_logits(h):
+        # the unquantized lm_head on the last position(s): mq_gemv_f16 streams the weights once (6.8 TB/s where hipBLASLt's kernel for
+        # the shape reaches 5.0); more than 8 rows per rank go to torch.matmul
+        if h.shape[0] <= 8 and h.shape[0] * hidden * 2 <= 65536:
+            ops.gemv_f16(h, lm_head, out=logits_step)
+        else:
+            torch.matmul(h, lm_head.t(), out=logits_step)
+
     def hot_path_and_logits():
         y = pf.step()                    # [M, hidden]: output of the last Linear of the step (down_proj)
         if with_logits:
             h = torch.nn.functional.rms_norm(y[-1:] if last_rows is None else y.index_select(0, last_rows), (hidden,), eps=1e-6)
-            torch.matmul(h, lm_head.t(), out=logits_step)
+            lm_logits(h)
         return y
 
     run_step = capture(hot_path_and_logits)
@@ -614,7 +622,7 @@ def main():
 
         def lm_only():
             h = torch.nn.functional.rms_norm(last_row, (hidden,), eps=1e-6)
-            torch.matmul(h, lm_head.t(), out=logits_step)
+            lm_logits(h)
         lm_ms = timed(lm_only)
     launches = pf.gemm_launches()
     traffic, traffic_note, traffic_source, traffic_stale = None, "no PMC traffic file for this workload", None, None

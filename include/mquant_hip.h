@@ -336,6 +336,14 @@ int mq_attn_prefill_quant_i8(const void *q, int dtype, long T, int heads, int kv
                              const float *kv_scale, float softmax_scale, int causal, float scale0, float scale1,
                              const uint8_t *row_sel, int8_t *out, long K_pad, long ldo, void *stream);
 
+/* out[m][n] = sum_k x[m][k] * W[n][k], 16-bit x ([M <= 8, K], ldx elements per row) and W ([N, K], ldw), fp32 products and sums,
+ * one rounding to the same 16-bit dtype: the UNQUANTIZED lm_head on the last position(s) of a prefill (the reference leaves
+ * lm_head in 16 bits: exam/quant_qwen2vl.py:130-143 wraps the decoder's and the vision tower's Linears only; HF computes
+ * logits = lm_head(hidden[:, -1:])).  Glue of the whole-prefill report, replaces torch.matmul (hipBLASLt) there: W is
+ * streamed once at the chip's HBM rate.  K a multiple of 8, rows 16-byte aligned, M * K * 2 bytes <= 64 KiB. */
+int mq_gemv_f16(const void *x, int dtype, int M, long K, long ldx, const void *w, long N, long ldw, void *out, long ldo,
+                void *stream);
+
 
 /* ---------------------------------------------------------------------------
  * GPTQ: the column loop of one lazy-batch block, gptq/gptq_utils.py:258-279 (symmetric

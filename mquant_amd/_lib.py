@@ -61,6 +61,7 @@ SIGNATURES = {
     "mq_kv_dequant_fp8": (_i, [_vp, _l, _i, _i, _l, _vp, _vp, _i, _l, _vp]),
     "mq_attn_prefill_fp8kv": (_i, [_vp, _i, _l, _i, _i, _i, _l, _vp, _l, _vp, _f, _i, _vp, _l, _vp]),
     "mq_attn_debug_waves": (_i, [_i]),
+    "mq_gemv_f16": (_i, [_vp, _i, _i, _l, _l, _vp, _l, _l, _vp, _l, _vp]),
     "mq_attn_prefill": (_i, [_vp, _i, _l, _i, _i, _i, _l, _vp, _vp, _l, _f, _i, _vp, _l, _vp]),
     "mq_attn_prefill_quant_i8": (_i, [_vp, _i, _l, _i, _i, _i, _l, _vp, _vp, _l, _vp, _l, _vp, _f, _i, _f, _f, _vp, _vp, _l, _l, _vp]),
     "mq_gptq_block": (_i, [_vp, _l, _i, _l, _vp, _l, _vp, _i, _vp, _l, _vp, _l, _vp]),

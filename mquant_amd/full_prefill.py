@@ -308,5 +308,5 @@ class FullPrefill:
                 half = gu.shape[1] // 2
                 hdn = self._act_lin(by["llm.down_proj"][i], gu[:, :half], gu[:, half:], ops.ACT_SILU_MUL, residual=hdn)
         last = F.rms_norm(hdn[-1:], (D,), eps=1e-6)
-        self.logits = last @ self.lm_head.t()
+        self.logits = ops.gemv_f16(last, self.lm_head)           # the 16-bit lm_head on one row: an HBM stream (mq_gemv_f16)
         return self.logits

@@ -517,6 +517,23 @@ def attn_prefill(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool
 
 
 @_on_device
+def gemv_f16(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """``x @ w.t()`` for a few rows x ([M <= 8, K]) against a large 16-bit matrix w ([N, K]) of the same fp16 / bf16 dtype
+    (``mq_gemv_f16``): the unquantized lm_head on the last position(s) -- w is streamed once at the chip's HBM rate, fp32
+    products and sums, one rounding.  Returns [M, N]."""
+    _need_cuda(x, w, out)
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and w.dtype == x.dtype and x.stride(1) == 1 and w.stride(1) == 1
+    if out is None:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    assert out.dtype == x.dtype and out.shape == (M, N) and out.stride(1) == 1
+    call("mq_gemv_f16", x.data_ptr(), dtype_code(x.dtype), M, K, x.stride(0) if M > 1 else K, w.data_ptr(), N,
+         w.stride(0) if N > 1 else K, out.data_ptr(), out.stride(0) if M > 1 else N, _stream())
+    return out
+
+
+@_on_device
 def attn_prefill_quant_i8(q: torch.Tensor, scale0: float, scale1: Optional[float] = None, *, k: torch.Tensor = None,
                           v: torch.Tensor = None, kv_cache: torch.Tensor = None, kv_scale: torch.Tensor = None,
                           causal: bool = True, softmax_scale: float = None, row_sel: Optional[torch.Tensor] = None,
