@@ -58,6 +58,8 @@ struct AttnArgs {
     float qs0, qs1;
     const uint8_t *row_sel;
     int deep_rows;           // grid rows that are ONE query tile (the deepest ones); the rows after them carry two (see the kernel)
+    float qi0, qi1;          // 1 / qs0, 1 / qs1 (IEEE, from the host) and whether the reciprocal form may be used (quant_rcp_ok)
+    int qr0, qr1;
 };
 
 template <int DT> struct AttnMma;
@@ -160,6 +162,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_prefill_kernel(AttnArgs p)
         }
     }
     const long q_row = qt * 32 + (lane & 31);                         // the query this lane owns (D layout: lane = column)
+    // the token-type flag of this row (fused int8 store), requested here rather than after the merge where it is used (a cold
+    // byte load on the workgroup's tail; launch time unchanged within the harness's resolution -- other workgroups fill the CU)
+    const unsigned sel = (p.qout && p.row_sel && q_row < p.T) ? p.row_sel[q_row] : 0;
     const int ko = lane >> 5;                                         // lane half: d 64 ko.. of K / Q, keys + 4 ko of S, octet ko of P
     const float sc = (KV8 ? p.kv_scale[kvh] : 1.0f) * p.softmax_scale * 1.4426950408889634f;   // K scale and log2(e) folded into the score scale
     const float s_v = KV8 ? p.kv_scale[p.kv_heads + kvh] : 1.0f;
@@ -371,9 +376,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_prefill_kernel(AttnArgs p)
         L += stats[((g0 + w) * 32 + (lane & 31)) * 2 + 1] * fw[w];
     }
     const float f = L > 0.0f ? s_v / L : 0.0f;
-    const float qs = (p.qout && p.row_sel && q_row < p.T && p.row_sel[q_row]) ? p.qs1 : p.qs0;
-    const float qinv = 1.0f / qs;
-    const bool qrcp = quant_rcp_ok(qs);
+    const float qs = sel ? p.qs1 : p.qs0, qinv = sel ? p.qi1 : p.qi0;
+    const bool qrcp = (sel ? p.qr1 : p.qr0) != 0;
 #pragma unroll
     for (int dt0 = 0; dt0 < NDT; dt0 += NWE) {
         const int dt = dt0 + wig;                                    // wave-uniform
@@ -389,17 +393,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_prefill_kernel(AttnArgs p)
         }
         if (q_row >= p.T) continue;
         if (p.qout) {
+            // the sixteen levels of this lane in one go (quant_levels_i8_packed: the levels of quant_levels by construction, one
+            // rarely-taken branch, packed by v_perm; 1 / s and the reciprocal-form flag come from the host)
+            float v16[16];
+            unsigned w4[4];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v16[e] = Elem<DT>::rnd(acc[e] * f);               // the 16-bit value the unfused path stores
+            quant_levels_i8_packed<16>(v16, qs, qinv, qrcp, w4);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (dt * 32 + 8 * g >= HD) break;                     // HD = 80: the last tile holds d 64 .. 79 only
-                float v4[4];
-                int q4[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v4[e] = Elem<DT>::rnd(acc[4 * g + e] * f);      // the 16-bit value the unfused path stores
-                quant_levels<4>(v4, qs, qinv, qrcp, -128.0f, 127.0f, q4);
                 const long col = (long)head * AT_D + dt * 32 + 8 * g + 4 * ko;
-                *reinterpret_cast<unsigned *>(p.qout + act_offset(q_row, col, p.q_kpad, p.q_ld)) =
-                    (q4[0] & 0xff) | ((q4[1] & 0xff) << 8) | ((q4[2] & 0xff) << 16) | ((unsigned)(q4[3] & 0xff) << 24);
+                *reinterpret_cast<unsigned *>(p.qout + act_offset(q_row, col, p.q_kpad, p.q_ld)) = w4[g];
             }
         } else {
             unsigned short *o = reinterpret_cast<unsigned short *>(p.out) + q_row * p.ldo + (long)head * AT_D + dt * 32;
@@ -538,6 +543,7 @@ extern "C" int mq_attn_prefill_quant_i8(const void *q, int dtype, long T, int he
     AttnArgs a{};
     a.q = q; a.out = nullptr; a.T = T; a.ldq = ldq; a.ldo = 0; a.heads = heads; a.kv_heads = kv_heads; a.causal = causal ? 1 : 0;
     a.softmax_scale = softmax_scale; a.qout = out; a.q_kpad = K_pad; a.q_ld = ldo; a.qs0 = scale0; a.qs1 = scale1; a.row_sel = row_sel;
+    a.qi0 = 1.0f / scale0; a.qi1 = 1.0f / scale1; a.qr0 = quant_rcp_ok(scale0) ? 1 : 0; a.qr1 = quant_rcp_ok(scale1) ? 1 : 0;
     if (kv8) {
         MQ_REQUIRE(ld_cache >= 2L * kv_heads * D && ((uintptr_t)kv_cache) % 16 == 0 && ld_cache % 16 == 0, "mq_attn_prefill_quant_i8: bad cache geometry");
         a.k = kv_cache; a.v = kv_cache + (long)kv_heads * D; a.kv_scale = kv_scale; a.ldkv = ld_cache;
