@@ -267,6 +267,48 @@ def test_paired_shallow_tiles_cover_every_tile_count(variant, T):
     assert torch.equal(out[4][deep_from:], out[5][deep_from:])
 
 
+def test_random_shapes_through_every_launch_form():
+    """Seeded sweep over token counts, head geometries, causal / not, the three K / V forms and the four launch forms (by shape, 2 waves,
+    4 waves with paired shallow tiles, 4 waves unpaired): the row map of the grid -- heads in x, second round reversed, paired rows -- must
+    visit every (head, query tile) exactly once whatever the counts are; each result against the float64 checker."""
+    from mquant_amd import ops
+    from mquant_amd._lib import call
+    rng = np.random.default_rng(20260)
+    try:
+        for case in range(36):
+            D = 80 if case % 6 == 5 else 128
+            HKV = int(rng.choice([1, 2, 4, 8]))
+            H = HKV * int(rng.choice([1, 2, 7]))
+            T = int(rng.choice([1, 31, 32, 63, 64, 96, 127, 192, 250, 383, 640, 900, 1111]))
+            causal = bool(rng.integers(0, 2))
+            variant = "fp16" if D == 80 else str(rng.choice(["fp16", "bf16", "fp8"]))
+            hook = int(rng.choice([0, 2, 4, 5]))
+            dtype = torch.bfloat16 if variant == "bf16" else torch.float16
+            g = torch.Generator(device=DEV).manual_seed(1000 + case)
+            qkv = (torch.randn(T, (H + 2 * HKV) * D, generator=g, device=DEV) * 0.9).to(dtype)
+            q = qkv[:, :H * D].view(T, H, D)
+            k = qkv[:, H * D:(H + HKV) * D].view(T, HKV, D)
+            v = qkv[:, (H + HKV) * D:].view(T, HKV, D)
+            call("mq_attn_debug_waves", hook)
+            if variant == "fp8":
+                kv = qkv[:, H * D:].view(T, 2 * HKV, D)
+                scale = ops.kv_scale_from_absmax(kv)
+                cache = ops.kv_quant_fp8(kv, scale)
+                got = ops.attn_prefill_fp8kv(q, cache, scale, causal=causal)
+                want = _ref(q, cache, scale, causal)
+            else:
+                got = ops.attn_prefill(q, k, v, causal=causal)
+                s = torch.einsum("thd,hkd->htk", q.double(), k.double().repeat_interleave(H // HKV, 1).permute(1, 0, 2)) * D ** -0.5
+                if causal:
+                    s = s.masked_fill(torch.ones(T, T, device=DEV, dtype=torch.bool).triu(1), float("-inf"))
+                want = (torch.softmax(s, dim=-1) @ v.double().repeat_interleave(H // HKV, 1).permute(1, 0, 2)).permute(1, 0, 2).reshape(T, H * D)
+            tol = 1.6e-2 if variant == "bf16" else 2.5e-3
+            err = float((got.double() - want).abs().max() / want.abs().max())
+            assert err < tol, (case, T, H, HKV, D, causal, variant, hook, err)
+    finally:
+        call("mq_attn_debug_waves", 0)
+
+
 def test_size_independent_properties_at_full_size():
     """Properties that need no checker: (i) scaling V by a power of two scales the output exactly (the V scale rides in the
     output scale / the values themselves, the softmax does not see it); (ii) a query whose keys all carry the same V row
