@@ -16,8 +16,8 @@
 //
 // A prefill of a few hundred tokens is a LATENCY problem (4 GFLOP for the 7B model's 768 tokens): one workgroup =
 // 32 query rows of one head, and its 4 waves SPLIT THE KEYS (wave w takes the 32-key blocks w, w + 4, ...), each with
-// its own running softmax statistics, merged through LDS at the end -- 672 workgroups with a critical path of 6
-// blocks instead of 168 with a critical path of 24.  Waves never synchronise inside the key loop:
+// its own running softmax statistics, merged through LDS at the end -- 672 workgroups (504 with the shallow tiles paired)
+// with a critical path of 6 blocks instead of 168 with a critical path of 24.  Waves never synchronise inside the key loop:
 //   * S is computed TRANSPOSED (keys x queries, V_MFMA_F32_32X32X16_F16/_BF16 with A = K rows, B = Q^T): in the D
 //     layout a lane then holds ONE query column and 16 keys in registers, so the softmax statistics of a query are
 //     lane-local (one exchange with lane + 32 for the other half of the keys) instead of 5-step shuffles per row;
@@ -30,6 +30,10 @@
 //     [4 k][16 d] block, lane t receives V[k0..k0+3][d0 + t]; tools/probes/ds_read_tr.hip);
 //   * the next block's K and V bytes are in flight (registers) while the current block is multiplied; the running
 //     output is rescaled only when some query's maximum actually moved.
+// Round 6 (profiles/r6_attention_rework.txt): K / V arrive through buffer descriptors (hardware range check, one 32-bit offset per
+// lane); the grid is (heads, rows of query tiles) with the deepest tiles of every head first, the second round of a causal launch
+// reversed, and -- where that brings a causal grid into one round of slots -- the shallow half of the tiles paired two to a
+// workgroup; launches beyond one round take 2-wave workgroups (attn_launch_t).
 #include "mq_common.h"
 #include <type_traits>
 
